@@ -1,0 +1,190 @@
+"""ctypes view of the C-ABI in include/nsparse.h.
+
+This is the binding a Python caller of the reference would write against nsparse.h; it is
+plumbing for tests/ and bench.py, not the product.  The product is libnsparse_{d,s}.so.
+The library must exist: there is NO fallback of any kind (no CPU path, no oracle import).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, "lib")
+
+c_int_p = C.POINTER(C.c_int)
+c_uint_p = C.POINTER(C.c_uint)
+c_ushort_p = C.POINTER(C.c_ushort)
+
+
+class sfPlan(C.Structure):
+    _fields_ = [("thread_grid", C.c_size_t), ("thread_block", C.c_size_t), ("isPlan", C.c_int),
+                ("SIGMA", C.c_int), ("seg_size", C.c_size_t), ("seg_num", C.c_size_t),
+                ("block_size", C.c_int)]
+
+
+class sfCSR(C.Structure):
+    _fields_ = [("rpt", c_int_p), ("col", c_int_p), ("val", C.c_void_p),
+                ("d_rpt", C.c_void_p), ("d_col", C.c_void_p), ("d_val", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("nnz", C.c_int), ("nnz_max", C.c_int),
+                ("matrix_name", C.c_char_p)]
+
+
+class sfAMB(C.Structure):
+    _fields_ = [("cs", c_int_p), ("cl", c_uint_p), ("sellcs_col", c_ushort_p), ("sellcs_val", C.c_void_p),
+                ("s_write_permutation", c_ushort_p), ("s_write_permutation_offset", c_ushort_p),
+                ("write_permutation", c_int_p),
+                ("d_cs", C.c_void_p), ("d_cl", C.c_void_p), ("d_sellcs_col", C.c_void_p),
+                ("d_sellcs_val", C.c_void_p), ("d_s_write_permutation", C.c_void_p),
+                ("d_s_write_permutation_offset", C.c_void_p), ("d_write_permutation", C.c_void_p),
+                ("block_size", C.c_int), ("nnz", C.c_int), ("M", C.c_int), ("N", C.c_int),
+                ("pad_M", C.c_int), ("chunk", C.c_int), ("SIGMA", C.c_int), ("group_num_col", C.c_int),
+                ("nnz_max", C.c_int), ("c_size", C.c_int), ("seg_size", C.c_size_t),
+                ("seg_num", C.c_size_t), ("matrix_name", C.c_char_p)]
+
+
+class SpgemmStats(C.Structure):
+    _fields_ = [("n_prod", C.c_longlong), ("nnz_c", C.c_int), ("max_prod_row", C.c_int),
+                ("max_nnz_row", C.c_int), ("sym_bin_size", C.c_int * 8), ("num_bin_size", C.c_int * 8),
+                ("sym_fail_rows", C.c_int), ("ms_setup", C.c_float), ("ms_symbolic", C.c_float),
+                ("ms_numeric", C.c_float), ("ms_total", C.c_float), ("ms_sym_bin", C.c_float * 8),
+                ("ms_num_bin", C.c_float * 8)]
+
+
+# every entry point declared in include/nsparse.h: name -> (restype, argtypes)
+_P = C.POINTER
+SIGNATURES = {
+    "init_vector": (None, [C.c_void_p, C.c_int]),
+    "init_csr_matrix_from_file": (None, [_P(sfCSR), C.c_char_p]),
+    "csr_memcpy": (None, [_P(sfCSR)]),
+    "csr_memcpyDtH": (None, [_P(sfCSR)]),
+    "release_cpu_csr": (None, [sfCSR]),
+    "release_cpu_amb": (None, [sfAMB]),
+    "release_csr": (None, [sfCSR]),
+    "release_amb": (None, [sfAMB]),
+    "init_plan": (None, [_P(sfPlan)]),
+    "set_plan": (None, [_P(sfPlan), C.c_size_t, C.c_int]),
+    "sf_csr2amb": (None, [_P(sfAMB), _P(sfCSR), C.c_void_p, _P(sfPlan)]),
+    "csr_kernel": (None, [C.c_void_p, _P(sfCSR), C.c_void_p]),
+    "ans_check": (None, [C.c_void_p, C.c_void_p, C.c_int]),
+    "sf_spmv_amb": (None, [C.c_void_p, _P(sfAMB), C.c_void_p, _P(sfPlan)]),
+    "get_spgemm_flop": (None, [_P(sfCSR), _P(sfCSR), C.c_int, _P(C.c_longlong)]),
+    "check_spgemm_answer": (None, [sfCSR, sfCSR]),
+    "spgemm_kernel_hash": (None, [_P(sfCSR), _P(sfCSR), _P(sfCSR)]),
+    "nsparse_last_error": (C.c_int, []),
+    "nsparse_last_error_string": (C.c_char_p, []),
+    "nsparse_ans_check_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
+    "nsparse_check_spgemm_count": (C.c_int, [_P(sfCSR), _P(sfCSR)]),
+    "nsparse_init_vector_seeded": (None, [C.c_void_p, C.c_int, C.c_ulonglong]),
+    "nsparse_set_amb_chunk": (C.c_int, [C.c_int]),
+    "nsparse_amb_footprint_bytes": (C.c_longlong, [_P(sfAMB)]),
+    "nsparse_spgemm_hash_numeric": (None, [_P(sfCSR), _P(sfCSR), _P(sfCSR)]),
+    "nsparse_get_spgemm_stats": (None, [_P(SpgemmStats)]),
+    "nsparse_get_spgemm_bins": (None, [c_int_p, c_int_p]),
+    "nsparse_set_profiling": (None, [C.c_int]),
+    "nsparse_set_workspace_cache": (None, [C.c_int]),
+    "nsparse_trim_workspace": (None, []),
+    "nsparse_last_spmv_ms": (C.c_float, []),
+    "nsparse_spmv_amb_async": (None, [C.c_void_p, _P(sfAMB), C.c_void_p, _P(sfPlan), C.c_void_p]),
+    "nsparse_synth_csr": (None, [_P(sfCSR), C.c_int, C.c_longlong, C.c_longlong, C.c_longlong,
+                                 C.c_ulonglong, C.c_longlong, C.c_longlong]),
+}
+
+_libs = {}
+
+
+class Lib:
+    """One precision build of the library ('d' = double, 's' = float)."""
+
+    def __init__(self, precision):
+        assert precision in ("d", "s")
+        path = os.path.join(LIB_DIR, f"libnsparse_{precision}.so")
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C nsparse_amd/csrc`.  There is no fallback path.")
+        self.precision = precision
+        self.real = np.float64 if precision == "d" else np.float32
+        self.path = path
+        self.dll = C.CDLL(path, mode=C.RTLD_LOCAL)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(self.dll, name)  # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+        # HIP runtime entry points used for plain device buffers in tests / bench
+        hip_path = "/opt/rocm/lib/libamdhip64.so"
+        self.hip = C.CDLL(hip_path if os.path.exists(hip_path) else "libamdhip64.so", mode=C.RTLD_GLOBAL)
+        self.hip.hipMalloc.argtypes = [_P(C.c_void_p), C.c_size_t]
+        self.hip.hipFree.argtypes = [C.c_void_p]
+        self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.hip.hipDeviceSynchronize.argtypes = []
+
+    # ---- small helpers -----------------------------------------------------------
+    def csr_from_numpy(self, rpt, col, val, N, name=b"numpy"):
+        """sfCSR whose HOST pointers alias numpy arrays (kept alive on the struct)."""
+        rpt = np.ascontiguousarray(rpt, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        val = np.ascontiguousarray(val, dtype=self.real)
+        m = sfCSR()
+        m.rpt = rpt.ctypes.data_as(c_int_p)
+        m.col = col.ctypes.data_as(c_int_p)
+        m.val = val.ctypes.data_as(C.c_void_p)
+        m.M = len(rpt) - 1
+        m.N = int(N)
+        m.nnz = int(rpt[-1])
+        m.nnz_max = int(np.diff(rpt).max()) if len(rpt) > 1 else 0
+        m.matrix_name = name
+        m._keep = (rpt, col, val)
+        return m
+
+    def csr_host_to_numpy(self, m, copy=True):
+        rpt = np.ctypeslib.as_array(m.rpt, (m.M + 1,))
+        col = np.ctypeslib.as_array(m.col, (max(m.nnz, 1),))[:m.nnz]
+        vb = (C.c_byte * (max(m.nnz, 1) * self.real().itemsize)).from_address(m.val)
+        val = np.frombuffer(vb, dtype=self.real)[:m.nnz]
+        if copy:
+            rpt, col, val = rpt.copy(), col.copy(), val.copy()
+        return dict(M=m.M, N=m.N, nnz=m.nnz, nnz_max=m.nnz_max, rpt=rpt, col=col, val=val)
+
+    def dmalloc(self, nbytes):
+        p = C.c_void_p()
+        rc = self.hip.hipMalloc(C.byref(p), max(int(nbytes), 1))
+        if rc != 0:
+            raise RuntimeError(f"hipMalloc({nbytes}) -> {rc}")
+        return p
+
+    def dfree(self, p):
+        self.hip.hipFree(p)
+
+    def h2d(self, dptr, arr):
+        arr = np.ascontiguousarray(arr)
+        rc = self.hip.hipMemcpy(dptr, arr.ctypes.data_as(C.c_void_p), arr.nbytes, 1)
+        assert rc == 0, rc
+
+    def d2h(self, dptr, shape, dtype):
+        out = np.empty(shape, dtype=dtype)
+        if out.nbytes:
+            rc = self.hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), dptr, out.nbytes, 2)
+            assert rc == 0, rc
+        return out
+
+    def amb_to_numpy(self, a):
+        """Device arrays of an sfAMB -> numpy (for bit-exact comparison with the oracle)."""
+        cs, ch, bs, n = a.c_size, a.chunk, a.block_size, a.nnz
+        return dict(
+            cs=self.d2h(a.d_cs, (cs,), np.int32), cl=self.d2h(a.d_cl, (cs,), np.uint32),
+            sellcs_col=self.d2h(a.d_sellcs_col, (n // bs,), np.uint16),
+            sellcs_val=self.d2h(a.d_sellcs_val, (n,), self.real),
+            s_write_permutation=self.d2h(a.d_s_write_permutation, (cs * ch,), np.uint16),
+            s_write_permutation_offset=self.d2h(a.d_s_write_permutation_offset, (cs,), np.uint16),
+            write_permutation=self.d2h(a.d_write_permutation, (cs * ch,), np.int32),
+            c_size=cs, chunk=ch, block_size=bs, nnz=n, pad_M=a.pad_M, seg_size=a.seg_size,
+            seg_num=a.seg_num, M=a.M, N=a.N)
+
+
+def load(precision="d"):
+    if precision not in _libs:
+        _libs[precision] = Lib(precision)
+    return _libs[precision]

@@ -1,0 +1,162 @@
+// device_mem.cpp -- device allocation cache, process context, H2D / D2H of sfCSR,
+// device-side frees.
+//
+// Replaces (reference file:line):
+//   csr_memcpy / csr_memcpyDtH     cuda-c/src/nsparse.cu:146-168
+//   release_csr / release_amb      cuda-c/src/nsparse.cu:209-235
+#include <map>
+#include <unordered_map>
+
+#include "internal.h"
+
+namespace nsp {
+
+namespace {
+struct Cache {
+    bool enabled = true;
+    std::unordered_map<void *, size_t> live;  // blocks handed out
+    std::multimap<size_t, void *> idle;       // blocks waiting for reuse
+    size_t idle_bytes = 0;
+};
+Cache &cache()
+{
+    static Cache c;
+    return c;
+}
+// Round so that near-equal requests of consecutive calls hit the same idle block.
+inline size_t round_size(size_t b)
+{
+    if (b == 0) b = 1;
+    const size_t g = b < (1u << 20) ? 256 : (b < (64u << 20) ? (64u << 10) : (2u << 20));
+    return (b + g - 1) / g * g;
+}
+}  // namespace
+
+void *dev_alloc(size_t bytes)
+{
+    Cache &c = cache();
+    const size_t want = round_size(bytes);
+    if (c.enabled) {
+        auto it = c.idle.lower_bound(want);
+        // accept an idle block up to 25 % (+1 MiB) larger than the request
+        if (it != c.idle.end() && it->first <= want + want / 4 + (1u << 20)) {
+            void *p = it->second;
+            c.live[p] = it->first;
+            c.idle_bytes -= it->first;
+            c.idle.erase(it);
+            return p;
+        }
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess && c.enabled && !c.idle.empty()) {
+        (void)hipGetLastError();
+        dev_cache_trim();  // give the idle blocks back and retry once
+        e = hipMalloc(&p, want);
+    }
+    NSP_CHECK(e);
+    if (c.enabled) c.live[p] = want;
+    return p;
+}
+
+void dev_free(void *p)
+{
+    if (!p) return;
+    Cache &c = cache();
+    auto it = c.live.find(p);
+    if (it != c.live.end()) {
+        if (c.enabled) {
+            c.idle.emplace(it->second, p);
+            c.idle_bytes += it->second;
+            c.live.erase(it);
+            return;
+        }
+        c.live.erase(it);
+    }
+    NSP_CHECK(hipFree(p));
+}
+
+void dev_cache_enable(bool on)
+{
+    if (!on) dev_cache_trim();
+    cache().enabled = on;
+}
+
+void dev_cache_trim()
+{
+    Cache &c = cache();
+    for (auto &kv : c.idle) (void)hipFree(kv.second);
+    c.idle.clear();
+    c.idle_bytes = 0;
+}
+
+Context &ctx()
+{
+    static Context c;
+    if (!c.ready) {
+        for (int i = 0; i < kMaxBins; i++) {
+            NSP_CHECK(hipStreamCreateWithFlags(&c.stream[i], hipStreamNonBlocking));
+            NSP_CHECK(hipEventCreateWithFlags(&c.ev_join[i], hipEventDisableTiming));
+        }
+        NSP_CHECK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+        for (auto &e : c.ev_t) NSP_CHECK(hipEventCreate(&e));
+        for (auto &e : c.ev_bin) NSP_CHECK(hipEventCreate(&e));
+        NSP_CHECK(hipHostMalloc((void **)&c.h_pinned, 256 * sizeof(int), hipHostMallocDefault));
+        NSP_CHECK(hipMalloc((void **)&c.d_scratch, 256 * sizeof(int)));
+        c.ready = true;
+    }
+    return c;
+}
+
+}  // namespace nsp
+
+extern "C" {
+
+void nsparse_set_workspace_cache(int on) { nsp::dev_cache_enable(on != 0); }
+void nsparse_trim_workspace(void) { nsp::dev_cache_trim(); }
+void nsparse_set_profiling(int on) { nsp::ctx().profiling = (on != 0); }
+
+void csr_memcpy(sfCSR *mat)
+{
+    nsp::clear_error();
+    mat->d_rpt = (int *)nsp::dev_alloc(sizeof(int) * (size_t)(mat->M + 1));
+    mat->d_col = (int *)nsp::dev_alloc(sizeof(int) * (size_t)mat->nnz);
+    mat->d_val = (real *)nsp::dev_alloc(sizeof(real) * (size_t)mat->nnz);
+    NSP_CHECK(hipMemcpy(mat->d_rpt, mat->rpt, sizeof(int) * (size_t)(mat->M + 1), hipMemcpyHostToDevice));
+    NSP_CHECK(hipMemcpy(mat->d_col, mat->col, sizeof(int) * (size_t)mat->nnz, hipMemcpyHostToDevice));
+    NSP_CHECK(hipMemcpy(mat->d_val, mat->val, sizeof(real) * (size_t)mat->nnz, hipMemcpyHostToDevice));
+}
+
+void csr_memcpyDtH(sfCSR *mat)
+{
+    nsp::clear_error();
+    // allocates the host arrays, caller frees with release_cpu_csr (as upstream)
+    mat->rpt = (int *)malloc(sizeof(int) * (size_t)(mat->M + 1));
+    mat->col = (int *)malloc(sizeof(int) * (size_t)(mat->nnz > 0 ? mat->nnz : 1));
+    mat->val = (real *)malloc(sizeof(real) * (size_t)(mat->nnz > 0 ? mat->nnz : 1));
+    NSP_CHECK(hipMemcpy(mat->rpt, mat->d_rpt, sizeof(int) * (size_t)(mat->M + 1), hipMemcpyDeviceToHost));
+    if (mat->nnz > 0) {
+        NSP_CHECK(hipMemcpy(mat->col, mat->d_col, sizeof(int) * (size_t)mat->nnz, hipMemcpyDeviceToHost));
+        NSP_CHECK(hipMemcpy(mat->val, mat->d_val, sizeof(real) * (size_t)mat->nnz, hipMemcpyDeviceToHost));
+    }
+}
+
+void release_csr(sfCSR mat)
+{
+    nsp::dev_free(mat.d_rpt);
+    nsp::dev_free(mat.d_col);
+    nsp::dev_free(mat.d_val);
+}
+
+void release_amb(sfAMB mat)
+{
+    nsp::dev_free(mat.d_cs);
+    nsp::dev_free(mat.d_cl);
+    nsp::dev_free(mat.d_sellcs_val);
+    nsp::dev_free(mat.d_sellcs_col);
+    nsp::dev_free(mat.d_write_permutation);
+    nsp::dev_free(mat.d_s_write_permutation);
+    nsp::dev_free(mat.d_s_write_permutation_offset);
+}
+
+}  // extern "C"

@@ -1,0 +1,321 @@
+// host_utils.cpp -- host side of the drop-in boundary: MatrixMarket loader, plan record,
+// CPU CSR SpMV, the two answer checks, host frees.  No device code in this file.
+//
+// Replaces (reference file:line):
+//   init_csr_matrix_from_file / convert_file_csr   cuda-c/src/nsparse.cu:14-144
+//   init_plan / set_plan                           cuda-c/src/nsparse.cu:171-187
+//   init_vector                                    cuda-c/src/nsparse.cu:190-199
+//   release_cpu_csr / release_cpu_amb              cuda-c/src/nsparse.cu:202-224
+//   csr_kernel                                     cuda-c/src/nsparse.cu:240-259
+//   ans_check / check_spgemm_answer                cuda-c/src/nsparse.cu:261-353
+#include <cctype>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+
+namespace nsp {
+
+static int g_err = 0;
+static std::string g_err_msg;
+
+void set_error(int code, const char *what, const char *file, int line)
+{
+    g_err = code;
+    char buf[512];
+    snprintf(buf, sizeof buf, "nsparse: error %d (%s) at %s:%d", code, what ? what : "?", file, line);
+    g_err_msg = buf;
+    fprintf(stderr, "%s\n", buf);
+    const char *na = getenv("NSPARSE_NO_ABORT");
+    if (!(na && na[0] == '1')) abort();
+}
+void clear_error()
+{
+    g_err = 0;
+    g_err_msg.clear();
+}
+
+}  // namespace nsp
+
+extern "C" {
+
+int nsparse_last_error(void) { return nsp::g_err; }
+const char *nsparse_last_error_string(void) { return nsp::g_err_msg.c_str(); }
+
+/* ---------------------------------------------------------------- loader --- */
+
+// One COO triple as read from the file.
+struct Entry {
+    int r, c;
+    real v;
+};
+
+// Parse a non-negative decimal; returns pointer past it, or nullptr when no digit.
+static inline const char *parse_int(const char *p, const char *end, int *out)
+{
+    while (p < end && (*p == ' ' || *p == '\t')) p++;
+    bool neg = false;
+    if (p < end && (*p == '-' || *p == '+')) { neg = (*p == '-'); p++; }
+    if (p >= end || !isdigit((unsigned char)*p)) return nullptr;
+    long v = 0;
+    while (p < end && isdigit((unsigned char)*p)) { v = v * 10 + (*p - '0'); p++; }
+    *out = (int)(neg ? -v : v);
+    return p;
+}
+
+void init_csr_matrix_from_file(sfCSR *mat, char *file_name)
+{
+    FILE *fp = fopen(file_name, "rb");
+    if (fp == NULL) {
+        printf("Cannot find file\n");  // reference nsparse.cu:35-38
+        exit(1);
+    }
+    printf("Read mtx file: %s\n", file_name);  // reference nsparse.cu:39
+    fseek(fp, 0, SEEK_END);
+    long fsz = ftell(fp);
+    fseek(fp, 0, SEEK_SET);
+    std::vector<char> buf((size_t)fsz + 1);
+    size_t got = fread(buf.data(), 1, (size_t)fsz, fp);
+    fclose(fp);
+    buf[got] = '\0';
+    const char *p = buf.data(), *end = buf.data() + got;
+
+    auto line_end = [&](const char *q) {
+        const char *e = (const char *)memchr(q, '\n', (size_t)(end - q));
+        return e ? e : end;
+    };
+
+    // banner: "general" anywhere in the first line => stored as is; anything else
+    // (symmetric, skew-symmetric, hermitian, pattern symmetric) => mirrored with the
+    // SAME sign (reference nsparse.cu:41-43,88-91,119-122).
+    const char *le = line_end(p);
+    bool unsym = std::string(p, le).find("general") != std::string::npos;
+    p = le < end ? le + 1 : end;
+    // skip comment lines, then the size line (reference nsparse.cu:44-49)
+    while (p < end && *p == '%') { le = line_end(p); p = le < end ? le + 1 : end; }
+    int M = 0, N = 0, nz_decl = 0;
+    {
+        const char *q = parse_int(p, end, &M);
+        if (q) q = parse_int(q, end, &N);
+        if (q) q = parse_int(q, end, &nz_decl);
+        if (!q) {
+            fprintf(stderr, "nsparse: malformed size line in %s\n", file_name);
+            exit(1);
+        }
+        le = line_end(p);
+        p = le < end ? le + 1 : end;
+    }
+
+    // entries: "row col [value]" per line; missing value => 1.0 (reference :68-76);
+    // complex files: only the first value token is used.  The reference over-runs its
+    // buffers if the file holds more than nz_decl entries; we stop at nz_decl.
+    std::vector<Entry> coo;
+    coo.reserve((size_t)(nz_decl > 0 ? nz_decl : 0));
+    while (p < end && (int)coo.size() < nz_decl) {
+        le = line_end(p);
+        Entry e;
+        const char *q = parse_int(p, le, &e.r);
+        if (q) {
+            q = parse_int(q, le, &e.c);
+            if (q) {
+                while (q < le && (*q == ' ' || *q == '\t')) q++;
+                if (q < le && *q != '\r' && *q != '\n') {
+                    e.v = (real)strtod(q, nullptr);  // atof semantics
+                } else {
+                    e.v = (real)1.0;
+                }
+                e.r -= 1;
+                e.c -= 1;
+                coo.push_back(e);
+            }
+        }
+        p = le < end ? le + 1 : end;
+    }
+    buf.clear();
+    buf.shrink_to_fit();
+
+    // count, prefix, fill -- entry (r,c) is appended to row r and, when mirrored and
+    // off-diagonal, (c,r) is appended to row c, in file order (reference :83-123).
+    const int num = (int)coo.size();
+    std::vector<int> cnt((size_t)(M > 0 ? M : 1), 0);
+    long long total = num;
+    for (int i = 0; i < num; i++) {
+        cnt[coo[i].r]++;
+        if (coo[i].c != coo[i].r && !unsym) { cnt[coo[i].c]++; total++; }
+    }
+    int *rpt = (int *)malloc(sizeof(int) * (size_t)(M + 1));
+    int *col = (int *)malloc(sizeof(int) * (size_t)(total > 0 ? total : 1));
+    real *val = (real *)malloc(sizeof(real) * (size_t)(total > 0 ? total : 1));
+    int off = 0, nnz_max = 0;
+    for (int i = 0; i < M; i++) {
+        rpt[i] = off;
+        off += cnt[i];
+        if (cnt[i] > nnz_max) nnz_max = cnt[i];
+        cnt[i] = 0;  // reused as the per-row fill cursor
+    }
+    rpt[M] = off;
+    for (int i = 0; i < num; i++) {
+        const int r = coo[i].r, c = coo[i].c;
+        col[rpt[r] + cnt[r]] = c;
+        val[rpt[r] + cnt[r]++] = coo[i].v;
+        if (c != r && !unsym) {
+            col[rpt[c] + cnt[c]] = r;
+            val[rpt[c] + cnt[c]++] = coo[i].v;
+        }
+    }
+    mat->rpt = rpt;
+    mat->col = col;
+    mat->val = val;
+    mat->M = M;
+    mat->N = N;
+    mat->nnz = (int)total;
+    mat->nnz_max = nnz_max;
+    mat->matrix_name = file_name;  // borrowed, like upstream (nsparse.cu:143)
+}
+
+/* ------------------------------------------------------------------ plan --- */
+
+void init_plan(sfPlan *plan) { plan->isPlan = FALSE; }
+
+void set_plan(sfPlan *plan, size_t seg_size, int block_size)
+{
+    plan->isPlan = TRUE;
+    plan->seg_size = seg_size > (size_t)USHORT_MAX ? (size_t)USHORT_MAX : seg_size;
+    plan->block_size = (block_size < 1 || block_size > MAX_BLOCK_SIZE) ? 1 : block_size;
+}
+
+/* --------------------------------------------------------------- vectors --- */
+
+void init_vector(real *x, int row)
+{
+    srand48((unsigned)time(NULL));
+    for (int i = 0; i < row; i++) x[i] = (real)drand48();
+}
+
+void nsparse_init_vector_seeded(real *x, int row, unsigned long long seed)
+{
+    unsigned long long s = seed;
+    for (int i = 0; i < row; i++) {
+        unsigned long long z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        x[i] = (real)((double)(z >> 11) * (1.0 / 9007199254740992.0));
+    }
+}
+
+/* ----------------------------------------------------------------- frees --- */
+
+void release_cpu_csr(sfCSR mat)
+{
+    free(mat.rpt);
+    free(mat.col);
+    free(mat.val);
+}
+
+void release_cpu_amb(sfAMB mat)
+{
+    // The GPU path never fills the host mirrors (neither does upstream, where calling
+    // this on a GPU-built sfAMB is undefined); free(NULL) is a no-op, so zero-initialised
+    // structs are safe.
+    free(mat.cs);
+    free(mat.cl);
+    free(mat.sellcs_val);
+    free(mat.sellcs_col);
+    free(mat.s_write_permutation);
+    free(mat.s_write_permutation_offset);
+}
+
+/* ------------------------------------------------------------ CPU SpMV ---- */
+
+void csr_kernel(real *y, sfCSR *cpu_mat, real *x)
+{
+    const int M = cpu_mat->M;
+    const int *rpt = cpu_mat->rpt, *col = cpu_mat->col;
+    const real *val = cpu_mat->val;
+    for (int i = 0; i < M; i++) {
+        real acc = 0;
+        const int b = rpt[i], e = rpt[i + 1];
+        for (int j = b; j < e; j++) acc += val[j] * x[col[j]];
+        y[i] = acc;
+    }
+}
+
+/* ---------------------------------------------------------------- checks --- */
+
+static inline real rabs(real v) { return v < 0 ? -v : v; }
+
+#if NSPARSE_REAL_IS_FLOAT
+static const real kScale = 1000;
+#else
+static const real kScale = 1000 * 1000;
+#endif
+
+int nsparse_ans_check_count(const real *csr_ans, const real *ans_vec, int N)
+{
+    int fails = 0;
+    for (int i = 0; i < N; i++)
+        if (rabs(ans_vec[i] - csr_ans[i]) * 100 * kScale > rabs(ans_vec[i])) fails++;
+    return fails;
+}
+
+void ans_check(real *csr_ans, real *ans_vec, int N)
+{
+    int shown = 0;
+    for (int i = 0; i < N && shown < 10; i++) {
+        const real delta = rabs(ans_vec[i] - csr_ans[i]);
+        if (delta * 100 * kScale > rabs(ans_vec[i])) {
+            printf("i=%d, ans=%e, csr=%e, delta=%e\n", i, (double)ans_vec[i], (double)csr_ans[i],
+                   (double)delta);
+            shown++;
+        }
+    }
+    printf(shown ? "Calculation Result is Incorrect\n" : "Calculation Result is Correct\n");
+}
+
+int nsparse_check_spgemm_count(const sfCSR *c, const sfCSR *ans)
+{
+    if (c->nnz != ans->nnz) return -1;
+    for (int i = 0; i <= c->M; i++)
+        if (c->rpt[i] != ans->rpt[i]) return -2;
+    for (int i = 0; i < c->nnz; i++)
+        if (c->col[i] != ans->col[i]) return -3;
+    int fails = 0;
+    for (int i = 0; i < c->nnz; i++)
+        if (rabs(ans->val[i] - c->val[i]) * 1000 * kScale > rabs(ans->val[i])) fails++;
+    return fails;
+}
+
+void check_spgemm_answer(sfCSR c, sfCSR ans)
+{
+    if (c.nnz != ans.nnz) {
+        printf("nnz is not correct: %d (correct), %d (incorrect)\n", ans.nnz, c.nnz);
+        return;
+    }
+    for (int i = 0; i <= c.M; i++) {
+        if (c.rpt[i] != ans.rpt[i]) {
+            printf("rpt[%d] is not correct: %d (correct),%d (incorrect)\n", i, ans.rpt[i], c.rpt[i]);
+            return;
+        }
+    }
+    for (int i = 0; i < c.nnz; i++) {
+        if (c.col[i] != ans.col[i]) {
+            printf("col[%d] is not correct: %d (correct), %d (incorrect)\n", i, ans.col[i], c.col[i]);
+            return;
+        }
+    }
+    int shown = 0;
+    for (int i = 0; i < c.nnz && shown < 10; i++) {
+        const real delta = rabs(ans.val[i] - c.val[i]);
+        if (delta * 1000 * kScale > rabs(ans.val[i])) {
+            printf("val[%d]: ans=%e, c=%e, delta=%e\n", i, (double)ans.val[i], (double)c.val[i],
+                   (double)delta);
+            shown++;
+        }
+    }
+    printf(shown ? "Calculation Result is Incorrect\n" : "Calculation Result is Correct\n");
+}
+
+}  // extern "C"

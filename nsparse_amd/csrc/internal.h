@@ -1,0 +1,57 @@
+// internal.h -- shared plumbing of libnsparse_{d,s}.so (not installed, not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "nsparse.h"
+
+namespace nsp {
+
+// ---- error channel -----------------------------------------------------------
+// The reference aborts through checkCudaErrors on any failure.  We do the
+// same by default, but record the code first so that NSPARSE_NO_ABORT=1 callers can
+// poll nsparse_last_error().
+void set_error(int code, const char *what, const char *file, int line);
+void clear_error();
+
+#define NSP_CHECK(expr)                                                          \
+    do {                                                                         \
+        hipError_t _e = (expr);                                                  \
+        if (_e != hipSuccess) ::nsp::set_error((int)_e, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+#define NSP_LAUNCH_CHECK() NSP_CHECK(hipGetLastError())
+
+// ---- device block cache ---------------------------------------------------------
+// hipMalloc / hipFree cost 0.1-1 ms each and hipFree synchronises the device; the
+// reference performs >= 8 of them inside every timed spgemm_kernel_hash call.
+// All device memory handed out by this library goes through this cache so that a steady
+// state loop (release_csr(c); spgemm_kernel_hash(a,b,&c);) touches the driver zero times.
+void *dev_alloc(size_t bytes);
+void dev_free(void *p);
+void dev_cache_enable(bool on);
+void dev_cache_trim();
+
+// ---- per-process context ---------------------------------------------------------
+constexpr int kMaxBins = 8;
+
+struct Context {
+    hipStream_t stream[kMaxBins] = {};  // one per row bin (the reference uses 7)
+    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_join[kMaxBins] = {};
+    hipEvent_t ev_t[8] = {};            // phase timing
+    hipEvent_t ev_bin[2 * kMaxBins] = {};  // per-bin kernel timing (profiling mode)
+    int *h_pinned = nullptr;            // 256 ints of pinned host memory for small D2H
+    int *d_scratch = nullptr;           // 256 ints of device scratch (counters)
+    bool profiling = false;
+    bool ready = false;
+};
+Context &ctx();
+
+inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+}  // namespace nsp

@@ -1,0 +1,1075 @@
+// spgemm_hash.hip -- hash-table SpGEMM  C = A * B  (symbolic + numeric) for gfx950.
+//
+// Replaces (reference file:line):
+//   spgemm_kernel_hash        cuda-c/src/kernel/kernel_spgemm_hash_d.cu:1035-1075  (and _s.cu)
+//   set_max_bin / set_min_bin                                            :156-246
+//   set_row_nnz (symbolic dispatch) + its kernels                        :266-622, :1077-1185
+//   calculate_value_col_bin (numeric dispatch) + its kernels             :631-1027, :1187-1288
+//   get_spgemm_flop           cuda-c/src/kernel/kernel_spgemm_cu_csr.cu:18-57
+//   SpGEMM_Hash_Numeric       cuda-cpp/inc/HashSpGEMM_volta.hpp:1018-1031 (numeric-only re-run)
+//
+// What is kept from the reference: the two-phase algorithm (count distinct columns per
+// row with a hash table, scan, then accumulate values and emit columns in ascending
+// order), the multiplicative hash with linear probing, and binning of rows by size so
+// that every bin gets its own LDS budget.  Everything else is designed for CDNA4:
+//
+//  * wave64.  Inside a row the threads of a workgroup are cut into groups of g lanes,
+//    g = pow2_ceil(average length of the B rows this C row touches), 1 <= g <= 64, chosen
+//    per row at run time.  A group walks one B row with coalesced loads; short B rows get
+//    narrow groups (many A entries in flight per wave), long ones a whole wavefront.  The
+//    reference needs two code paths for this (4-lane "pwarp" rows vs warp-per-A-entry).
+//  * LDS ladder re-derived for 160 KiB/CU (spgemm_hash_kernel_gen.c:51-91 gives the rule:
+//    largest table that still leaves the CU occupied, halve downwards).  Symbolic tables
+//    reach 32768 keys (128 KiB); the reference stops at 8192 and sends everything above to
+//    global memory.  The table actually cleared and probed is sized per ROW
+//    (pow2 >= 1.5 n for numeric, pow2 >= n_prod for symbolic), not per bin, so a small row
+//    in a big bin does not pay for the bin's worst case.
+//  * compaction by ballot + popcount inside the wave (no global cursor, no d_row_nz
+//    reuse: the reference's atomicAdd(d_nz+rid,1) compaction is racy without warp
+//    lock-step), column sort by an LDS bitonic network on 32-bit keys whose
+//    sub-wave stages run without workgroup barriers (the reference's rank sort is
+//    O(nz^2), 16.7 M compares for a 4096-entry row), values fetched afterwards by probing
+//    the still-intact table.
+//  * rows that do not fit LDS: persistent workgroups pull rows from a queue and hash into a
+//    private slice of one bounded global slab (tables sized per row, cleared per row), the
+//    unsorted result is ordered by one rocprim::segmented_radix_sort_pairs.  Memory is
+//    O(workgroups * largest table), not O(rows * largest table) as in the reference
+//    (kernel_spgemm_hash_d.cu:1156-1170,1258-1281).
+//  * one D2H of (bin sizes, max, nnz) per phase through pinned memory instead of the
+//    reference's >= 9 blocking cudaMemcpy; all scratch comes from the block cache.
+//
+// Results: C.rpt / C.col are bit-identical to the reference by construction (distinct
+// columns per row, ascending); C.val differs only by floating-point summation order
+// (LDS atomics), same as the reference vs cuSPARSE (tolerance 1e-9 double / 1e-6 float,
+// nsparse.cu:300-353).
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
+
+#include <algorithm>
+#include <cstring>
+
+#include "internal.h"
+
+namespace nsp {
+namespace spgemm {
+
+constexpr int HASH_SCAL = 107;  // same multiplier as the reference (kernel_spgemm_hash_d.cu:30)
+constexpr int NB = kMaxBins;
+
+// ---- bin ladders ------------------------------------------------------------------
+// Symbolic, n = intermediate products of the row (upper bound of its nnz):
+//   bin 0  n <= 32      sub-wave rows, 4 lanes per row, 64-key table per row
+//   bin 1  n <= 512     one workgroup per row,   64 threads, table <=   512 keys ( 2 KiB)
+//   bin 2  n <= 2048                            128 threads,        <=  2048      ( 8 KiB)
+//   bin 3  n <= 8192                            256 threads,        <=  8192      (32 KiB)
+//   bin 4  n <= 32768                          1024 threads,        <= 32768      (128 KiB)
+//   bin 5  n  > 32768   1024 threads, 32768 keys, row FAILS over to the global table when
+//                       it holds more than 24576 distinct keys
+// Numeric, n = exact nnz of the C row, table = pow2_ceil(1.5 n) (load factor <= 2/3):
+//   bin 0  n <= 16      sub-wave rows, 4 lanes per row, 32 slots per row
+//   bin 1  n <= 170     64 threads,  table <=  256 slots
+//   bin 2  n <= 682     256 threads, table <= 1024
+//   bin 3  n <= 2730    512 threads, table <= 4096
+//   bin 4  n <= 5461    1024 threads, table <= 8192  (96 KiB fp64 + 32 KiB sort keys)
+//   bin 5  n  > 5461    global-memory tables
+struct Thr {
+    int t[NB - 1];
+};
+constexpr Thr kSymThr = {{32, 512, 2048, 8192, 32768, 0x7fffffff, 0x7fffffff}};
+constexpr Thr kNumThr = {{16, 170, 682, 2730, 5461, 0x7fffffff, 0x7fffffff}};
+constexpr int kSymLargeBin = 5;
+constexpr int kNumGlobalBin = 5;
+constexpr int kSymLargeT = 32768;
+constexpr int kSymLargeLimit = 24576;
+
+// device-resident counters of one binning pass (lives in Context::d_scratch)
+struct BinState {
+    int hist[NB];
+    int cursor[NB];
+    int maxv;
+    int fail_count;
+    int queue_head;
+    int nnz;
+    long long total;
+};
+
+struct Stats {
+    nsparse_spgemm_stats s;
+};
+static Stats g_stats;
+
+__host__ __device__ __forceinline__ int bin_of(int n, const Thr &thr)
+{
+    int b = 0;
+#pragma unroll
+    for (int q = 0; q < NB - 1; q++) b += (n > thr.t[q]) ? 1 : 0;
+    return b;
+}
+
+__device__ __forceinline__ int pow2_ceil(int v) { return v <= 1 ? 1 : (1 << (32 - __clz(v - 1))); }
+
+__device__ __forceinline__ int lds_load(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Insert `key` into an open-addressing table of (mask+1) ints (empty = -1), linear
+// probing.  Returns the slot; *fresh = 1 when this call created the entry.
+__device__ __forceinline__ int ht_find_or_insert(int *tab, int mask, int key, int *fresh)
+{
+    int h = (int)(((unsigned)key * (unsigned)HASH_SCAL) & (unsigned)mask);
+    *fresh = 0;
+    while (true) {
+        const int cur = lds_load(tab + h);
+        if (cur == key) return h;
+        if (cur == -1) {
+            const int old = atomicCAS(tab + h, -1, key);
+            if (old == -1) { *fresh = 1; return h; }
+            if (old == key) return h;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+// Same on a table in global memory.  Only the value returned by the CAS decides, so a
+// stale L1 line (another CU cannot touch this slice, but atomics execute in L2) can at
+// worst cost one extra CAS.
+__device__ __forceinline__ long long gt_find_or_insert(int *tab, long long mask, int key, int *fresh)
+{
+    long long h = ((long long)key * HASH_SCAL) & mask;
+    *fresh = 0;
+    while (true) {
+        const int cur = __hip_atomic_load(tab + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return h;
+        if (cur == -1) {
+            const int old = atomicCAS(tab + h, -1, key);
+            if (old == -1) { *fresh = 1; return h; }
+            if (old == key) return h;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// lanes per B row for a C row with `np` products spread over `alen` entries of A
+__device__ __forceinline__ int group_width(int np, int alen)
+{
+    const int avg = alen > 0 ? (np + alen - 1) / alen : 1;
+    int g = pow2_ceil(avg);
+    return g > 64 ? 64 : (g < 1 ? 1 : g);
+}
+
+// ===================================================================================
+//  setup: products per row, histogram, bin-grouped row permutation
+// ===================================================================================
+
+// W lanes cooperate on one row of A (W = pow2 <= 64 chosen from the average row length so
+// that the A.col loads of a wave coalesce).  Restates set_intprod_num (:70-86) fused with
+// set_bin (:88-112) and with the flop sum of get_spgemm_flop.
+template <int W>
+__global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ arpt,
+                                                      const int *__restrict__ acol,
+                                                      const int *__restrict__ brpt, int M,
+                                                      int *__restrict__ row_prod, Thr thr,
+                                                      BinState *bs)
+{
+    __shared__ int s_hist[NB];
+    __shared__ int s_max;
+    __shared__ unsigned long long s_total;
+    if (threadIdx.x < NB) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_max = 0; s_total = 0; }
+    __syncthreads();
+    const int row = (blockIdx.x * 256 + threadIdx.x) / W;
+    const int lane = threadIdx.x % W;
+    long long n = 0;
+    if (row < M) {
+        const int e = arpt[row + 1];
+        for (int j = arpt[row] + lane; j < e; j += W) {
+            const int c = __builtin_nontemporal_load(acol + j);
+            n += brpt[c + 1] - brpt[c];
+        }
+    }
+#pragma unroll
+    for (int o = W / 2; o >= 1; o >>= 1) n += __shfl_xor(n, o);
+    if (row < M && lane == 0) {
+        const int ni = n > 0x7fffffffLL ? 0x7fffffff : (int)n;  // saturate (hub rows)
+        row_prod[row] = ni;
+        atomicAdd(&s_hist[bin_of(ni, thr)], 1);
+        atomicMax(&s_max, ni);
+        atomicAdd(&s_total, (unsigned long long)n);
+    }
+    __syncthreads();
+    if (threadIdx.x < NB && s_hist[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], s_hist[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        atomicMax(&bs->maxv, s_max);
+        atomicAdd((unsigned long long *)&bs->total, s_total);
+    }
+}
+
+// histogram of an existing per-row count (numeric binning, set_min_bin :201-246)
+__global__ __launch_bounds__(256) void k_hist(const int *__restrict__ n, int M, Thr thr, BinState *bs)
+{
+    __shared__ int s_hist[NB];
+    __shared__ int s_max;
+    if (threadIdx.x < NB) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_max = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < M) {
+        const int v = n[i];
+        atomicAdd(&s_hist[bin_of(v, thr)], 1);
+        atomicMax(&s_max, v);
+    }
+    __syncthreads();
+    if (threadIdx.x < NB && s_hist[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], s_hist[threadIdx.x]);
+    if (threadIdx.x == 0) atomicMax(&bs->maxv, s_max);
+}
+
+__global__ __launch_bounds__(256) void k_row_len(const int *__restrict__ rpt, int *__restrict__ len, int M)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < M) len[i] = rpt[i + 1] - rpt[i];
+}
+
+// rows grouped by bin (set_row_perm :125-154): one LDS pass ranks the rows of a block
+// inside their bin, one global atomic per (block, bin) reserves the range.
+__global__ __launch_bounds__(256) void k_bin_scatter(const int *__restrict__ n, int M, Thr thr,
+                                                     BinState *bs, int *__restrict__ perm)
+{
+    __shared__ int s_cnt[NB];
+    __shared__ int s_base[NB];
+    if (threadIdx.x < NB) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int b = 0, r = 0;
+    if (i < M) {
+        b = bin_of(n[i], thr);
+        r = atomicAdd(&s_cnt[b], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        int off = 0;
+        for (int q = 0; q < (int)threadIdx.x; q++) off += bs->hist[q];
+        const int c = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = off + (c ? atomicAdd(&bs->cursor[threadIdx.x], c) : 0);
+    }
+    __syncthreads();
+    if (i < M) perm[s_base[b] + r] = i;
+}
+
+// ===================================================================================
+//  symbolic phase
+// ===================================================================================
+
+// bin 0: LPR lanes per row, TROW keys per row (set_row_nz_bin_pwarp :266-327).
+template <int BS, int LPR, int TROW>
+__global__ __launch_bounds__(BS) void k_sym_small(const int *__restrict__ arpt,
+                                                  const int *__restrict__ acol,
+                                                  const int *__restrict__ brpt,
+                                                  const int *__restrict__ bcol,
+                                                  const int *__restrict__ row_perm,
+                                                  int *__restrict__ row_nz, int bin_off, int bin_size)
+{
+    constexpr int RPB = BS / LPR;
+    __shared__ int tab[RPB * TROW];
+    for (int i = threadIdx.x; i < RPB * TROW; i += BS) tab[i] = -1;
+    __syncthreads();
+    const int lrow = threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int q = blockIdx.x * RPB + lrow;
+    int cnt = 0;
+    int rid = 0;
+    if (q < bin_size) {
+        rid = row_perm[bin_off + q];
+        int *t = tab + lrow * TROW;
+        const int e = arpt[rid + 1];
+        for (int j = arpt[rid] + sub; j < e; j += LPR) {
+            const int c = __builtin_nontemporal_load(acol + j);
+            const int ke = brpt[c + 1];
+            for (int k = brpt[c]; k < ke; k++) {
+                int fresh;
+                ht_find_or_insert(t, TROW - 1, bcol[k], &fresh);
+                cnt += fresh;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (q < bin_size && sub == 0) row_nz[rid] = cnt;
+}
+
+// bins 1..5: one workgroup per row (set_row_nz_bin_each_tb :399-472; LARGE = the try-in-LDS
+// kernel with a fail list, set_row_nz_bin_each_tb_large :474-554).
+template <int BS, int TMAX, bool LARGE>
+__global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
+                                               const int *__restrict__ acol,
+                                               const int *__restrict__ brpt,
+                                               const int *__restrict__ bcol,
+                                               const int *__restrict__ row_perm,
+                                               const int *__restrict__ row_prod,
+                                               int *__restrict__ row_nz, int bin_off,
+                                               BinState *bs, int *__restrict__ fail_list)
+{
+    __shared__ __attribute__((aligned(16))) int tab[TMAX];
+    __shared__ int s_nz;
+    const int rid = row_perm[bin_off + blockIdx.x];
+    const int np = row_prod[rid];
+    int T = LARGE ? TMAX : pow2_ceil(np);
+    if (T < 64) T = 64;
+    if (T > TMAX) T = TMAX;
+    const int mask = T - 1;
+    {
+        int4 *t4 = reinterpret_cast<int4 *>(tab);
+        const int4 m1 = make_int4(-1, -1, -1, -1);
+        for (int i = threadIdx.x; i < T / 4; i += BS) t4[i] = m1;
+    }
+    if (threadIdx.x == 0) s_nz = 0;
+    __syncthreads();
+
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int g = group_width(np, a_end - a_beg);
+    const int ngroups = BS / g;
+    const int gid = threadIdx.x / g, gl = threadIdx.x % g;
+    int cnt = 0;
+    bool full = false;
+    for (int j = a_beg + gid; j < a_end && !full; j += ngroups) {
+        const int c = __builtin_nontemporal_load(acol + j);
+        const int ke = brpt[c + 1];
+        for (int k = brpt[c] + gl; k < ke; k += g) {
+            if (LARGE) {
+                if (lds_load(&s_nz) >= kSymLargeLimit) { full = true; break; }
+            }
+            int fresh;
+            ht_find_or_insert(tab, mask, bcol[k], &fresh);
+            if (LARGE) {
+                if (fresh) atomicAdd(&s_nz, 1);
+            } else {
+                cnt += fresh;
+            }
+        }
+    }
+    if (!LARGE) {
+        cnt = wave_sum(cnt);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nz = s_nz;
+        if (LARGE && nz >= kSymLargeLimit) {
+            fail_list[atomicAdd(&bs->fail_count, 1)] = rid;
+        } else {
+            row_nz[rid] = nz;
+        }
+    }
+}
+
+// overflow rows: persistent workgroups, private slice of a global slab
+// (set_row_nz_bin_each_gl :556-622, bounded-memory variant HashSpGEMM_volta.hpp:341-412).
+template <int BS>
+__global__ __launch_bounds__(BS) void k_sym_global(const int *__restrict__ arpt,
+                                                   const int *__restrict__ acol,
+                                                   const int *__restrict__ brpt,
+                                                   const int *__restrict__ bcol,
+                                                   const int *__restrict__ fail_list, int count,
+                                                   const int *__restrict__ row_prod,
+                                                   int *__restrict__ row_nz, int ncols,
+                                                   BinState *bs, int *__restrict__ slab,
+                                                   long long slice)
+{
+    __shared__ int s_row;
+    __shared__ int s_nz;
+    int *tab = slab + (long long)blockIdx.x * slice;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_row = atomicAdd(&bs->queue_head, 1);
+            s_nz = 0;
+        }
+        __syncthreads();
+        const int q = s_row;
+        if (q >= count) break;
+        const int rid = fail_list[q];
+        long long bound = row_prod[rid];
+        if (bound > ncols) bound = ncols;  // a row of C has at most ncols distinct columns
+        long long T = 64;
+        while (T < 2 * bound) T <<= 1;
+        if (T > slice) T = slice;
+        const long long mask = T - 1;
+        for (long long i = threadIdx.x; i < T; i += BS) tab[i] = -1;
+        __syncthreads();
+        const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+        int cnt = 0;
+        for (int j = a_beg + (threadIdx.x >> 6); j < a_end; j += BS / 64) {
+            const int c = acol[j];
+            const int ke = brpt[c + 1];
+            for (int k = brpt[c] + (threadIdx.x & 63); k < ke; k += 64) {
+                int fresh;
+                gt_find_or_insert(tab, mask, bcol[k], &fresh);
+                cnt += fresh;
+            }
+        }
+        cnt = wave_sum(cnt);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
+        __syncthreads();
+        if (threadIdx.x == 0) row_nz[rid] = s_nz;
+    }
+}
+
+// ===================================================================================
+//  numeric phase
+// ===================================================================================
+
+// bin 0: LPR lanes per row, TROW slots per row, rank sort (calculate_value_col_bin_pwarp
+// :631-723).  The LPR lanes of a row live in one wavefront, so wave-level ordering of LDS
+// operations is all the synchronisation needed between accumulate and read-out.
+template <int BS, int LPR, int TROW>
+__global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
+                                                  const int *__restrict__ acol,
+                                                  const real *__restrict__ aval,
+                                                  const int *__restrict__ brpt,
+                                                  const int *__restrict__ bcol,
+                                                  const real *__restrict__ bval,
+                                                  const int *__restrict__ crpt,
+                                                  int *__restrict__ ccol, real *__restrict__ cval,
+                                                  const int *__restrict__ row_perm, int bin_off,
+                                                  int bin_size, int write_col)
+{
+    constexpr int RPB = BS / LPR;
+    __shared__ int keys[RPB * TROW];
+    __shared__ real vals[RPB * TROW];
+    for (int i = threadIdx.x; i < RPB * TROW; i += BS) {
+        keys[i] = -1;
+        vals[i] = 0;
+    }
+    __syncthreads();
+    const int lrow = threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int q = blockIdx.x * RPB + lrow;
+    const bool active = q < bin_size;
+    int rid = 0;
+    int *kt = keys + lrow * TROW;
+    real *vt = vals + lrow * TROW;
+    if (active) {
+        rid = row_perm[bin_off + q];
+        const int e = arpt[rid + 1];
+        for (int j = arpt[rid] + sub; j < e; j += LPR) {
+            const int c = __builtin_nontemporal_load(acol + j);
+            const real av = __builtin_nontemporal_load(aval + j);
+            const int ke = brpt[c + 1];
+            for (int k = brpt[c]; k < ke; k++) {
+                int fresh;
+                const int h = ht_find_or_insert(kt, TROW - 1, bcol[k], &fresh);
+                unsafeAtomicAdd(vt + h, av * bval[k]);
+            }
+        }
+    }
+    __syncthreads();  // uniform: every thread reaches it
+    if (active) {
+        const int off = crpt[rid];
+        for (int s = sub; s < TROW; s += LPR) {
+            const int key = kt[s];
+            if (key == -1) continue;
+            int rank = 0;
+            for (int u = 0; u < TROW; u++) {
+                const int o = kt[u];
+                rank += (o != -1 && o < key) ? 1 : 0;
+            }
+            if (write_col) ccol[off + rank] = key;
+            cval[off + rank] = vt[s];
+        }
+    }
+}
+
+// In-LDS bitonic sort of P (power of two) ints, ascending.  Stages whose partner distance
+// is < 128 keep every compare-exchange pair inside one wavefront's 128-element segment and
+// run back to back with wave-level ordering only; only the wider stages need a workgroup
+// barrier.
+template <int BS>
+__device__ __forceinline__ void bitonic_sort_lds(int *s, int P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    constexpr int NW = BS / 64;
+    // compare-exchange of pair number t at partner distance j inside merge size k
+    auto cex = [&](int t, int j, int k) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        const int a = s[i], b = s[p];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { s[i] = b; s[p] = a; }
+    };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // phase 1: every merge size up to 128 stays inside a 128-element segment
+    const int kmax1 = P < 128 ? P : 128;
+    for (int seg = wid; seg * 128 < P; seg += NW) {
+        const int t = seg * 64 + lane;
+        for (int k = 2; k <= kmax1; k <<= 1)
+            for (int j = k >> 1; j >= 1; j >>= 1) {
+                if (t < P / 2) cex(t, j, k);
+                wave_sync();
+            }
+    }
+    __syncthreads();
+    // phase 2: wide stages with workgroup barriers, then the sub-segment tail of each merge
+    for (int k = 256; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= 128; j >>= 1) {
+            for (int t = threadIdx.x; t < P / 2; t += BS) cex(t, j, k);
+            __syncthreads();
+        }
+        for (int seg = wid; seg * 128 < P; seg += NW) {
+            const int t = seg * 64 + lane;
+            for (int j = 64; j >= 1; j >>= 1) {
+                cex(t, j, k);
+                wave_sync();
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// bins 1..4: one workgroup per row (calculate_value_col_bin_each_tb :829-927).
+template <int BS, int TMAX, int PMAX>
+__global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
+                                               const int *__restrict__ acol,
+                                               const real *__restrict__ aval,
+                                               const int *__restrict__ brpt,
+                                               const int *__restrict__ bcol,
+                                               const real *__restrict__ bval,
+                                               const int *__restrict__ crpt,
+                                               int *__restrict__ ccol, real *__restrict__ cval,
+                                               const int *__restrict__ row_perm,
+                                               const int *__restrict__ row_prod, int bin_off,
+                                               int write_col)
+{
+    __shared__ __attribute__((aligned(16))) real vals[TMAX];
+    __shared__ __attribute__((aligned(16))) int keys[TMAX];
+    __shared__ __attribute__((aligned(16))) int srt[PMAX];
+    __shared__ int s_cnt;
+    const int rid = row_perm[bin_off + blockIdx.x];
+    const int off = crpt[rid];
+    const int n = crpt[rid + 1] - off;
+    int T = pow2_ceil(n + (n >> 1));
+    if (T < 64) T = 64;
+    if (T > TMAX) T = TMAX;
+    const int mask = T - 1;
+    for (int i = threadIdx.x; i < T; i += BS) {
+        keys[i] = -1;
+        vals[i] = 0;
+    }
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int g = group_width(row_prod[rid], a_end - a_beg);
+    const int ngroups = BS / g;
+    const int gid = threadIdx.x / g, gl = threadIdx.x % g;
+    for (int j = a_beg + gid; j < a_end; j += ngroups) {
+        const int c = __builtin_nontemporal_load(acol + j);
+        const real av = __builtin_nontemporal_load(aval + j);
+        const int ke = brpt[c + 1];
+        for (int k = brpt[c] + gl; k < ke; k += g) {
+            int fresh;
+            const int h = ht_find_or_insert(keys, mask, bcol[k], &fresh);
+            unsafeAtomicAdd(vals + h, av * bval[k]);
+        }
+    }
+    __syncthreads();
+
+    // compaction: ballot + popcount inside the wave, one LDS atomic per 64 slots
+    const int lane = threadIdx.x & 63;
+    for (int base = (threadIdx.x >> 6) * 64; base < T; base += BS) {
+        const int key = keys[base + lane];
+        const bool occ = key != -1;
+        const unsigned long long m = __ballot(occ);
+        if (m) {
+            int start = 0;
+            if (lane == 0) start = atomicAdd(&s_cnt, __popcll(m));
+            start = __shfl(start, 0);
+            if (occ) srt[start + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        }
+    }
+    const int P = pow2_ceil(n);
+    for (int i = n + threadIdx.x; i < P; i += BS) srt[i] = 0x7fffffff;
+    __syncthreads();
+    if (P > 1) bitonic_sort_lds<BS>(srt, P);
+
+    for (int i = threadIdx.x; i < n; i += BS) {
+        const int key = srt[i];
+        int h = (int)(((unsigned)key * (unsigned)HASH_SCAL) & (unsigned)mask);
+        while (keys[h] != key) h = (h + 1) & mask;
+        if (write_col) ccol[off + i] = key;
+        cval[off + i] = vals[h];
+    }
+}
+
+// bin 5: persistent workgroups, private (keys, values) slices of global slabs; the row is
+// written UNSORTED into (tcol, tval) at its C offset and sorted afterwards by one rocprim
+// segmented radix sort (calculate_value_col_bin_each_gl :929-1027).
+template <int BS>
+__global__ __launch_bounds__(BS) void k_num_global(const int *__restrict__ arpt,
+                                                   const int *__restrict__ acol,
+                                                   const real *__restrict__ aval,
+                                                   const int *__restrict__ brpt,
+                                                   const int *__restrict__ bcol,
+                                                   const real *__restrict__ bval,
+                                                   const int *__restrict__ crpt,
+                                                   int *__restrict__ tcol, real *__restrict__ tval,
+                                                   const int *__restrict__ row_perm, int bin_off,
+                                                   int count, BinState *bs,
+                                                   int *__restrict__ kslab, real *__restrict__ vslab,
+                                                   long long slice, int *__restrict__ seg_beg,
+                                                   int *__restrict__ seg_end)
+{
+    __shared__ int s_row;
+    __shared__ int s_cnt;
+    int *keys = kslab + (long long)blockIdx.x * slice;
+    real *vals = vslab + (long long)blockIdx.x * slice;
+    const int lane = threadIdx.x & 63;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_row = atomicAdd(&bs->queue_head, 1);
+            s_cnt = 0;
+        }
+        __syncthreads();
+        const int q = s_row;
+        if (q >= count) break;
+        const int rid = row_perm[bin_off + q];
+        const int off = crpt[rid];
+        const int n = crpt[rid + 1] - off;
+        if (threadIdx.x == 0) {
+            seg_beg[q] = off;
+            seg_end[q] = off + n;
+        }
+        long long T = 64;
+        while (T < 2LL * n) T <<= 1;
+        if (T > slice) T = slice;
+        const long long mask = T - 1;
+        for (long long i = threadIdx.x; i < T; i += BS) {
+            keys[i] = -1;
+            vals[i] = 0;
+        }
+        __syncthreads();
+        const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+        for (int j = a_beg + (threadIdx.x >> 6); j < a_end; j += BS / 64) {
+            const int c = acol[j];
+            const real av = aval[j];
+            const int ke = brpt[c + 1];
+            for (int k = brpt[c] + lane; k < ke; k += 64) {
+                int fresh;
+                const long long h = gt_find_or_insert(keys, mask, bcol[k], &fresh);
+                unsafeAtomicAdd(vals + h, av * bval[k]);
+            }
+        }
+        __syncthreads();
+        for (long long base = (threadIdx.x >> 6) * 64; base < T; base += BS) {
+            const int key = __hip_atomic_load(keys + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool occ = key != -1;
+            const unsigned long long m = __ballot(occ);
+            if (m) {
+                int start = 0;
+                if (lane == 0) start = atomicAdd(&s_cnt, __popcll(m));
+                start = __shfl(start, 0);
+                if (occ) {
+                    const int pos = off + start + __popcll(m & ((1ull << lane) - 1ull));
+                    tcol[pos] = key;
+                    tval[pos] = __hip_atomic_load(vals + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
+// ===================================================================================
+//  host orchestration
+// ===================================================================================
+
+static void scan_exclusive(const int *in, int *out, int n, hipStream_t st)
+{
+    size_t tmp_bytes = 0;
+    NSP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), st));
+    void *tmp = dev_alloc(tmp_bytes ? tmp_bytes : 1);
+    NSP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), st));
+    NSP_CHECK(hipStreamSynchronize(st));
+    dev_free(tmp);
+}
+
+static inline int pick_w(long long nnz, int M)
+{
+    const long long avg = M > 0 ? (nnz + M - 1) / M : 1;
+    int w = 1;
+    while (w < avg && w < 64) w <<= 1;
+    return w;
+}
+
+static void launch_row_products(const sfCSR *a, const sfCSR *b, int *row_prod, BinState *d_bs,
+                                hipStream_t st)
+{
+    const int M = a->M;
+    const int w = pick_w(a->nnz, M);
+    const int grid = ceil_div((long long)M * w, 256);
+#define NSP_RP(W)                                                                              \
+    case W:                                                                                    \
+        hipLaunchKernelGGL(k_row_products<W>, dim3(grid), dim3(256), 0, st, a->d_rpt, a->d_col, \
+                           b->d_rpt, M, row_prod, kSymThr, d_bs);                              \
+        break;
+    switch (w) {
+        NSP_RP(1) NSP_RP(2) NSP_RP(4) NSP_RP(8) NSP_RP(16) NSP_RP(32) NSP_RP(64)
+    }
+#undef NSP_RP
+    NSP_LAUNCH_CHECK();
+}
+
+struct Timer {
+    Context &cx;
+    explicit Timer(Context &c) : cx(c) {}
+    void mark(int i, hipStream_t st) { NSP_CHECK(hipEventRecord(cx.ev_t[i], st)); }
+    float ms(int i, int j)
+    {
+        float v = 0;
+        NSP_CHECK(hipEventElapsedTime(&v, cx.ev_t[i], cx.ev_t[j]));
+        return v;
+    }
+};
+
+// streams: bin b runs on cx.stream[b]; stream[0] is the main line.  In profiling mode
+// everything is serialised on stream[0] and bracketed by events.
+struct BinLauncher {
+    Context &cx;
+    bool used[NB] = {};
+    bool prof;
+    int ev_base;  // unused
+    explicit BinLauncher(Context &c) : cx(c), prof(c.profiling) {}
+    void fork()
+    {
+        if (prof) return;
+        NSP_CHECK(hipEventRecord(cx.ev_fork, cx.stream[0]));
+    }
+    hipStream_t begin(int b)
+    {
+        if (prof) {
+            NSP_CHECK(hipEventRecord(cx.ev_bin[2 * b], cx.stream[0]));
+            used[b] = true;
+            return cx.stream[0];
+        }
+        if (b != 0 && !used[b]) NSP_CHECK(hipStreamWaitEvent(cx.stream[b], cx.ev_fork, 0));
+        used[b] = true;
+        return cx.stream[b];
+    }
+    void end(int b)
+    {
+        if (prof) NSP_CHECK(hipEventRecord(cx.ev_bin[2 * b + 1], cx.stream[0]));
+    }
+    void join()
+    {
+        if (prof) return;
+        for (int b = 1; b < NB; b++) {
+            if (!used[b]) continue;
+            NSP_CHECK(hipEventRecord(cx.ev_join[b], cx.stream[b]));
+            NSP_CHECK(hipStreamWaitEvent(cx.stream[0], cx.ev_join[b], 0));
+        }
+    }
+    void collect(float *out)
+    {
+        for (int b = 0; b < NB; b++) {
+            out[b] = 0;
+            if (prof && used[b]) NSP_CHECK(hipEventElapsedTime(&out[b], cx.ev_bin[2 * b], cx.ev_bin[2 * b + 1]));
+        }
+    }
+};
+
+static int global_slab_groups(long long slice_elems, size_t bytes_per_elem, int rows)
+{
+    // persistent workgroups for the overflow path: bounded by rows, by 2 per CU, and by a
+    // slab budget of 16 GiB (HBM3E is 288 GB; the budget only matters for multi-million
+    // column matrices).
+    const long long budget = 16LL << 30;
+    long long g = budget / (slice_elems * (long long)bytes_per_elem);
+    if (g > 512) g = 512;
+    if (g > rows) g = rows;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static void symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, int *row_nz,
+                           int *row_perm, const int *hist, int max_prod, BinState *d_bs,
+                           Context &cx, float *ms_bin, int *fail_rows)
+{
+    BinLauncher L(cx);
+    int off[NB + 1];
+    off[0] = 0;
+    for (int q = 0; q < NB; q++) off[q + 1] = off[q] + hist[q];
+    const int *arpt = a->d_rpt, *acol = a->d_col, *brpt = b->d_rpt, *bcol = b->d_col;
+    *fail_rows = 0;
+    int *fail_list = nullptr;
+    L.fork();
+#define NSP_SYM_TB(BIN, BS, TMAX)                                                              \
+    if (hist[BIN] > 0) {                                                                       \
+        hipStream_t st = L.begin(BIN);                                                         \
+        hipLaunchKernelGGL((k_sym_tb<BS, TMAX, false>), dim3(hist[BIN]), dim3(BS), 0, st, arpt, \
+                           acol, brpt, bcol, row_perm, row_prod, row_nz, off[BIN], d_bs,       \
+                           (int *)nullptr);                                                    \
+        NSP_LAUNCH_CHECK();                                                                    \
+        L.end(BIN);                                                                            \
+    }
+    NSP_SYM_TB(4, 1024, 32768)
+    NSP_SYM_TB(3, 256, 8192)
+    NSP_SYM_TB(2, 128, 2048)
+    NSP_SYM_TB(1, 64, 512)
+#undef NSP_SYM_TB
+    if (hist[0] > 0) {
+        hipStream_t st = L.begin(0);
+        constexpr int BS = 256, LPR = 4;
+        hipLaunchKernelGGL((k_sym_small<BS, LPR, 64>), dim3(ceil_div(hist[0], BS / LPR)), dim3(BS), 0,
+                           st, arpt, acol, brpt, bcol, row_perm, row_nz, off[0], hist[0]);
+        NSP_LAUNCH_CHECK();
+        L.end(0);
+    }
+    // the overflow bin needs a host round trip (fail count), so it is issued last: by then
+    // every other bin is already queued on its own stream.
+    if (hist[5] > 0) {
+        hipStream_t st = L.begin(5);
+        fail_list = (int *)dev_alloc(sizeof(int) * (size_t)hist[5]);
+        hipLaunchKernelGGL((k_sym_tb<1024, kSymLargeT, true>), dim3(hist[5]), dim3(1024), 0, st, arpt,
+                           acol, brpt, bcol, row_perm, row_prod, row_nz, off[5], d_bs, fail_list);
+        NSP_LAUNCH_CHECK();
+        NSP_CHECK(hipMemcpyAsync(cx.h_pinned + 128, &d_bs->fail_count, sizeof(int), hipMemcpyDeviceToHost, st));
+        NSP_CHECK(hipStreamSynchronize(st));
+        const int fails = cx.h_pinned[128];
+        *fail_rows = fails;
+        if (fails > 0) {
+            long long bound = std::min<long long>(max_prod, b->N);
+            long long slice = 64;
+            while (slice < 2 * bound) slice <<= 1;
+            const int groups = global_slab_groups(slice, sizeof(int), fails);
+            int *slab = (int *)dev_alloc(sizeof(int) * (size_t)slice * groups);
+            hipLaunchKernelGGL((k_sym_global<512>), dim3(groups), dim3(512), 0, st, arpt, acol, brpt,
+                               bcol, fail_list, fails, row_prod, row_nz, b->N, d_bs, slab, slice);
+            NSP_LAUNCH_CHECK();
+            NSP_CHECK(hipStreamSynchronize(st));
+            dev_free(slab);
+        }
+        L.end(5);
+    }
+    L.join();
+    NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
+    L.collect(ms_bin);
+    if (fail_list) dev_free(fail_list);
+}
+
+static void numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const int *row_prod,
+                          const int *row_perm, const int *hist, int max_nz, BinState *d_bs,
+                          Context &cx, float *ms_bin, int write_col)
+{
+    BinLauncher L(cx);
+    int off[NB + 1];
+    off[0] = 0;
+    for (int q = 0; q < NB; q++) off[q + 1] = off[q] + hist[q];
+    const int *arpt = a->d_rpt, *acol = a->d_col, *brpt = b->d_rpt, *bcol = b->d_col;
+    const real *aval = a->d_val, *bval = b->d_val;
+    L.fork();
+    if (hist[kNumGlobalBin] > 0) {
+        hipStream_t st = L.begin(kNumGlobalBin);
+        const int rows = hist[kNumGlobalBin];
+        long long slice = 64;
+        while (slice < 2LL * max_nz) slice <<= 1;
+        const int groups = global_slab_groups(slice, sizeof(int) + sizeof(real), rows);
+        int *kslab = (int *)dev_alloc(sizeof(int) * (size_t)slice * groups);
+        real *vslab = (real *)dev_alloc(sizeof(real) * (size_t)slice * groups);
+        int *tcol = (int *)dev_alloc(sizeof(int) * (size_t)c->nnz);
+        real *tval = (real *)dev_alloc(sizeof(real) * (size_t)c->nnz);
+        int *seg = (int *)dev_alloc(sizeof(int) * 2 * (size_t)rows);
+        // when the structure is kept (numeric-only re-run) sort into scratch columns
+        int *out_col = write_col ? c->d_col : (int *)dev_alloc(sizeof(int) * (size_t)c->nnz);
+        hipLaunchKernelGGL((k_num_global<512>), dim3(groups), dim3(512), 0, st, arpt, acol, aval, brpt,
+                           bcol, bval, c->d_rpt, tcol, tval, row_perm, off[kNumGlobalBin], rows, d_bs,
+                           kslab, vslab, slice, seg, seg + rows);
+        NSP_LAUNCH_CHECK();
+        size_t tmp_bytes = 0;
+        NSP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, tcol, out_col, tval, c->d_val,
+                                                      (unsigned)c->nnz, (unsigned)rows, seg, seg + rows,
+                                                      0, 32, st));
+        void *tmp = dev_alloc(tmp_bytes ? tmp_bytes : 1);
+        NSP_CHECK(rocprim::segmented_radix_sort_pairs(tmp, tmp_bytes, tcol, out_col, tval, c->d_val,
+                                                      (unsigned)c->nnz, (unsigned)rows, seg, seg + rows,
+                                                      0, 32, st));
+        NSP_CHECK(hipStreamSynchronize(st));
+        L.end(kNumGlobalBin);
+        dev_free(tmp);
+        if (!write_col) dev_free(out_col);
+        dev_free(seg);
+        dev_free(tval);
+        dev_free(tcol);
+        dev_free(vslab);
+        dev_free(kslab);
+    }
+#define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
+    if (hist[BIN] > 0) {                                                                       \
+        hipStream_t st = L.begin(BIN);                                                         \
+        hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX>), dim3(hist[BIN]), dim3(BS), 0, st, arpt,  \
+                           acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, \
+                           row_prod, off[BIN], write_col);                                     \
+        NSP_LAUNCH_CHECK();                                                                    \
+        L.end(BIN);                                                                            \
+    }
+    NSP_NUM_TB(4, 1024, 8192, 8192)
+    NSP_NUM_TB(3, 512, 4096, 4096)
+    NSP_NUM_TB(2, 256, 1024, 1024)
+    NSP_NUM_TB(1, 64, 256, 256)
+#undef NSP_NUM_TB
+    if (hist[0] > 0) {
+        hipStream_t st = L.begin(0);
+        constexpr int BS = 256, LPR = 4;
+        hipLaunchKernelGGL((k_num_small<BS, LPR, 32>), dim3(ceil_div(hist[0], BS / LPR)), dim3(BS), 0,
+                           st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val,
+                           row_perm, off[0], hist[0], write_col);
+        NSP_LAUNCH_CHECK();
+        L.end(0);
+    }
+    L.join();
+    NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
+    L.collect(ms_bin);
+}
+
+static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
+{
+    clear_error();
+    Context &cx = ctx();
+    Timer tm(cx);
+    hipStream_t s0 = cx.stream[0];
+    const int M = a->M;
+    nsparse_spgemm_stats &S = g_stats.s;
+    memset(&S, 0, sizeof(S));
+    tm.mark(0, s0);
+
+    BinState *d_sym = reinterpret_cast<BinState *>(cx.d_scratch);
+    BinState *d_num = d_sym + 1;
+    BinState *h_sym = reinterpret_cast<BinState *>(cx.h_pinned);
+    BinState *h_num = h_sym + 1;
+    static_assert(2 * sizeof(BinState) <= 128 * sizeof(int), "scratch layout");
+
+    int *row_prod = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
+    int *row_nz = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
+    int *row_perm = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
+    NSP_CHECK(hipMemsetAsync(d_sym, 0, 2 * sizeof(BinState), s0));
+
+    // ---- setup: products per row (+ symbolic bins) ------------------------------------
+    launch_row_products(a, b, row_prod, d_sym, s0);
+    const int grid_m = ceil_div(M, 256);
+    if (!numeric_only) {
+        hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_prod, M, kSymThr, d_sym, row_perm);
+        NSP_LAUNCH_CHECK();
+    }
+    NSP_CHECK(hipMemcpyAsync(h_sym, d_sym, sizeof(BinState), hipMemcpyDeviceToHost, s0));
+    NSP_CHECK(hipStreamSynchronize(s0));
+    S.n_prod = h_sym->total;
+    S.max_prod_row = h_sym->maxv;
+    for (int q = 0; q < NB; q++) S.sym_bin_size[q] = h_sym->hist[q];
+    tm.mark(1, s0);
+
+    // ---- symbolic: nnz of every row of C, then C.rpt ----------------------------------
+    if (!numeric_only) {
+        c->M = M;
+        c->N = b->N;
+        symbolic_phase(a, b, row_prod, row_nz, row_perm, h_sym->hist, h_sym->maxv, d_sym, cx,
+                       S.ms_sym_bin, &S.sym_fail_rows);
+        c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
+        NSP_CHECK(hipMemsetAsync(row_nz + M, 0, sizeof(int), s0));
+        scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
+    } else {
+        // structure given: row_nz[i] = rpt[i+1] - rpt[i] is recovered inside the kernels
+        // from C.rpt; for binning we need it explicitly.
+        hipLaunchKernelGGL(k_row_len, dim3(ceil_div(M, 256)), dim3(256), 0, s0, c->d_rpt, row_nz, M);
+        NSP_LAUNCH_CHECK();
+    }
+    tm.mark(2, s0);
+
+    // ---- numeric binning ------------------------------------------------------------
+    hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(256), 0, s0, row_nz, M, kNumThr, d_num);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_nz, M, kNumThr, d_num, row_perm);
+    NSP_LAUNCH_CHECK();
+    NSP_CHECK(hipMemcpyAsync(&d_num->nnz, c->d_rpt + M, sizeof(int), hipMemcpyDeviceToDevice, s0));
+    NSP_CHECK(hipMemcpyAsync(h_num, d_num, sizeof(BinState), hipMemcpyDeviceToHost, s0));
+    NSP_CHECK(hipStreamSynchronize(s0));
+    for (int q = 0; q < NB; q++) S.num_bin_size[q] = h_num->hist[q];
+    S.max_nnz_row = h_num->maxv;
+    if (!numeric_only) {
+        c->nnz = h_num->nnz;
+        c->d_col = (int *)dev_alloc(sizeof(int) * (size_t)(c->nnz > 0 ? c->nnz : 1));
+        c->d_val = (real *)dev_alloc(sizeof(real) * (size_t)(c->nnz > 0 ? c->nnz : 1));
+    }
+    S.nnz_c = c->nnz;
+
+    // ---- numeric --------------------------------------------------------------------
+    numeric_phase(a, b, c, row_prod, row_perm, h_num->hist, h_num->maxv, d_num, cx, S.ms_num_bin,
+                  numeric_only ? 0 : 1);
+    tm.mark(3, s0);
+    NSP_CHECK(hipStreamSynchronize(s0));
+    NSP_CHECK(hipDeviceSynchronize());  // synchronous on return, like upstream (:1287)
+    S.ms_setup = tm.ms(0, 1);
+    S.ms_symbolic = tm.ms(1, 2);
+    S.ms_numeric = tm.ms(2, 3);
+    S.ms_total = tm.ms(0, 3);
+
+    dev_free(row_perm);
+    dev_free(row_nz);
+    dev_free(row_prod);
+}
+
+__global__ __launch_bounds__(256) void k_flop(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                              const int *__restrict__ brpt, int M,
+                                              unsigned long long *total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long n = 0;
+    if (i < M)
+        for (int j = arpt[i]; j < arpt[i + 1]; j++) n += (unsigned long long)(brpt[acol[j] + 1] - brpt[acol[j]]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) n += __shfl_xor(n, o);
+    if ((threadIdx.x & 63) == 0 && n) atomicAdd(total, n);
+}
+
+}  // namespace spgemm
+}  // namespace nsp
+
+extern "C" {
+
+void spgemm_kernel_hash(sfCSR *a, sfCSR *b, sfCSR *c) { nsp::spgemm::run(a, b, c, false); }
+
+void nsparse_spgemm_hash_numeric(sfCSR *a, sfCSR *b, sfCSR *c) { nsp::spgemm::run(a, b, c, true); }
+
+void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out) { *out = nsp::spgemm::g_stats.s; }
+
+void nsparse_get_spgemm_bins(int *sym, int *num)
+{
+    for (int q = 0; q < nsp::spgemm::NB - 1; q++) {
+        sym[q] = nsp::spgemm::kSymThr.t[q];
+        num[q] = nsp::spgemm::kNumThr.t[q];
+    }
+}
+
+void get_spgemm_flop(sfCSR *a, sfCSR *b, int M, long long int *flop)
+{
+    nsp::clear_error();
+    nsp::Context &cx = nsp::ctx();
+    unsigned long long *d_total = reinterpret_cast<unsigned long long *>(cx.d_scratch + 192);
+    NSP_CHECK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), cx.stream[0]));
+    hipLaunchKernelGGL(nsp::spgemm::k_flop, dim3(nsp::ceil_div(M, 256)), dim3(256), 0, cx.stream[0],
+                       a->d_rpt, a->d_col, b->d_rpt, M, d_total);
+    NSP_LAUNCH_CHECK();
+    unsigned long long h = 0;
+    NSP_CHECK(hipMemcpyAsync(&h, d_total, sizeof(h), hipMemcpyDeviceToHost, cx.stream[0]));
+    NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
+    *flop = (long long)(2 * h);
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// spmv_amb.hip -- y = A x from the AMB format, for gfx950.
+//
+// Replaces (reference file:line):
+//   kernel_spmv_init_ans            cuda-c/src/kernel/kernel_spmv_amb.cu:10-19
+//   kernel_spmv_amb_atomic<1..20>   cuda-c/src/kernel/kernel_spmv_amb.cu:21-79
+//   sf_spmv_amb (+ the template recursion dispatcher)            :81-104
+//
+// Same traversal as the reference (one lane per (chunk, row slot); per block one 16-bit
+// column + block_size values, values laid out column-major inside the chunk so that a
+// wavefront reads contiguous memory), re-thought for CDNA4:
+//   * a chunk is 64 rows = one wavefront (chunk 32 also supported: two chunks per wave);
+//   * the value / column streams are read once -> nontemporal loads, x stays cacheable;
+//   * when the matrix has a single column segment every output row is owned by exactly one
+//     lane, so the result is stored, not atomically added, and is bit-reproducible; with
+//     several segments the native fp64/fp32 global atomic add is used (the reference spins
+//     on a 64-bit CAS, kernel_spmv_amb.cu:70-76);
+//   * workgroup b runs on XCD b % 8 (observed dispatch order); the block index is remapped so
+//     that each XCD walks one contiguous eighth of the chunks and its private L2 sees one
+//     contiguous window of x instead of eight interleaved ones;
+//   * reads of x are clamped to N-1 and rows >= M are not written, so neither the
+//     N + MAX_BLOCK_SIZE / M + WARP over-allocation of the reference's callers
+//     (spmv_amb.cu:32-33) nor the uninitialised tail of x can influence the result.
+#include "internal.h"
+
+namespace nsp {
+namespace spmv {
+
+static float g_last_ms = 0.f;
+
+template <int BSZ, int C, bool ATOMIC>
+__global__ __launch_bounds__(1024) void k_spmv_amb(real *__restrict__ y, const real *__restrict__ val,
+                                                   const unsigned short *__restrict__ col,
+                                                   const unsigned int *__restrict__ cl,
+                                                   const int *__restrict__ cs,
+                                                   const real *__restrict__ x,
+                                                   const unsigned short *__restrict__ perm,
+                                                   const unsigned short *__restrict__ perm_off,
+                                                   int rows, int seg_size, int M, int N, int nb8)
+{
+    // XCD-aware remap: hardware block b -> logical block (b % 8) * nb8 + b / 8
+    const int lb = (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3);
+    const long long i = (long long)lb * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const int c = (int)(i / C);
+    const int lane = (int)(i % C);
+    const int row = (int)__builtin_nontemporal_load(perm + i) + (int)perm_off[c] * USHORT_MAX;
+    const int cs0 = cs[c];
+    const unsigned int length = cl[c];
+    const int width = (int)(length & SCL_BIT);
+    const int c_off = (int)(length >> SCL_BORDER) * seg_size;
+    const real *v = val + cs0 + lane;
+    const unsigned short *cp = col + cs0 / BSZ + lane;
+    const int nmax = N - 1;
+    real acc = 0;
+#pragma unroll 4
+    for (int h = 0; h <= width; h++) {
+        const int cc = (int)__builtin_nontemporal_load(cp) + c_off;
+#pragma unroll
+        for (int b = 0; b < BSZ; b++) {
+            const int xi = cc + b < nmax ? cc + b : nmax;
+            acc += __builtin_nontemporal_load(v) * x[xi];
+            v += C;
+        }
+        cp += C;
+    }
+    if (row < M) {
+        if (ATOMIC) unsafeAtomicAdd(y + row, acc);
+        else y[row] = acc;
+    }
+}
+
+template <int BSZ>
+static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipStream_t st)
+{
+    const int rows = mat->c_size * mat->chunk;
+    const int nb = ceil_div(rows, tb);
+    const int nb8 = ceil_div(nb, 8);
+    const bool atomic = mat->seg_num > 1;
+    const dim3 grid(nb8 * 8), block(tb);
+#define NSP_GO(CC, AT)                                                                          \
+    hipLaunchKernelGGL((k_spmv_amb<BSZ, CC, AT>), grid, block, 0, st, d_y, mat->d_sellcs_val,      \
+                       mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
+                       mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8)
+    if (mat->chunk == 64) {
+        if (atomic) NSP_GO(64, true); else NSP_GO(64, false);
+    } else {
+        if (atomic) NSP_GO(32, true); else NSP_GO(32, false);
+    }
+#undef NSP_GO
+}
+
+static void launch(real *d_y, const sfAMB *mat, const real *d_x, const sfPlan *plan, hipStream_t st)
+{
+    // y = 0 (kernel_spmv_init_ans): rows of dropped (all-empty) chunks are never visited
+    NSP_CHECK(hipMemsetAsync(d_y, 0, sizeof(real) * (size_t)mat->M, st));
+    if (mat->c_size <= 0) return;
+    int tb = (int)plan->thread_block;
+    if (tb < 64 || tb > 1024 || (tb & 63)) tb = 256;
+    switch (mat->block_size) {
+#define NSP_CASE(B) case B: launch_bs<B>(d_y, mat, d_x, tb, st); break;
+        NSP_CASE(1) NSP_CASE(2) NSP_CASE(3) NSP_CASE(4) NSP_CASE(5) NSP_CASE(6) NSP_CASE(7)
+        NSP_CASE(8) NSP_CASE(9) NSP_CASE(10) NSP_CASE(11) NSP_CASE(12) NSP_CASE(13) NSP_CASE(14)
+        NSP_CASE(15) NSP_CASE(16) NSP_CASE(17) NSP_CASE(18) NSP_CASE(19) NSP_CASE(20)
+#undef NSP_CASE
+        default: set_error(-20, "AMB: block_size out of range", __FILE__, __LINE__);
+    }
+    NSP_LAUNCH_CHECK();
+}
+
+}  // namespace spmv
+}  // namespace nsp
+
+extern "C" {
+
+void nsparse_spmv_amb_async(real *d_y, sfAMB *mat, real *d_x, sfPlan *plan, void *stream)
+{
+    nsp::spmv::launch(d_y, mat, d_x, plan, (hipStream_t)stream);
+}
+
+// Synchronous, on the null stream, so that it orders after whatever the caller queued there
+// (the reference launches on the default stream and ends with cudaThreadSynchronize).
+void sf_spmv_amb(real *d_y, sfAMB *mat, real *d_x, sfPlan *plan)
+{
+    nsp::clear_error();
+    nsp::Context &cx = nsp::ctx();
+    if (cx.profiling) NSP_CHECK(hipEventRecord(cx.ev_t[4], 0));
+    nsp::spmv::launch(d_y, mat, d_x, plan, 0);
+    if (cx.profiling) NSP_CHECK(hipEventRecord(cx.ev_t[5], 0));
+    NSP_CHECK(hipStreamSynchronize(0));
+    if (cx.profiling) NSP_CHECK(hipEventElapsedTime(&nsp::spmv::g_last_ms, cx.ev_t[4], cx.ev_t[5]));
+}
+
+float nsparse_last_spmv_ms(void) { return nsp::spmv::g_last_ms; }
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+// synth.cpp -- deterministic synthetic stand-ins for the SuiteSparse inputs of BASELINE.md
+// (no network on the GPU box, so cant / webbase-1M / nlpkkt120 cannot be downloaded) and the
+// R-MAT generator of config 5.  Host only.  Columns ascend inside every row, as they do for a
+// column-major-sorted .mtx through the reference loader.
+//
+// There is no reference counterpart: the reference reads .mtx files only.  These generators
+// exist so that bench.py and the full-size property tests have the same inputs on every box.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+
+inline unsigned long long mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline double u01(unsigned long long z) { return (double)(z >> 11) * (1.0 / 9007199254740992.0); }
+
+// symmetric pseudo-random value for the unordered pair (r, c)
+inline real pair_value(unsigned long long seed, long long r, long long c)
+{
+    const long long lo = r < c ? r : c, hi = r < c ? c : r;
+    const double u = u01(mix64(seed ^ mix64((unsigned long long)lo * 0x100000001B3ull + (unsigned long long)hi)));
+    return (real)(r == c ? 4.0 + u : 0.1 + u);
+}
+
+struct Builder {
+    std::vector<int> rpt, col;
+    std::vector<real> val;
+    int nnz_max = 0;
+    void finish(sfCSR *mat, long long M, long long N)
+    {
+        mat->M = (int)M;
+        mat->N = (int)N;
+        mat->nnz = (int)col.size();
+        mat->nnz_max = nnz_max;
+        mat->rpt = (int *)malloc(sizeof(int) * (size_t)(M + 1));
+        mat->col = (int *)malloc(sizeof(int) * (col.size() ? col.size() : 1));
+        mat->val = (real *)malloc(sizeof(real) * (val.size() ? val.size() : 1));
+        memcpy(mat->rpt, rpt.data(), sizeof(int) * (size_t)(M + 1));
+        if (!col.empty()) {
+            memcpy(mat->col, col.data(), sizeof(int) * col.size());
+            memcpy(mat->val, val.data(), sizeof(real) * val.size());
+        }
+        mat->d_rpt = nullptr;
+        mat->d_col = nullptr;
+        mat->d_val = nullptr;
+        mat->matrix_name = (char *)"synthetic";
+    }
+};
+
+// 27-point stencil on an nx*ny*nz grid with `dof` unknowns per node (dof=3: FEM brick,
+// "cant" class; dof=1: scalar grid, "nlpkkt" class).  Global ids: node*dof + d.
+void gen_stencil(sfCSR *mat, int dof, long long nx, long long ny, long long nz,
+                 unsigned long long seed, long long rb, long long re)
+{
+    const long long nodes = nx * ny * nz, Mfull = nodes * dof;
+    if (re <= 0 || re > Mfull) re = Mfull;
+    if (rb < 0) rb = 0;
+    Builder b;
+    const long long M = re - rb;
+    b.rpt.resize((size_t)M + 1);
+    b.col.reserve((size_t)M * 27 * dof);
+    b.val.reserve((size_t)M * 27 * dof);
+    for (long long r = rb; r < re; r++) {
+        b.rpt[(size_t)(r - rb)] = (int)b.col.size();
+        const long long node = r / dof;
+        const long long x = node % nx, y = (node / nx) % ny, z = node / (nx * ny);
+        const size_t before = b.col.size();
+        for (long long dz = -1; dz <= 1; dz++) {
+            const long long zz = z + dz;
+            if (zz < 0 || zz >= nz) continue;
+            for (long long dy = -1; dy <= 1; dy++) {
+                const long long yy = y + dy;
+                if (yy < 0 || yy >= ny) continue;
+                for (long long dx = -1; dx <= 1; dx++) {
+                    const long long xx = x + dx;
+                    if (xx < 0 || xx >= nx) continue;
+                    const long long nb = (zz * ny + yy) * nx + xx;
+                    for (int d = 0; d < dof; d++) {
+                        const long long c = nb * dof + d;
+                        b.col.push_back((int)c);
+                        b.val.push_back(pair_value(seed, r, c));
+                    }
+                }
+            }
+        }
+        const int len = (int)(b.col.size() - before);
+        if (len > b.nnz_max) b.nnz_max = len;
+    }
+    b.rpt[(size_t)M] = (int)b.col.size();
+    b.finish(mat, M, Mfull);
+}
+
+// power-law web graph ("webbase" class): short rows with a heavy tail of long ones, columns
+// split between a local window and globally popular hub pages.
+void gen_powerlaw(sfCSR *mat, long long n, long long target_nnz, unsigned long long seed,
+                  long long rb, long long re)
+{
+    if (re <= 0 || re > n) re = n;
+    if (rb < 0) rb = 0;
+    const double avg = (double)target_nnz / (double)n;
+    Builder b;
+    const long long M = re - rb;
+    b.rpt.resize((size_t)M + 1);
+    std::vector<int> tmp;
+    for (long long r = rb; r < re; r++) {
+        b.rpt[(size_t)(r - rb)] = (int)b.col.size();
+        unsigned long long s = mix64(seed ^ mix64((unsigned long long)r));
+        // Pareto(alpha = 2.1) degree with mean ~avg, capped at n/200
+        const double u = u01(s);
+        double d = (avg * 0.52) / std::pow(1.0 - u, 1.0 / 2.1);
+        long long deg = (long long)d;
+        if (deg < 1) deg = 1;
+        if (deg > n / 200) deg = n / 200;
+        tmp.clear();
+        for (long long k = 0; k < deg; k++) {
+            s = mix64(s);
+            const double a = u01(s);
+            s = mix64(s);
+            long long c;
+            if (a < 0.55) {  // local link
+                c = r + (long long)((u01(s) - 0.5) * 2000.0);
+            } else {  // hub: heavily skewed towards low ids
+                const double t = u01(s);
+                c = (long long)((double)n * t * t * t * t);
+            }
+            if (c < 0) c = 0;
+            if (c >= n) c = n - 1;
+            tmp.push_back((int)c);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        for (int c : tmp) {
+            b.col.push_back(c);
+            b.val.push_back((real)(0.1 + u01(mix64(seed ^ mix64((unsigned long long)r * 0x9E3779B1ull + (unsigned long long)c)))));
+        }
+        if ((int)tmp.size() > b.nnz_max) b.nnz_max = (int)tmp.size();
+    }
+    b.rpt[(size_t)M] = (int)b.col.size();
+    b.finish(mat, M, n);
+}
+
+// R-MAT (a,b,c,d) = (0.57,0.19,0.19,0.05), no vertex permutation, duplicates merged with
+// summed values.
+void gen_rmat(sfCSR *mat, int scale, long long ef, unsigned long long seed, long long rb, long long re)
+{
+    const long long n = 1LL << scale, m = n * ef;
+    if (re <= 0 || re > n) re = n;
+    if (rb < 0) rb = 0;
+    std::vector<unsigned long long> e;
+    e.reserve((size_t)m);
+    unsigned long long s = mix64(seed);
+    for (long long k = 0; k < m; k++) {
+        unsigned long long r = 0, c = 0;
+        for (int bit = 0; bit < scale; bit++) {
+            s = mix64(s);
+            const double u = u01(s);
+            const int rbit = u >= 0.76;                               // c or d quadrant
+            const int cbit = (u >= 0.57 && u < 0.76) || (u >= 0.95);  // b or d quadrant
+            r |= (unsigned long long)rbit << bit;
+            c |= (unsigned long long)cbit << bit;
+        }
+        if ((long long)r >= rb && (long long)r < re) e.push_back((r << 32) | c);
+    }
+    std::sort(e.begin(), e.end());
+    Builder b;
+    const long long M = re - rb;
+    b.rpt.assign((size_t)M + 1, 0);
+    size_t i = 0;
+    for (long long r = rb; r < re; r++) {
+        b.rpt[(size_t)(r - rb)] = (int)b.col.size();
+        const size_t before = b.col.size();
+        while (i < e.size() && (long long)(e[i] >> 32) == r) {
+            const unsigned long long key = e[i];
+            int mult = 0;
+            while (i < e.size() && e[i] == key) { mult++; i++; }
+            const int c = (int)(key & 0xffffffffull);
+            b.col.push_back(c);
+            b.val.push_back((real)(mult * (0.05 + u01(mix64(seed ^ mix64(key))))));
+        }
+        const int len = (int)(b.col.size() - before);
+        if (len > b.nnz_max) b.nnz_max = len;
+    }
+    b.rpt[(size_t)M] = (int)b.col.size();
+    b.finish(mat, M, n);
+}
+
+}  // namespace
+
+extern "C" void nsparse_synth_csr(sfCSR *mat, int kind, long long p0, long long p1, long long p2,
+                                  unsigned long long seed, long long row_begin, long long row_end)
+{
+    switch (kind) {
+        case 0: gen_stencil(mat, 3, p0, p1, p2, seed, row_begin, row_end); break;
+        case 1: gen_stencil(mat, 1, p0, p1, p2, seed, row_begin, row_end); break;
+        case 2: gen_powerlaw(mat, p0, p1, seed, row_begin, row_end); break;
+        case 3: gen_rmat(mat, (int)p0, p1, seed, row_begin, row_end); break;
+        default:
+            fprintf(stderr, "nsparse_synth_csr: unknown kind %d\n", kind);
+            memset(mat, 0, sizeof(*mat));
+    }
+}

@@ -1,0 +1,723 @@
+/*
+ * nsparse_oracle.c -- CPU restatement of the reference's hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under nsparse_amd/ may include, link, load or
+ * call this file.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and only as the checker / the reported CPU baseline.
+ *
+ * PINNING STATUS.  The reference (EBD-CREST/nsparse) cannot be compiled in this
+ * image: every source includes <cuda.h>, helper_cuda.h, cusparse_v2.h or the Thrust
+ * CUDA backend, none of which exist here, and the rules forbid stand-ins.  The
+ * reference's test strategy holds exactly one fixture, data/test.mtx, and no expected
+ * outputs (its SpGEMM oracle is cuSPARSE, its SpMV oracle is its own csr_kernel).
+ * This oracle is therefore pinned by
+ *   (1) that fixture (tests/golden/test.mtx, a data file) with the known answers of
+ *       SURVEY.md 8c / BASELINE.md 3 (CSR, y, C = A^2, AMB layout), and
+ *   (2) vectors produced by an independent implementation (scipy.sparse) on seeded
+ *       matrices, committed under tests/golden/ with their generator script.
+ * There are no outputs of the reference itself to compare with: SpGEMM/AMB parity is
+ * "pinned to independent known answers, unpinned against reference-run outputs".
+ *
+ * Every function cites the reference lines it restates.  The code is a sequential
+ * re-derivation of the algorithm, not a translation of the CUDA kernels.
+ *
+ * Build: see oracle/Makefile (two builds: -DDOUBLE -> liboracle_d.so, -DFLOAT -> _s).
+ */
+#include <limits.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef FLOAT
+typedef float real;
+#else
+typedef double real;
+#endif
+
+#define ORC_LINE_MAX 256
+#define ORC_USHORT_MAX 65536
+#define ORC_SCL_BORDER 16
+#define ORC_SCL_BIT ((1 << ORC_SCL_BORDER) - 1)
+#define ORC_MAX_BLOCK_SIZE 20
+#define ORC_BIN_NUM 7
+
+int orc_sizeof_real(void) { return (int)sizeof(real); }
+
+/* ------------------------------------------------------------------------- */
+/* MatrixMarket loader -- restates convert_file_csr, cuda-c/src/nsparse.cu:14-136.
+ *  - banner line containing "general" => unsymmetric, else mirror (same sign)
+ *  - skip lines starting with '%', then "%d %d %d"
+ *  - each entry: atoi / ' ' / atoi / optional ' ' atof; missing value => 1.0
+ *  - counts, offsets, then a second pass that appends (r,c) to row r and, when
+ *    mirrored and off-diagonal, (c,r) to row c, in file order.
+ * Deviation (documented): lines without any digit are skipped; upstream would
+ * dereference a NULL pointer on them.                                          */
+int orc_load_mtx(const char *path, int *M, int *N, int *nnz, int *nnz_max,
+                 int **rpt_out, int **col_out, real **val_out)
+{
+    FILE *fp = fopen(path, "r");
+    if (!fp) return -1;
+    char line[ORC_LINE_MAX];
+    int unsym = 0;
+    if (!fgets(line, ORC_LINE_MAX, fp)) { fclose(fp); return -2; }
+    if (strstr(line, "general")) unsym = 1;
+    do {
+        if (!fgets(line, ORC_LINE_MAX, fp)) { fclose(fp); return -2; }
+    } while (line[0] == '%');
+    int nz_decl = 0;
+    if (sscanf(line, "%d %d %d", M, N, &nz_decl) != 3) { fclose(fp); return -3; }
+
+    int *rc = (int *)malloc(sizeof(int) * (size_t)(nz_decl > 0 ? nz_decl : 1));
+    int *cc = (int *)malloc(sizeof(int) * (size_t)(nz_decl > 0 ? nz_decl : 1));
+    real *vc = (real *)malloc(sizeof(real) * (size_t)(nz_decl > 0 ? nz_decl : 1));
+    int num = 0;
+    while (num < nz_decl && fgets(line, ORC_LINE_MAX, fp)) {
+        char *ch = line;
+        if (!strpbrk(ch, "0123456789")) continue;
+        rc[num] = atoi(ch) - 1;
+        ch = strchr(ch, ' ');
+        if (!ch) continue;
+        ch++;
+        cc[num] = atoi(ch) - 1;
+        ch = strchr(ch, ' ');
+        if (ch != NULL) {
+            ch++;
+            vc[num] = (real)atof(ch);
+        } else {
+            vc[num] = (real)1.0;
+        }
+        num++;
+    }
+    fclose(fp);
+
+    int m = *M;
+    int *cnt = (int *)calloc((size_t)(m > 0 ? m : 1), sizeof(int));
+    int total = num;
+    for (int i = 0; i < num; i++) {
+        cnt[rc[i]]++;
+        if (cc[i] != rc[i] && !unsym) { cnt[cc[i]]++; total++; }
+    }
+    int *rpt = (int *)malloc(sizeof(int) * (size_t)(m + 1));
+    int *col = (int *)malloc(sizeof(int) * (size_t)(total > 0 ? total : 1));
+    real *val = (real *)malloc(sizeof(real) * (size_t)(total > 0 ? total : 1));
+    int off = 0, mx = 0;
+    for (int i = 0; i < m; i++) {
+        rpt[i] = off;
+        off += cnt[i];
+        if (cnt[i] > mx) mx = cnt[i];
+    }
+    rpt[m] = off;
+    int *fill = (int *)calloc((size_t)(m > 0 ? m : 1), sizeof(int));
+    for (int i = 0; i < num; i++) {
+        int r = rc[i], c = cc[i];
+        col[rpt[r] + fill[r]] = c;
+        val[rpt[r] + fill[r]++] = vc[i];
+        if (c != r && !unsym) {
+            col[rpt[c] + fill[c]] = r;
+            val[rpt[c] + fill[c]++] = vc[i];
+        }
+    }
+    free(rc); free(cc); free(vc); free(cnt); free(fill);
+    *nnz = total;
+    *nnz_max = mx;
+    *rpt_out = rpt; *col_out = col; *val_out = val;
+    return 0;
+}
+
+void orc_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------------------- */
+/* CPU CSR SpMV -- restates csr_kernel, cuda-c/src/nsparse.cu:240-259:
+ * per row, sequential sum in storage order, accumulator of type real.         */
+void orc_csr_spmv(int M, const int *rpt, const int *col, const real *val,
+                  const real *x, real *y)
+{
+    for (int i = 0; i < M; i++) {
+        real acc = 0;
+        for (int j = rpt[i]; j < rpt[i + 1]; j++) acc += val[j] * x[col[j]];
+        y[i] = acc;
+    }
+}
+
+/* same arithmetic, rows spread over the host cores ("all host cores") */
+void orc_csr_spmv_omp(int M, const int *rpt, const int *col, const real *val,
+                      const real *x, real *y)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < M; i++) {
+        real acc = 0;
+        for (int j = rpt[i]; j < rpt[i + 1]; j++) acc += val[j] * x[col[j]];
+        y[i] = acc;
+    }
+}
+
+/* ans_check rule -- restates cuda-c/src/nsparse.cu:261-298: an entry fails when
+ * |ans - ref| * 100 * scale > |ans| with scale 1e3 (float) / 1e6 (double).
+ * Returns the number of failing entries (upstream stops printing at 10).       */
+int orc_ans_check(const real *csr_ans, const real *ans_vec, int n)
+{
+    int fails = 0;
+#ifdef FLOAT
+    real scale = 1000;
+#else
+    real scale = 1000 * 1000;
+#endif
+    for (int i = 0; i < n; i++) {
+        real delta = ans_vec[i] - csr_ans[i];
+        real base = ans_vec[i];
+        if (delta < 0) delta = -delta;
+        if (base < 0) base = -base;
+        if (delta * 100 * scale > base) fails++;
+    }
+    return fails;
+}
+
+/* check_spgemm_answer rule -- restates cuda-c/src/nsparse.cu:300-353.
+ * -1: nnz differs, -2: rpt differs, -3: col differs, else number of values with
+ * |ans - c| * 1000 * scale > |ans|.                                            */
+int orc_check_spgemm(int M, int c_nnz, const int *c_rpt, const int *c_col, const real *c_val,
+                     int a_nnz, const int *a_rpt, const int *a_col, const real *a_val)
+{
+    if (c_nnz != a_nnz) return -1;
+    for (int i = 0; i <= M; i++) if (c_rpt[i] != a_rpt[i]) return -2;
+    for (int i = 0; i < c_nnz; i++) if (c_col[i] != a_col[i]) return -3;
+#ifdef FLOAT
+    real scale = 1000;
+#else
+    real scale = 1000 * 1000;
+#endif
+    int fails = 0;
+    for (int i = 0; i < c_nnz; i++) {
+        real delta = a_val[i] - c_val[i];
+        real base = a_val[i];
+        if (delta < 0) delta = -delta;
+        if (base < 0) base = -base;
+        if (delta * 1000 * scale > base) fails++;
+    }
+    return fails;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SpGEMM                                                                      */
+
+/* per-row intermediate products -- restates set_intprod_num,
+ * kernel_spgemm_hash_d.cu:70-86 (int per row, global max), and the flop numerator of
+ * get_spgemm_flop, kernel_spgemm_cu_csr.cu:18-57 (total = sum, flop = 2 * total).   */
+void orc_spgemm_nprod(int M, const int *arpt, const int *acol, const int *brpt,
+                      int *row_prod, long long *total, int *max_prod)
+{
+    long long t = 0;
+    int mx = 0;
+    for (int i = 0; i < M; i++) {
+        int n = 0;
+        for (int j = arpt[i]; j < arpt[i + 1]; j++) n += brpt[acol[j] + 1] - brpt[acol[j]];
+        row_prod[i] = n;
+        t += n;
+        if (n > mx) mx = n;
+    }
+    *total = t;
+    *max_prod = mx;
+}
+
+/* the reference's 7-bin rule -- restates set_bin, kernel_spgemm_hash_d.cu:88-112:
+ * for j = 0..4: if n <= (min << j): bin j when n <= mmin, else bin j+1; else bin 6.
+ * symbolic: (min, mmin) = (512, 32); numeric: (256, 16).                        */
+void orc_bin_hist_ref(int M, const int *n, int min, int mmin, int *bins)
+{
+    for (int b = 0; b < ORC_BIN_NUM; b++) bins[b] = 0;
+    for (int i = 0; i < M; i++) {
+        int j, done = 0;
+        for (j = 0; j < ORC_BIN_NUM - 2; j++) {
+            if (n[i] <= (min << j)) {
+                bins[n[i] <= mmin ? j : j + 1]++;
+                done = 1;
+                break;
+            }
+        }
+        if (!done) bins[ORC_BIN_NUM - 1]++;
+    }
+}
+
+/* generic threshold histogram used by the MI355X build's bin ladder: bin = first b
+ * with n <= thr[b], else nthr.                                                   */
+void orc_bin_hist_thr(int M, const int *n, int nthr, const int *thr, int *bins)
+{
+    for (int b = 0; b <= nthr; b++) bins[b] = 0;
+    for (int i = 0; i < M; i++) {
+        int b = 0;
+        while (b < nthr && n[i] > thr[b]) b++;
+        bins[b]++;
+    }
+}
+
+/* symbolic phase: what every set_row_nz_bin_* kernel computes
+ * (kernel_spgemm_hash_d.cu:266-327,399-472,474-554,556-622): the number of DISTINCT
+ * column ids among the intermediate products of each row (a key is inserted once,
+ * whatever its value), then C.rpt = exclusive scan (:1183), nnz(C) = rpt[M] (:1184). */
+int orc_spgemm_symbolic(int M, int Ncols, const int *arpt, const int *acol,
+                        const int *brpt, const int *bcol, int *row_nz, int *crpt)
+{
+    int *mark = (int *)malloc(sizeof(int) * (size_t)(Ncols > 0 ? Ncols : 1));
+    for (int i = 0; i < Ncols; i++) mark[i] = -1;
+    int acc = 0;
+    for (int i = 0; i < M; i++) {
+        int n = 0;
+        for (int j = arpt[i]; j < arpt[i + 1]; j++) {
+            int k = acol[j];
+            for (int p = brpt[k]; p < brpt[k + 1]; p++) {
+                int c = bcol[p];
+                if (mark[c] != i) { mark[c] = i; n++; }
+            }
+        }
+        row_nz[i] = n;
+        crpt[i] = acc;
+        acc += n;
+    }
+    crpt[M] = acc;
+    free(mark);
+    return acc;
+}
+
+static int cmp_int(const void *a, const void *b)
+{
+    int x = *(const int *)a, y = *(const int *)b;
+    return (x > y) - (x < y);
+}
+
+/* numeric phase: what every calculate_value_col_bin_* kernel computes
+ * (kernel_spgemm_hash_d.cu:631-723,829-927,929-1027): per row, accumulate
+ * aval*bval by column id, then emit (col, val) in ASCENDING column order at C.rpt[row].
+ * Entries whose products cancel to 0.0 stay (structure is symbolic).  The GPU sums
+ * in a nondeterministic order; this restatement sums in (A-entry, B-entry) order.   */
+void orc_spgemm_numeric(int M, int Ncols,
+                        const int *arpt, const int *acol, const real *aval,
+                        const int *brpt, const int *bcol, const real *bval,
+                        const int *crpt, int *ccol, real *cval)
+{
+    real *acc = (real *)calloc((size_t)(Ncols > 0 ? Ncols : 1), sizeof(real));
+    int *mark = (int *)malloc(sizeof(int) * (size_t)(Ncols > 0 ? Ncols : 1));
+    for (int i = 0; i < Ncols; i++) mark[i] = -1;
+    for (int i = 0; i < M; i++) {
+        int base = crpt[i], n = 0;
+        for (int j = arpt[i]; j < arpt[i + 1]; j++) {
+            int k = acol[j];
+            real av = aval[j];
+            for (int p = brpt[k]; p < brpt[k + 1]; p++) {
+                int c = bcol[p];
+                if (mark[c] != i) { mark[c] = i; acc[c] = 0; ccol[base + n++] = c; }
+                acc[c] += av * bval[p];
+            }
+        }
+        qsort(ccol + base, (size_t)n, sizeof(int), cmp_int);
+        for (int q = 0; q < n; q++) cval[base + q] = acc[ccol[base + q]];
+    }
+    free(acc);
+    free(mark);
+}
+
+/* whole C = A B on all host cores: rows are independent, so each thread runs the two
+ * phases above on a block of rows (symbolic into row_nz, scan, numeric).  Used only as
+ * the "all host cores" CPU baseline; the arithmetic per row is identical.          */
+int orc_spgemm_omp(int M, int Ncols,
+                   const int *arpt, const int *acol, const real *aval,
+                   const int *brpt, const int *bcol, const real *bval,
+                   int *crpt, int **ccol_out, real **cval_out)
+{
+    int *row_nz = (int *)malloc(sizeof(int) * (size_t)(M + 1));
+#pragma omp parallel
+    {
+        int *mark = (int *)malloc(sizeof(int) * (size_t)(Ncols > 0 ? Ncols : 1));
+        for (int i = 0; i < Ncols; i++) mark[i] = -1;
+#pragma omp for schedule(dynamic, 64)
+        for (int i = 0; i < M; i++) {
+            int n = 0;
+            for (int j = arpt[i]; j < arpt[i + 1]; j++) {
+                int k = acol[j];
+                for (int p = brpt[k]; p < brpt[k + 1]; p++) {
+                    int c = bcol[p];
+                    if (mark[c] != i) { mark[c] = i; n++; }
+                }
+            }
+            row_nz[i] = n;
+        }
+        free(mark);
+    }
+    int acc = 0;
+    for (int i = 0; i < M; i++) { crpt[i] = acc; acc += row_nz[i]; }
+    crpt[M] = acc;
+    int *ccol = (int *)malloc(sizeof(int) * (size_t)(acc > 0 ? acc : 1));
+    real *cval = (real *)malloc(sizeof(real) * (size_t)(acc > 0 ? acc : 1));
+#pragma omp parallel
+    {
+        real *sum = (real *)calloc((size_t)(Ncols > 0 ? Ncols : 1), sizeof(real));
+        int *mark = (int *)malloc(sizeof(int) * (size_t)(Ncols > 0 ? Ncols : 1));
+        for (int i = 0; i < Ncols; i++) mark[i] = -1;
+#pragma omp for schedule(dynamic, 64)
+        for (int i = 0; i < M; i++) {
+            int base = crpt[i], n = 0;
+            for (int j = arpt[i]; j < arpt[i + 1]; j++) {
+                int k = acol[j];
+                real av = aval[j];
+                for (int p = brpt[k]; p < brpt[k + 1]; p++) {
+                    int c = bcol[p];
+                    if (mark[c] != i) { mark[c] = i; sum[c] = 0; ccol[base + n++] = c; }
+                    sum[c] += av * bval[p];
+                }
+            }
+            qsort(ccol + base, (size_t)n, sizeof(int), cmp_int);
+            for (int q = 0; q < n; q++) cval[base + q] = sum[ccol[base + q]];
+        }
+        free(sum);
+        free(mark);
+    }
+    free(row_nz);
+    *ccol_out = ccol;
+    *cval_out = cval;
+    return acc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* AMB                                                                         */
+
+typedef struct {
+    int *cs;                               /* [c_size]                */
+    unsigned int *cl;                      /* [c_size]                */
+    unsigned short *sellcs_col;            /* [nnz / block_size]      */
+    real *sellcs_val;                      /* [nnz]                   */
+    unsigned short *s_write_permutation;   /* [c_size * chunk]        */
+    unsigned short *s_write_permutation_offset; /* [c_size]           */
+    int *write_permutation;                /* [c_size * chunk]        */
+    int block_size, nnz, M, N, pad_M, chunk, SIGMA, group_num_col, c_size;
+    long long seg_size, seg_num;
+    /* intermediates kept for tests (un-blocked ELL of the non-empty chunks) */
+    int *packed_cl;                        /* [c_size] (width-1) | seg<<16 */
+    int *packed_cs;                        /* [c_size] offsets into ell_*  */
+    unsigned short *ell_col;               /* [ell_nnz] column % seg_size  */
+    real *ell_val;                         /* [ell_nnz]                    */
+    int ell_nnz;
+} orc_amb;
+
+/* stable descending sort of (key, payload) -- the semantics of
+ * thrust::stable_sort_by_key(..., thrust::greater<int>()), convert_amb.cu:688-691.
+ * Bottom-up merge sort; ties keep their input order.                            */
+static void stable_sort_desc(int *key, int *pay, int n)
+{
+    if (n < 2) return;
+    int *k2 = (int *)malloc(sizeof(int) * (size_t)n);
+    int *p2 = (int *)malloc(sizeof(int) * (size_t)n);
+    int *ka = key, *pa = pay, *kb = k2, *pb = p2;
+    for (int w = 1; w < n; w *= 2) {
+        for (int lo = 0; lo < n; lo += 2 * w) {
+            int mid = lo + w < n ? lo + w : n;
+            int hi = lo + 2 * w < n ? lo + 2 * w : n;
+            int i = lo, j = mid, o = lo;
+            while (i < mid && j < hi) {
+                if (ka[j] > ka[i]) { kb[o] = ka[j]; pb[o++] = pa[j++]; }
+                else { kb[o] = ka[i]; pb[o++] = pa[i++]; }
+            }
+            while (i < mid) { kb[o] = ka[i]; pb[o++] = pa[i++]; }
+            while (j < hi) { kb[o] = ka[j]; pb[o++] = pa[j++]; }
+        }
+        int *t = ka; ka = kb; kb = t;
+        t = pa; pa = pb; pb = t;
+    }
+    if (ka != key) {
+        memcpy(key, ka, sizeof(int) * (size_t)n);
+        memcpy(pay, pa, sizeof(int) * (size_t)n);
+    }
+    free(k2);
+    free(p2);
+}
+
+void orc_amb_free(orc_amb *a)
+{
+    free(a->cs); free(a->cl); free(a->sellcs_col); free(a->sellcs_val);
+    free(a->s_write_permutation); free(a->s_write_permutation_offset);
+    free(a->write_permutation); free(a->packed_cl); free(a->packed_cs);
+    free(a->ell_col); free(a->ell_val);
+    memset(a, 0, sizeof(*a));
+}
+
+/* stages 1-6 of convert_amb_at (convert_amb.cu:604-751), everything before blocking.
+ * `chunk` is 32 upstream (mat->chunk = WARP, :859); it is a parameter here because the
+ * MI355X build also supports 64.  `sigma` is SHORT_MAX upstream (:863).           */
+static int amb_build_ell(int M, int N, const int *rpt, const int *col, const real *val,
+                         long long seg_size, int chunk, int sigma, orc_amb *out)
+{
+    int pad_M = chunk * ((M + chunk - 1) / chunk);
+    int G = (int)((N + seg_size - 1) / seg_size);
+    if (G < 1) G = 1;
+    long long R = (long long)pad_M * G;
+    int nz = rpt[M];
+
+    /* 1. segmented CSR (convert_segmented_csr :208-251; set_segmented_nnz_num :138-165;
+     *    set_segmented_col_val :183-206): virtual row g*pad_M+i holds the entries of row
+     *    i whose column / seg_size == g, in the row's storage order.                   */
+    int *nnz_num = (int *)calloc((size_t)R, sizeof(int));
+    int *in_off = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));
+    for (int i = 0; i < M; i++)
+        for (int p = rpt[i]; p < rpt[i + 1]; p++) {
+            long long v = (long long)(col[p] / seg_size) * pad_M + i;
+            in_off[p] = nnz_num[v]++;
+        }
+    int *seg_rpt = (int *)malloc(sizeof(int) * (size_t)(R + 1));
+    seg_rpt[0] = 0;
+    for (long long v = 0; v < R; v++) seg_rpt[v + 1] = seg_rpt[v] + nnz_num[v];
+    int *seg_col = (int *)malloc(sizeof(int) * (size_t)(nz > 0 ? nz : 1));
+    real *seg_val = (real *)malloc(sizeof(real) * (size_t)(nz > 0 ? nz : 1));
+    for (int i = 0; i < M; i++)
+        for (int p = rpt[i]; p < rpt[i + 1]; p++) {
+            long long v = (long long)(col[p] / seg_size) * pad_M + i;
+            seg_col[seg_rpt[v] + in_off[p]] = col[p];
+            seg_val[seg_rpt[v] + in_off[p]] = val[p];
+        }
+    free(in_off);
+
+    /* 2-3. identity permutation (:662) then, per segment and per sigma window of the
+     *      REAL rows [start, min(start+sigma, M)), stable descending sort by length
+     *      (:671-696).  The keys (nnz_num) are permuted together with the payload.     */
+    int *perm = (int *)malloc(sizeof(int) * (size_t)R);
+    for (long long v = 0; v < R; v++) perm[v] = (int)v;
+    int sg = sigma;
+    if (M < sg) sg = M;
+    if (sg > 1) {
+        for (int g = 0; g < G; g++) {
+            int start = 0, end = 0;
+            while (start < M) {
+                end += sg;
+                if (end >= M) end = M;
+                stable_sort_desc(nnz_num + (long long)g * pad_M + start,
+                                 perm + (long long)g * pad_M + start, end - start);
+                start += sg;
+            }
+        }
+    }
+
+    /* 4. chunk widths and offsets (set_cl :46-64, init_cs + scan :66-102) and the
+     *    column-major ELL fill (set_sellcs_col_val :104-136): padding entries carry value
+     *    0 and the column that the chunk's FIRST row has at the same position.         */
+    long long nchunk = R / chunk;
+    int *full_cl = (int *)malloc(sizeof(int) * (size_t)nchunk);
+    int *full_cs = (int *)malloc(sizeof(int) * (size_t)nchunk);
+    int ell = 0;
+    for (long long c = 0; c < nchunk; c++) {
+        int mx = 0;
+        for (int t = 0; t < chunk; t++)
+            if (nnz_num[c * chunk + t] > mx) mx = nnz_num[c * chunk + t];
+        full_cl[c] = mx;
+        full_cs[c] = ell;
+        ell += mx * chunk;
+    }
+    int *ell_col_i = (int *)malloc(sizeof(int) * (size_t)(ell > 0 ? ell : 1));
+    real *ell_val = (real *)malloc(sizeof(real) * (size_t)(ell > 0 ? ell : 1));
+    for (long long v = 0; v < R; v++) {
+        long long c = v / chunk;
+        int t = (int)(v % chunk);
+        int width = full_cl[c], own = nnz_num[v];
+        for (int j = 0; j < width; j++) {
+            int dst = full_cs[c] + t + j * chunk;
+            if (j < own) {
+                ell_val[dst] = seg_val[seg_rpt[perm[v]] + j];
+                ell_col_i[dst] = seg_col[seg_rpt[perm[v]] + j];
+            } else {
+                ell_val[dst] = 0;
+                ell_col_i[dst] = seg_col[seg_rpt[perm[c * chunk]] + j];
+            }
+        }
+    }
+    free(seg_rpt); free(seg_col); free(seg_val);
+
+    /* 5. compression (:715-742): count non-empty chunks (get_c_size :301-311), 16-bit
+     *    columns and cl = (width-1) | segment<<16 (set_ushort_col :313-346), packed index
+     *    by scan of the non-empty flags (:348-371), packed cl/cs (:373-386).            */
+    int c_size = 0;
+    for (long long c = 0; c < nchunk; c++) if (full_cl[c] != 0) c_size++;
+    unsigned short *ell_col = (unsigned short *)malloc(sizeof(unsigned short) * (size_t)(ell > 0 ? ell : 1));
+    for (int e = 0; e < ell; e++) ell_col[e] = (unsigned short)(ell_col_i[e] % seg_size);
+    int *pcl = (int *)malloc(sizeof(int) * (size_t)(c_size > 0 ? c_size : 1));
+    int *pcs = (int *)malloc(sizeof(int) * (size_t)(c_size > 0 ? c_size : 1));
+    int *wp = (int *)malloc(sizeof(int) * (size_t)(c_size > 0 ? c_size : 1) * chunk);
+    unsigned short *swp = (unsigned short *)malloc(sizeof(unsigned short) * (size_t)(c_size > 0 ? c_size : 1) * chunk);
+    unsigned short *swpo = (unsigned short *)malloc(sizeof(unsigned short) * (size_t)(c_size > 0 ? c_size : 1));
+    int pc = 0;
+    for (long long c = 0; c < nchunk; c++) {
+        if (full_cl[c] == 0) continue;
+        int seg = (int)(ell_col_i[full_cs[c]] / seg_size);
+        pcl[pc] = (full_cl[c] - 1) | (seg << ORC_SCL_BORDER);
+        pcs[pc] = full_cs[c];
+        /* 6. permutation (:745-751): virtual -> real row (update_write_permutation
+         *    :253-263 subtracts the segment base of the POSITION), keep non-empty chunks
+         *    (:265-280), split into low 16 bits per lane and high part from lane 0 (:282-297) */
+        for (int t = 0; t < chunk; t++) {
+            long long v = c * chunk + t;
+            int r = perm[v] - (int)(v / pad_M) * pad_M;
+            wp[pc * chunk + t] = r;
+            swp[pc * chunk + t] = (unsigned short)(r % ORC_USHORT_MAX);
+            if (t == 0) swpo[pc] = (unsigned short)(r / ORC_USHORT_MAX);
+        }
+        pc++;
+    }
+    free(ell_col_i); free(full_cl); free(full_cs); free(nnz_num); free(perm);
+
+    out->M = M; out->N = N; out->pad_M = pad_M; out->chunk = chunk; out->SIGMA = sigma;
+    out->group_num_col = G; out->seg_size = seg_size; out->seg_num = G; out->c_size = c_size;
+    out->packed_cl = pcl; out->packed_cs = pcs; out->ell_col = ell_col; out->ell_val = ell_val;
+    out->ell_nnz = ell;
+    out->write_permutation = wp; out->s_write_permutation = swp;
+    out->s_write_permutation_offset = swpo;
+    return 0;
+}
+
+/* blocks needed by one lane -- restates the per-lane loop of set_blocked_cl,
+ * convert_amb.cu:388-413: a new block starts when col - base >= block_size.      */
+static int lane_blocks(const unsigned short *s, int stride, int W, int bs)
+{
+    int base = s[0], width = 0;
+    for (int k = 1; k < W; k++) {
+        if ((int)s[k * stride] - base >= bs) { base = s[k * stride]; width += bs; }
+    }
+    width += bs;
+    return width / bs;
+}
+
+/* stage 7 (blocking): set_blocked_cl + init_blocked_cs + scan (convert_amb.cu:388-471)
+ * and set_blocked_col_val (:473-525).                                            */
+static void amb_block(orc_amb *a, int bs)
+{
+    int C = a->chunk, cs_n = a->c_size;
+    free(a->cs); free(a->cl); free(a->sellcs_col); free(a->sellcs_val);
+    a->cs = (int *)malloc(sizeof(int) * (size_t)(cs_n > 0 ? cs_n : 1));
+    a->cl = (unsigned int *)malloc(sizeof(unsigned int) * (size_t)(cs_n > 0 ? cs_n : 1));
+    int total = 0;
+    for (int c = 0; c < cs_n; c++) {
+        int W = (a->packed_cl[c] & ORC_SCL_BIT) + 1;
+        int mx = 0;
+        for (int t = 0; t < C; t++) {
+            int nb = lane_blocks(a->ell_col + a->packed_cs[c] + t, C, W, bs);
+            if (nb > mx) mx = nb;
+        }
+        a->cl[c] = (unsigned int)((mx - 1) | ((a->packed_cl[c] >> ORC_SCL_BORDER) << ORC_SCL_BORDER));
+        a->cs[c] = total;
+        total += mx * C * bs;
+    }
+    a->nnz = total;
+    a->block_size = bs;
+    a->sellcs_col = (unsigned short *)malloc(sizeof(unsigned short) * (size_t)(total / bs > 0 ? total / bs : 1));
+    a->sellcs_val = (real *)malloc(sizeof(real) * (size_t)(total > 0 ? total : 1));
+    for (int c = 0; c < cs_n; c++) {
+        int W = (a->packed_cl[c] & ORC_SCL_BIT) + 1;
+        int nblk = (int)(a->cl[c] & ORC_SCL_BIT) + 1;
+        for (int t = 0; t < C; t++) {
+            const unsigned short *s = a->ell_col + a->packed_cs[c] + t;
+            const real *v = a->ell_val + a->packed_cs[c] + t;
+            unsigned short *bc = a->sellcs_col + a->cs[c] / bs + t;
+            real *bv = a->sellcs_val + a->cs[c] + t;
+            int it = 0;
+            for (int k = 0; k < nblk; k++) {
+                if (it < W) {
+                    int base = s[it * C];
+                    bc[k * C] = (unsigned short)base;
+                    bv[(k * bs) * C] = v[it * C];
+                    it++;
+                    for (int h = 1; h < bs; h++) {
+                        if (it < W && (int)s[it * C] - base == h) {
+                            bv[(k * bs + h) * C] = v[it * C];
+                            it++;
+                        } else {
+                            bv[(k * bs + h) * C] = 0;
+                        }
+                    }
+                } else {
+                    bc[k * C] = (unsigned short)((s[(W - 1) * C] / bs) * bs);
+                    for (int h = 0; h < bs; h++) bv[(k * bs + h) * C] = 0;
+                }
+            }
+        }
+    }
+}
+
+/* bytes moved by one SpMV -- restates the footprint model of convert_amb.cu:785-791
+ * (64-bit here; upstream uses int).                                               */
+long long orc_amb_footprint(const orc_amb *a)
+{
+    long long w = (long long)sizeof(real), f = 0;
+    f += ((long long)a->nnz / a->block_size) * 2;
+    f += (long long)a->nnz * w;
+    f += (long long)a->c_size * 4 * 2;
+    f += (long long)a->c_size * a->chunk * 2 + (long long)a->c_size * 2;
+    f += (long long)a->c_size * a->chunk * w * 2;
+    f += (long long)a->M * w * 2;
+    return f;
+}
+
+/* manual-plan conversion: the plan->isPlan == TRUE path of sf_csr2amb
+ * (convert_amb.cu:867-877) with set_plan's clamps (nsparse.cu:176-187).           */
+int orc_csr2amb(int M, int N, const int *rpt, const int *col, const real *val,
+                long long seg_size, int block_size, int chunk, int sigma, orc_amb *out)
+{
+    memset(out, 0, sizeof(*out));
+    if (seg_size > ORC_USHORT_MAX) seg_size = ORC_USHORT_MAX;
+    if (seg_size < 1) seg_size = 1;
+    if (block_size < 1 || block_size > ORC_MAX_BLOCK_SIZE) block_size = 1;
+    amb_build_ell(M, N, rpt, col, val, seg_size, chunk, sigma, out);
+    amb_block(out, block_size);
+    return 0;
+}
+
+/* plan search with the static footprint model: the `#undef AT` branch of
+ * convert_amb_at (convert_amb.cu:783-797) inside the candidate loops of sf_csr2amb
+ * (:878-925): seg_size in {65536, 1024, 2048, 3072, 4096} when N < 131072 (in
+ * {65536,1,2,3,4} when N < 100), else {65536}; block_size 1..20; strict '<' keeps the
+ * first minimum.  Returns the chosen (seg_size, block_size).                       */
+int orc_amb_plan_model(int M, int N, const int *rpt, const int *col, const real *val,
+                       int chunk, int sigma, long long *best_seg, int *best_bs,
+                       long long *best_bytes)
+{
+    long long cand[5];
+    int ncand = (N < 128 * 1024) ? 5 : 1;
+    cand[0] = 64 * 1024;
+    for (int i = 1; i < ncand; i++) cand[i] = (N < 100) ? i : (long long)i * 1024;
+    long long best = LLONG_MAX;
+    for (int s = 0; s < ncand; s++) {
+        orc_amb a;
+        memset(&a, 0, sizeof(a));
+        amb_build_ell(M, N, rpt, col, val, cand[s], chunk, sigma, &a);
+        for (int bs = 1; bs <= ORC_MAX_BLOCK_SIZE; bs++) {
+            amb_block(&a, bs);
+            long long f = orc_amb_footprint(&a);
+            if (best > f) { best = f; *best_seg = cand[s]; *best_bs = bs; }
+        }
+        orc_amb_free(&a);
+    }
+    *best_bytes = best;
+    return 0;
+}
+
+/* AMB SpMV traversal -- restates kernel_spmv_init_ans + kernel_spmv_amb_atomic,
+ * kernel_spmv_amb.cu:10-79, one (chunk, lane) at a time in index order.  y must hold
+ * pad_M elements (upstream writes padded rows past M, spmv_amb.cu:33); x must hold
+ * N + MAX_BLOCK_SIZE elements (spmv_amb.cu:32), the tail zero.                      */
+void orc_amb_spmv(const orc_amb *a, const real *x, real *y)
+{
+    int C = a->chunk, bs = a->block_size;
+    for (int i = 0; i < a->pad_M; i++) y[i] = 0;
+    for (int i = 0; i < a->c_size * C; i++) {
+        int c = i / C, lane = i % C;
+        int row = a->s_write_permutation[i] + a->s_write_permutation_offset[c] * ORC_USHORT_MAX;
+        int start = a->cs[c] + lane;
+        int colstart = a->cs[c] / bs + lane;
+        unsigned int length = a->cl[c];
+        int width = (int)(length & ORC_SCL_BIT);
+        long long c_off = (long long)(length >> ORC_SCL_BORDER) * a->seg_size;
+        real ans = 0;
+        for (int h = 0; h <= width; h++) {
+            long long cc = a->sellcs_col[colstart] + c_off;
+            for (int b = 0; b < bs; b++) {
+                ans += a->sellcs_val[start] * x[cc + b];
+                start += C;
+            }
+            colstart += C;
+        }
+        y[row] += ans;
+    }
+}

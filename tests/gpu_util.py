@@ -1,0 +1,87 @@
+"""Helpers for the -m gpu parity tests: everything goes through the C-ABI."""
+import ctypes as C
+
+import numpy as np
+
+import nsparse_amd as ns
+
+
+def spgemm(lib, A, B=None, numeric_again=False):
+    """C = A B through csr_memcpy / spgemm_kernel_hash / csr_memcpyDtH.  Returns (C dict, stats)."""
+    B = A if B is None else B
+    a = lib.csr_from_numpy(A["rpt"], A["col"], A["val"], A["N"])
+    b = lib.csr_from_numpy(B["rpt"], B["col"], B["val"], B["N"])
+    c = ns.sfCSR()
+    lib.csr_memcpy(C.byref(a))
+    lib.csr_memcpy(C.byref(b))
+    flop = C.c_longlong()
+    lib.get_spgemm_flop(C.byref(a), C.byref(b), a.M, C.byref(flop))
+    lib.spgemm_kernel_hash(C.byref(a), C.byref(b), C.byref(c))
+    st = ns.SpgemmStats()
+    lib.nsparse_get_spgemm_stats(C.byref(st))
+    lib.csr_memcpyDtH(C.byref(c))
+    out = lib.csr_host_to_numpy(c)
+    lib.release_cpu_csr(c)
+    out["flop"] = flop.value
+    if numeric_again:
+        # numeric-only re-run on the kept structure with a poisoned value array
+        poison = np.full(max(c.nnz, 1), np.nan, dtype=lib.real)
+        lib.h2d(c.d_val, poison)
+        lib.nsparse_spgemm_hash_numeric(C.byref(a), C.byref(b), C.byref(c))
+        out["val_again"] = lib.d2h(c.d_val, (c.nnz,), lib.real)
+        out["col_again"] = lib.d2h(c.d_col, (c.nnz,), np.int32)
+    lib.release_csr(c)
+    lib.release_csr(a)
+    lib.release_csr(b)
+    return out, st
+
+
+class DeviceAMB:
+    """CSR on the device converted to AMB; y = A x through sf_spmv_amb."""
+
+    def __init__(self, lib, A, seg_size=None, block_size=None, chunk=64):
+        self.lib, self.A = lib, A
+        lib.nsparse_set_amb_chunk(chunk)
+        self.csr = lib.csr_from_numpy(A["rpt"], A["col"], A["val"], A["N"])
+        lib.csr_memcpy(C.byref(self.csr))
+        w = lib.real().itemsize
+        self.d_x = lib.dmalloc((A["N"] + 20) * w)
+        self.d_y = lib.dmalloc((A["M"] + 64) * w)
+        # poison the over-allocated tails: the kernel must not depend on them
+        lib.h2d(self.d_x, np.full(A["N"] + 20, np.nan, dtype=lib.real))
+        self.plan = ns.sfPlan()
+        if seg_size is None:
+            lib.init_plan(C.byref(self.plan))
+        else:
+            lib.set_plan(C.byref(self.plan), seg_size, block_size)
+        self.amb = ns.sfAMB()
+        lib.h2d(self.d_x, np.zeros(A["N"], dtype=lib.real))
+        lib.sf_csr2amb(C.byref(self.amb), C.byref(self.csr), self.d_x, C.byref(self.plan))
+
+    def arrays(self):
+        return self.lib.amb_to_numpy(self.amb)
+
+    def spmv(self, x):
+        lib = self.lib
+        lib.h2d(self.d_x, np.ascontiguousarray(x, dtype=lib.real))
+        lib.h2d(self.d_y, np.full(self.A["M"] + 64, 7.0, dtype=lib.real))
+        lib.sf_spmv_amb(self.d_y, C.byref(self.amb), self.d_x, C.byref(self.plan))
+        y = lib.d2h(self.d_y, (self.A["M"] + 64,), lib.real)
+        assert (y[self.A["M"]:] == 7.0).all(), "kernel wrote past y[M-1]"
+        return y[:self.A["M"]]
+
+    def close(self):
+        lib = self.lib
+        lib.release_amb(self.amb)
+        lib.release_csr(self.csr)
+        lib.dfree(self.d_x)
+        lib.dfree(self.d_y)
+        lib.nsparse_set_amb_chunk(64)
+
+
+def synth(lib, kind, p0, p1=0, p2=0, seed=1, rows=(0, 0)):
+    m = ns.sfCSR()
+    lib.nsparse_synth_csr(C.byref(m), kind, p0, p1, p2, seed, rows[0], rows[1])
+    A = lib.csr_host_to_numpy(m)
+    lib.release_cpu_csr(m)
+    return A

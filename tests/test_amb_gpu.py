@@ -1,0 +1,114 @@
+"""Parity of the device CSR->AMB conversion (bit-exact arrays) and of the AMB SpMV kernel
+(reference ans_check rule: 1e-8 double / 1e-5 float relative) with the CPU oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import nsparse_amd as ns
+from conftest import GOLDEN, TEST_MTX, load_golden
+from gpu_util import DeviceAMB, synth
+
+pytestmark = pytest.mark.gpu
+
+ARRAYS = ("cs", "cl", "sellcs_col", "sellcs_val", "s_write_permutation",
+          "s_write_permutation_offset", "write_permutation")
+
+
+def assert_same_format(dev, ora):
+    for k in ("c_size", "nnz", "pad_M", "chunk", "block_size", "seg_num"):
+        assert dev[k] == getattr(ora, k), k
+    for k in ARRAYS:
+        assert np.array_equal(dev[k], getattr(ora, k)), f"AMB array {k} differs from the oracle"
+
+
+def test_test_mtx_layout_chunk32(lib_d, oracle_d):
+    m = ns.sfCSR()
+    lib_d.init_csr_matrix_from_file(C.byref(m), os.path.join(GOLDEN, "test.mtx").encode())
+    A = lib_d.csr_host_to_numpy(m)
+    lib_d.release_cpu_csr(m)
+    d = DeviceAMB(lib_d, A, 65536, 1, chunk=32)
+    arr = d.arrays()
+    assert arr["cs"].tolist() == [0] and arr["cl"].tolist() == [2] and arr["nnz"] == 96
+    assert arr["s_write_permutation"].tolist() == [2, 0, 4, 1, 3] + list(range(5, 32))
+    assert_same_format(arr, oracle_d.csr2amb(A, 65536, 1, 32))
+    assert d.spmv(np.array(TEST_MTX["x"], float)).tolist() == TEST_MTX["y"]
+    d.close()
+
+
+@pytest.mark.parametrize("chunk", [32, 64])
+@pytest.mark.parametrize("prec", ["d", "s"])
+@pytest.mark.parametrize("name,seg,bs", [
+    ("banded2k", 65536, 1), ("banded2k", 1024, 3), ("banded2k", 300, 20), ("banded2k", 65536, 7),
+    ("rmat_s10", 65536, 1), ("rmat_s10", 256, 4),
+    ("wide_seg", 65536, 1), ("wide_seg", 4096, 5), ("wide_seg", 65536, 2),
+    ("banded_signed1k", 65536, 2),
+])
+def test_manual_plan_bit_exact(name, seg, bs, prec, chunk, lib_d, lib_s, oracle_d, oracle_s):
+    lib, orc = (lib_d, oracle_d) if prec == "d" else (lib_s, oracle_s)
+    g = load_golden(name)
+    g = dict(g, val=g["val"].astype(lib.real))
+    d = DeviceAMB(lib, g, seg, bs, chunk=chunk)
+    ora = orc.csr2amb(g, seg, bs, chunk)
+    assert_same_format(d.arrays(), ora)
+    assert lib.nsparse_amb_footprint_bytes(C.byref(d.amb)) == ora.footprint
+    x = g["x"].astype(lib.real)
+    y = d.spmv(x)
+    y_ref = orc.csr_spmv(g["rpt"], g["col"], g["val"], x)
+    assert orc.ans_check(y_ref, y) == 0
+    if ora.seg_num == 1:
+        # single segment: plain stores, same summation order as the oracle traversal
+        assert np.array_equal(y, ora.spmv(x))
+    d.close()
+
+
+@pytest.mark.parametrize("name", ["banded2k", "wide_seg", "rmat_s10"])
+def test_auto_plan_matches_footprint_model(name, lib_d, oracle_d):
+    g = load_golden(name)
+    d = DeviceAMB(lib_d, g, chunk=64)
+    seg, bs, by = oracle_d.amb_plan_model(g, 64)
+    assert (d.plan.isPlan, d.plan.seg_size, d.plan.block_size) == (1, seg, bs)
+    assert lib_d.nsparse_amb_footprint_bytes(C.byref(d.amb)) == by
+    assert d.plan.thread_block in (64, 128, 256, 512, 1024)
+    assert_same_format(d.arrays(), oracle_d.csr2amb(g, seg, bs, 64))
+    y = d.spmv(g["x"])
+    assert oracle_d.ans_check(g["y"], y) == 0
+    d.close()
+
+
+def test_unsorted_rows_are_sorted_internally(lib_d, oracle_d):
+    g = load_golden("banded2k")
+    rng = np.random.default_rng(3)
+    col, val = g["col"].copy(), g["val"].copy()
+    for i in range(g["M"]):
+        b, e = g["rpt"][i], g["rpt"][i + 1]
+        p = rng.permutation(e - b)
+        col[b:e], val[b:e] = col[b:e][p], val[b:e][p]
+    d = DeviceAMB(lib_d, dict(g, col=col, val=val), 65536, 2)
+    assert_same_format(d.arrays(), oracle_d.csr2amb(g, 65536, 2, 64))
+    d.close()
+
+
+def test_sigma_windows_and_16bit_permutation(lib_d, oracle_d):
+    """M > 65536: several sigma windows, per-chunk high part of the permutation non-zero."""
+    A = synth(lib_d, 2, 150000, 500000, 0, seed=9)
+    d = DeviceAMB(lib_d, A, 65536, 1)
+    arr = d.arrays()
+    assert arr["s_write_permutation_offset"].max() == 2
+    assert_same_format(arr, oracle_d.csr2amb(A, 65536, 1, 64))
+    x = np.random.default_rng(1).random(A["N"])
+    assert oracle_d.ans_check(oracle_d.csr_spmv(A["rpt"], A["col"], A["val"], x), d.spmv(x)) == 0
+    d.close()
+
+
+def test_full_size_cant_class(lib_d, oracle_d):
+    A = synth(lib_d, 0, 9, 9, 257, seed=0x5EED0022)
+    d = DeviceAMB(lib_d, A)  # auto plan
+    x = np.zeros(A["N"])
+    lib_d.nsparse_init_vector_seeded(x.ctypes.data_as(C.c_void_p), A["N"], 0x5EED0001)
+    y = d.spmv(x)
+    assert oracle_d.ans_check(oracle_d.csr_spmv(A["rpt"], A["col"], A["val"], x), y) == 0
+    # linearity: A(2x) == 2 A(x) exactly (power-of-two scaling commutes with rounding)
+    assert np.array_equal(d.spmv(2 * x), 2 * y)
+    d.close()

@@ -1,0 +1,181 @@
+"""Parity of the HIP hash SpGEMM with the CPU oracle, through the C-ABI.
+
+Rules (reference check_spgemm_answer, nsparse.cu:300-353): nnz, rpt and col EXACT (ascending
+columns), values within 1e-9 relative (double) / 1e-6 (float)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import nsparse_amd as ns
+from conftest import GOLDEN, TEST_MTX, load_golden
+from gpu_util import spgemm, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def assert_parity(orc, got, ref, signed=False):
+    assert got["nnz"] == ref["nnz"]
+    assert np.array_equal(got["rpt"], ref["rpt"]), "C.rpt differs"
+    assert np.array_equal(got["col"], ref["col"]), "C.col differs"
+    if not signed:
+        assert orc.check_spgemm(got, ref) == 0, "values outside the reference tolerance"
+    else:
+        # cancelling sums: compare against the magnitude of the products instead
+        eps = 1e-12 if orc.precision == "d" else 1e-5
+        scale = np.abs(ref["val"]).max()
+        assert np.abs(got["val"] - ref["val"]).max() <= eps * scale * 64
+
+
+def test_test_mtx_known_answer(lib_d, oracle_d):
+    m = ns.sfCSR()
+    lib_d.init_csr_matrix_from_file(C.byref(m), os.path.join(GOLDEN, "test.mtx").encode())
+    A = lib_d.csr_host_to_numpy(m)
+    lib_d.release_cpu_csr(m)
+    got, st = spgemm(lib_d, A)
+    assert got["rpt"].tolist() == TEST_MTX["c_rpt"]
+    assert got["col"].tolist() == TEST_MTX["c_col"]
+    assert got["val"].tolist() == TEST_MTX["c_val"]
+    assert got["flop"] == 2 * TEST_MTX["n_prod"] and st.n_prod == TEST_MTX["n_prod"]
+    assert list(st.sym_bin_size)[:2] == [5, 0] and list(st.num_bin_size)[:2] == [5, 0]
+
+
+@pytest.mark.parametrize("prec", ["d", "s"])
+@pytest.mark.parametrize("name", ["banded2k", "banded_signed1k", "rmat_s10"])
+def test_golden_vectors(name, prec, lib_d, lib_s, oracle_d, oracle_s):
+    lib, orc = (lib_d, oracle_d) if prec == "d" else (lib_s, oracle_s)
+    g = load_golden(name)
+    got, st = spgemm(lib, g, numeric_again=True)
+    ref = dict(M=g["M"], nnz=len(g["c_col"]), rpt=g["c_rpt"], col=g["c_col"],
+               val=g["c_val"].astype(lib.real))
+    assert_parity(orc, got, ref, signed="signed" in name)
+    assert got["flop"] == 2 * int(g["row_prod"].sum())
+    # numeric-only re-run reproduces the values on the kept structure
+    assert np.array_equal(got["col_again"], got["col"])
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9 if prec == "d" else 1e-5,
+                               atol=1e-12 if prec == "d" else 1e-5)
+
+
+def _bins_match(orc, st, row_prod, row_nz, lib):
+    sym = (C.c_int * 7)()
+    num = (C.c_int * 7)()
+    lib.nsparse_get_spgemm_bins(sym, num)
+    assert list(st.sym_bin_size) == orc.bin_hist_thr(row_prod, list(sym)).tolist()
+    assert list(st.num_bin_size) == orc.bin_hist_thr(row_nz, list(num)).tolist()
+
+
+@pytest.mark.parametrize("kind,p,prec", [
+    (0, (6, 6, 20), "d"),          # FEM brick: wide wave-per-row groups, numeric bins 1-2
+    (1, (24, 24, 24), "d"),        # scalar stencil: 27-long B rows
+    (2, (60000, 200000, 0), "s"),  # power law: bin 0 + heavy tail (webbase class, fp32)
+    (2, (60000, 200000, 0), "d"),
+    (3, (12, 8, 0), "d"),          # R-MAT: hub rows
+])
+def test_synthetic_vs_oracle(kind, p, prec, lib_d, lib_s, oracle_d, oracle_s):
+    lib, orc = (lib_d, oracle_d) if prec == "d" else (lib_s, oracle_s)
+    A = synth(lib, kind, *p, seed=0x5EED0022)
+    ref = orc.spgemm(A, A)
+    got, st = spgemm(lib, A)
+    assert_parity(orc, got, ref)
+    rp, tot, mx = orc.nprod(A["rpt"], A["col"], A["rpt"])
+    assert st.n_prod == tot and st.max_prod_row == mx and st.nnz_c == ref["nnz"]
+    assert st.max_nnz_row == int(ref["row_nz"].max())
+    _bins_match(orc, st, rp, ref["row_nz"], lib)
+
+
+def test_rectangular_and_empty_rows(lib_d, oracle_d):
+    """A (M x K) * B (K x N) with K != M != N, empty rows in A and B, an all-empty C row."""
+    rng = np.random.default_rng(7)
+    import scipy.sparse as sp
+    A = sp.random(300, 500, density=0.01, random_state=rng, format="csr")
+    B = sp.random(500, 90000, density=0.0005, random_state=rng, format="csr")
+    A.sort_indices(); B.sort_indices()
+    da = dict(M=300, N=500, rpt=A.indptr.astype(np.int32), col=A.indices.astype(np.int32), val=A.data)
+    db = dict(M=500, N=90000, rpt=B.indptr.astype(np.int32), col=B.indices.astype(np.int32), val=B.data)
+    ref = oracle_d.spgemm(da, db)
+    got, _ = spgemm(lib_d, da, db)
+    assert got["M"] == 300 and got["N"] == 90000
+    assert_parity(oracle_d, got, ref)
+    assert (np.diff(got["rpt"]) == 0).any()
+
+
+def test_empty_matrix(lib_d, oracle_d):
+    A = dict(M=64, N=64, rpt=np.zeros(65, np.int32), col=np.zeros(0, np.int32), val=np.zeros(0))
+    got, st = spgemm(lib_d, A)
+    assert got["nnz"] == 0 and not got["rpt"].any() and st.n_prod == 0
+
+
+def _force_rows(n_rows, n_cols, row_len, rng, extra=None):
+    """square matrix whose first row touches `row_len` distinct long rows"""
+    import scipy.sparse as sp
+    A = sp.random(n_rows, n_cols, density=row_len / n_cols, random_state=rng, format="lil")
+    if extra:
+        for r, cols in extra.items():
+            A[r, cols] = 1.0 + rng.random(len(cols))
+    A = A.tocsr()
+    A.sort_indices()
+    return dict(M=n_rows, N=n_cols, rpt=A.indptr.astype(np.int32), col=A.indices.astype(np.int32),
+                val=A.data.astype(np.float64))
+
+
+def test_every_bin_is_exercised(lib_d, oracle_d):
+    """Rows sized to land in every symbolic bin (0-5, incl. the try-in-LDS bin) and every numeric
+    bin incl. the global-table bin; structure must still be exact."""
+    rng = np.random.default_rng(11)
+    n = 40000
+    hub_cols = np.sort(rng.choice(n, 1200, replace=False))
+    big_cols = np.sort(rng.choice(n, 400, replace=False))
+    A = _force_rows(n, n, 12, rng, extra={0: hub_cols, 1: big_cols, 2: big_cols[:150], 3: big_cols[:60]})
+    ref = oracle_d.spgemm(A, A)
+    got, st = spgemm(lib_d, A)
+    assert_parity(oracle_d, got, ref)
+    rp, _, _ = oracle_d.nprod(A["rpt"], A["col"], A["rpt"])
+    _bins_match(oracle_d, st, rp, ref["row_nz"], lib_d)
+    assert st.sym_bin_size[5] >= 1, "no row reached the try-in-LDS symbolic bin"
+    assert st.num_bin_size[5] >= 1, "no row reached the global numeric bin"
+    assert sum(1 for b in list(st.num_bin_size)[:6] if b > 0) >= 4
+
+
+def test_symbolic_overflow_falls_back_to_global_table(lib_d, oracle_d):
+    """A row with > 24576 distinct output columns must fail over from LDS to the global table."""
+    rng = np.random.default_rng(5)
+    n = 120000
+    cols = np.sort(rng.choice(n, 3000, replace=False))
+    A = _force_rows(n, n, 14, rng, extra={7: cols})
+    ref = oracle_d.spgemm(A, A)
+    assert ref["row_nz"][7] > 24576
+    got, st = spgemm(lib_d, A)
+    assert st.sym_fail_rows >= 1
+    assert_parity(oracle_d, got, ref)
+
+
+def test_workspace_cache_off_is_identical(lib_d, oracle_d):
+    g = load_golden("banded2k")
+    lib_d.nsparse_set_workspace_cache(0)
+    try:
+        a, _ = spgemm(lib_d, g)
+    finally:
+        lib_d.nsparse_set_workspace_cache(1)
+    b, _ = spgemm(lib_d, g)
+    assert np.array_equal(a["col"], b["col"]) and np.array_equal(a["rpt"], b["rpt"])
+
+
+def test_full_size_cant_class_properties(lib_d, oracle_d):
+    """BASELINE config 2 size (62,451 rows, ~4.3 M nnz, ~0.3 G products).  Oracle parity on the
+    full matrix (the C oracle needs ~1 s) plus size-independent properties: ascending columns,
+    symmetry of the structure of A^2 for symmetric A, linearity in the values."""
+    A = synth(lib_d, 0, 9, 9, 257, seed=0x5EED0022)
+    assert A["M"] == 62451
+    got, st = spgemm(lib_d, A)
+    ref = oracle_d.spgemm(A, A)
+    assert_parity(oracle_d, got, ref)
+    for i in range(0, A["M"], 997):
+        c = got["col"][got["rpt"][i]:got["rpt"][i + 1]]
+        assert (np.diff(c) > 0).all()
+    import scipy.sparse as sp
+    S = sp.csr_matrix((np.ones(got["nnz"]), got["col"], got["rpt"]), shape=(A["M"], A["N"]))
+    assert (S != S.T).nnz == 0
+    A2 = dict(A, val=A["val"] * 3.0)
+    got2, _ = spgemm(lib_d, A2)
+    np.testing.assert_allclose(got2["val"], 9.0 * got["val"], rtol=1e-9)
