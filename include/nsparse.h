@@ -227,7 +227,7 @@ typedef struct {
     float ms_symbolic;        /* all symbolic kernels + scan     (HIP events)       */
     float ms_numeric;         /* numeric binning + all numeric kernels              */
     float ms_total;           /* whole call                                         */
-    float ms_sym_bin[8];      /* per-bin kernel time, valid when profiling is on    */
+    float ms_sym_bin[8];      /* per-bin kernel time, HIP events on the bin's own stream */
     float ms_num_bin[8];
 } nsparse_spgemm_stats;
 void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out);
@@ -235,8 +235,9 @@ void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out);
 /* Upper thresholds of the symbolic / numeric bins (7 values each; bin 7 = above). */
 void nsparse_get_spgemm_bins(int *sym_thresholds, int *num_thresholds);
 
-/* 1: bracket every kernel with HIP events on its own stream and serialise the
- *    bins (for roofline measurement); 0 (default): bins overlap on streams.    */
+/* 1: serialise the row bins on one stream (clean per-kernel durations for roofline work
+ *    and rocprof); 0 (default): bins overlap on their own streams.  The per-bin HIP-event
+ *    timings in nsparse_spgemm_stats are recorded in both modes.                */
 void nsparse_set_profiling(int on);
 
 /* 1 (default): device blocks released by release_csr/release_amb and the internal

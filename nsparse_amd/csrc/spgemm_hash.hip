@@ -746,32 +746,29 @@ struct Timer {
 struct BinLauncher {
     Context &cx;
     bool used[NB] = {};
-    bool prof;
-    int ev_base;  // unused
-    explicit BinLauncher(Context &c) : cx(c), prof(c.profiling) {}
+    bool serial;  // profiling mode: one stream, bins back to back
+    explicit BinLauncher(Context &c) : cx(c), serial(c.profiling) {}
     void fork()
     {
-        if (prof) return;
-        NSP_CHECK(hipEventRecord(cx.ev_fork, cx.stream[0]));
+        if (!serial) NSP_CHECK(hipEventRecord(cx.ev_fork, cx.stream[0]));
     }
+    // The begin/end events sit on the stream the bin's kernels are launched on, so their
+    // difference is the duration of those kernels whether or not other bins overlap.
     hipStream_t begin(int b)
     {
-        if (prof) {
-            NSP_CHECK(hipEventRecord(cx.ev_bin[2 * b], cx.stream[0]));
-            used[b] = true;
-            return cx.stream[0];
-        }
-        if (b != 0 && !used[b]) NSP_CHECK(hipStreamWaitEvent(cx.stream[b], cx.ev_fork, 0));
+        hipStream_t st = serial ? cx.stream[0] : cx.stream[b];
+        if (!serial && b != 0 && !used[b]) NSP_CHECK(hipStreamWaitEvent(st, cx.ev_fork, 0));
         used[b] = true;
-        return cx.stream[b];
+        NSP_CHECK(hipEventRecord(cx.ev_bin[2 * b], st));
+        return st;
     }
     void end(int b)
     {
-        if (prof) NSP_CHECK(hipEventRecord(cx.ev_bin[2 * b + 1], cx.stream[0]));
+        NSP_CHECK(hipEventRecord(cx.ev_bin[2 * b + 1], serial ? cx.stream[0] : cx.stream[b]));
     }
     void join()
     {
-        if (prof) return;
+        if (serial) return;
         for (int b = 1; b < NB; b++) {
             if (!used[b]) continue;
             NSP_CHECK(hipEventRecord(cx.ev_join[b], cx.stream[b]));
@@ -782,7 +779,7 @@ struct BinLauncher {
     {
         for (int b = 0; b < NB; b++) {
             out[b] = 0;
-            if (prof && used[b]) NSP_CHECK(hipEventElapsedTime(&out[b], cx.ev_bin[2 * b], cx.ev_bin[2 * b + 1]));
+            if (used[b]) NSP_CHECK(hipEventElapsedTime(&out[b], cx.ev_bin[2 * b], cx.ev_bin[2 * b + 1]));
         }
     }
 };

@@ -124,7 +124,7 @@ def test_every_bin_is_exercised(lib_d, oracle_d):
     bin incl. the global-table bin; structure must still be exact."""
     rng = np.random.default_rng(11)
     n = 40000
-    hub_cols = np.sort(rng.choice(n, 1200, replace=False))
+    hub_cols = np.sort(rng.choice(n, 3500, replace=False))
     big_cols = np.sort(rng.choice(n, 400, replace=False))
     A = _force_rows(n, n, 12, rng, extra={0: hub_cols, 1: big_cols, 2: big_cols[:150], 3: big_cols[:60]})
     ref = oracle_d.spgemm(A, A)
