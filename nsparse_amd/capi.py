@@ -112,9 +112,12 @@ class Lib:
             fn.restype = res
             fn.argtypes = args
             setattr(self, name, fn)
-        # HIP runtime entry points used for plain device buffers in tests / bench
-        hip_path = "/opt/rocm/lib/libamdhip64.so"
-        self.hip = C.CDLL(hip_path if os.path.exists(hip_path) else "libamdhip64.so", mode=C.RTLD_GLOBAL)
+        # HIP runtime entry points used for plain device buffers in tests / bench.  They are
+        # looked up through the library's own handle (dlsym searches its dependencies), so
+        # they come from the SAME libamdhip64.so.7 the library is bound to: the system ROCm
+        # one in a plain process, torch's bundled one (same SONAME) when torch was imported
+        # first.  Never dlopen a second HIP runtime by path.
+        self.hip = self.dll
         self.hip.hipMalloc.argtypes = [_P(C.c_void_p), C.c_size_t]
         self.hip.hipFree.argtypes = [C.c_void_p]
         self.hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]

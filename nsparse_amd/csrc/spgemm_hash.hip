@@ -157,12 +157,90 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
-// lanes per B row for a C row with `np` products spread over `alen` entries of A
-__device__ __forceinline__ int group_width(int np, int alen)
+// Lanes per B row for a C row with `np` products spread over `alen` entries of A, for a
+// workgroup of BS threads.  With g lanes per group the row takes
+//     ceil(alen / (BS/g)) * ceil(avg_len / g)   group steps,
+// so g trades padding of the B rows (small g pads less) against imbalance between groups
+// (large g, few groups).  The largest g with the fewest steps wins.
+__device__ __forceinline__ int group_width(int np, int alen, int BS)
 {
-    const int avg = alen > 0 ? (np + alen - 1) / alen : 1;
-    int g = pow2_ceil(avg);
-    return g > 64 ? 64 : (g < 1 ? 1 : g);
+    if (alen <= 0) return 64;
+    const int avg = (np + alen - 1) / alen;
+    int best_g = 64, best_t = 0x7fffffff;
+#pragma unroll
+    for (int g = 64; g >= 1; g >>= 1) {
+        const int ng = BS / g;
+        const int t = ((alen + ng - 1) / ng) * ((avg + g - 1) / g);
+        if (t < best_t) { best_t = t; best_g = g; }
+    }
+    return best_g;
+}
+
+// Walk every intermediate product of one C row with the threads of a workgroup and hand
+// (column, aval * bval) to `consume`.
+//
+// The naive loop (per A entry: load A.col -> load B.rpt[c], B.rpt[c+1] -> load B.col/B.val)
+// is a chain of three dependent global loads per A entry, 2-3 k cycles of latency for one or
+// two wave-steps of work.  Here each lane of a group loads ONE A entry and its B row extent,
+// so a batch of g entries costs the two dependent latencies once; the entries are then
+// broadcast inside the group with wave shuffles (ds_bpermute), and the first chunk of B row
+// t+1 is already in flight while row t is being hashed.
+template <int BS, bool WITH_VAL, typename F>
+__device__ __forceinline__ void walk_products(const int *__restrict__ acol, const real *__restrict__ aval,
+                                              const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                              const real *__restrict__ bval, int a_beg, int a_end,
+                                              int g, F &&consume)
+{
+    const int ngroups = BS / g;
+    const int gid = threadIdx.x / g, gl = threadIdx.x % g;
+    const int first = a_beg + gid;
+    const int cnt = first < a_end ? (a_end - first + ngroups - 1) / ngroups : 0;
+    // wave-uniform trip count: the first group of the wave owns the most entries
+    const int gid0 = (int)(threadIdx.x & ~63u) / g;
+    const int first0 = a_beg + gid0;
+    const int cnt_max = first0 < a_end ? (a_end - first0 + ngroups - 1) / ngroups : 0;
+    for (int b0 = 0; b0 < cnt_max; b0 += g) {
+        const int m = b0 + gl;
+        int my_kb = 0, my_ke = 0;
+        real my_av = 0;
+        if (m < cnt) {
+            const int j = first + m * ngroups;
+            const int c = __builtin_nontemporal_load(acol + j);
+            if (WITH_VAL) my_av = __builtin_nontemporal_load(aval + j);
+            my_kb = brpt[c];
+            my_ke = brpt[c + 1];
+        }
+        const int nb = cnt_max - b0 < g ? cnt_max - b0 : g;
+        int cur_kb = __shfl(my_kb, 0, g), cur_ke = __shfl(my_ke, 0, g);
+        real cur_av = WITH_VAL ? __shfl(my_av, 0, g) : (real)0;
+        int k = cur_kb + gl;
+        bool pre_ok = k < cur_ke;
+        int pre_key = 0;
+        real pre_val = 0;
+        if (pre_ok) {
+            pre_key = bcol[k];
+            if (WITH_VAL) pre_val = bval[k];
+        }
+        for (int t = 0; t < nb; t++) {
+            const int tn = t + 1 < nb ? t + 1 : t;
+            const int nxt_kb = __shfl(my_kb, tn, g), nxt_ke = __shfl(my_ke, tn, g);
+            const real nxt_av = WITH_VAL ? __shfl(my_av, tn, g) : (real)0;
+            const bool ok = pre_ok;
+            const int key = pre_key;
+            const real val = pre_val;
+            const int kn = nxt_kb + gl;
+            pre_ok = (t + 1 < nb) && kn < nxt_ke;
+            if (pre_ok) {
+                pre_key = bcol[kn];
+                if (WITH_VAL) pre_val = bval[kn];
+            }
+            if (ok) consume(key, cur_av * val);
+            for (int kk = cur_kb + gl + g; kk < cur_ke; kk += g) consume(bcol[kk], WITH_VAL ? cur_av * bval[kk] : (real)0);
+            cur_kb = nxt_kb;
+            cur_ke = nxt_ke;
+            cur_av = nxt_av;
+        }
+    }
 }
 
 // ===================================================================================
@@ -185,30 +263,34 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
     if (threadIdx.x < NB) s_hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) { s_max = 0; s_total = 0; }
     __syncthreads();
-    const int row = (blockIdx.x * 256 + threadIdx.x) / W;
     const int lane = threadIdx.x % W;
-    long long n = 0;
-    if (row < M) {
-        const int e = arpt[row + 1];
-        for (int j = arpt[row] + lane; j < e; j += W) {
-            const int c = __builtin_nontemporal_load(acol + j);
-            n += brpt[c + 1] - brpt[c];
+    constexpr int RPB = 256 / W;
+    // grid-stride over rows: the grid is capped so that the ~10 same-address global atomics
+    // per workgroup at the end stay in the low thousands (they serialise in L2).
+    for (int row = blockIdx.x * RPB + threadIdx.x / W; row - (int)(threadIdx.x / W) < M; row += gridDim.x * RPB) {
+        long long n = 0;
+        if (row < M) {
+            const int e = arpt[row + 1];
+            for (int j = arpt[row] + lane; j < e; j += W) {
+                const int c = __builtin_nontemporal_load(acol + j);
+                n += brpt[c + 1] - brpt[c];
+            }
         }
-    }
 #pragma unroll
-    for (int o = W / 2; o >= 1; o >>= 1) n += __shfl_xor(n, o);
-    if (row < M && lane == 0) {
-        const int ni = n > 0x7fffffffLL ? 0x7fffffff : (int)n;  // saturate (hub rows)
-        row_prod[row] = ni;
-        atomicAdd(&s_hist[bin_of(ni, thr)], 1);
-        atomicMax(&s_max, ni);
-        atomicAdd(&s_total, (unsigned long long)n);
+        for (int o = W / 2; o >= 1; o >>= 1) n += __shfl_xor(n, o);
+        if (row < M && lane == 0) {
+            const int ni = n > 0x7fffffffLL ? 0x7fffffff : (int)n;  // saturate (hub rows)
+            row_prod[row] = ni;
+            atomicAdd(&s_hist[bin_of(ni, thr)], 1);
+            atomicMax(&s_max, ni);
+            atomicAdd(&s_total, (unsigned long long)n);
+        }
     }
     __syncthreads();
     if (threadIdx.x < NB && s_hist[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], s_hist[threadIdx.x]);
     if (threadIdx.x == 0) {
-        atomicMax(&bs->maxv, s_max);
-        atomicAdd((unsigned long long *)&bs->total, s_total);
+        if (s_max > __hip_atomic_load(&bs->maxv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&bs->maxv, s_max);
+        if (s_total) atomicAdd((unsigned long long *)&bs->total, s_total);
     }
 }
 
@@ -333,24 +415,28 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
     __syncthreads();
 
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(np, a_end - a_beg);
-    const int ngroups = BS / g;
-    const int gid = threadIdx.x / g, gl = threadIdx.x % g;
+    const int g = group_width(np, a_end - a_beg, BS);
     int cnt = 0;
-    bool full = false;
-    for (int j = a_beg + gid; j < a_end && !full; j += ngroups) {
-        const int c = __builtin_nontemporal_load(acol + j);
-        const int ke = brpt[c + 1];
-        for (int k = brpt[c] + gl; k < ke; k += g) {
-            if (LARGE) {
+    if (!LARGE) {
+        walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, a_beg,
+                                 a_end, g, [&](int key, real) {
+                                     int fresh;
+                                     ht_find_or_insert(tab, mask, key, &fresh);
+                                     cnt += fresh;
+                                 });
+    } else {
+        // try-in-LDS: plain walk with early exit once the table holds kSymLargeLimit keys
+        const int ngroups = BS / g;
+        const int gid = threadIdx.x / g, gl = threadIdx.x % g;
+        bool full = false;
+        for (int j = a_beg + gid; j < a_end && !full; j += ngroups) {
+            const int c = __builtin_nontemporal_load(acol + j);
+            const int ke = brpt[c + 1];
+            for (int k = brpt[c] + gl; k < ke; k += g) {
                 if (lds_load(&s_nz) >= kSymLargeLimit) { full = true; break; }
-            }
-            int fresh;
-            ht_find_or_insert(tab, mask, bcol[k], &fresh);
-            if (LARGE) {
+                int fresh;
+                ht_find_or_insert(tab, mask, bcol[k], &fresh);
                 if (fresh) atomicAdd(&s_nz, 1);
-            } else {
-                cnt += fresh;
             }
         }
     }
@@ -569,19 +655,12 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     __syncthreads();
 
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(row_prod[rid], a_end - a_beg);
-    const int ngroups = BS / g;
-    const int gid = threadIdx.x / g, gl = threadIdx.x % g;
-    for (int j = a_beg + gid; j < a_end; j += ngroups) {
-        const int c = __builtin_nontemporal_load(acol + j);
-        const real av = __builtin_nontemporal_load(aval + j);
-        const int ke = brpt[c + 1];
-        for (int k = brpt[c] + gl; k < ke; k += g) {
-            int fresh;
-            const int h = ht_find_or_insert(keys, mask, bcol[k], &fresh);
-            unsafeAtomicAdd(vals + h, av * bval[k]);
-        }
-    }
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS);
+    walk_products<BS, true>(acol, aval, brpt, bcol, bval, a_beg, a_end, g, [&](int key, real v) {
+        int fresh;
+        const int h = ht_find_or_insert(keys, mask, key, &fresh);
+        unsafeAtomicAdd(vals + h, v);
+    });
     __syncthreads();
 
     // compaction: ballot + popcount inside the wave, one LDS atomic per 64 slots
@@ -716,7 +795,8 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, int *row_prod, B
 {
     const int M = a->M;
     const int w = pick_w(a->nnz, M);
-    const int grid = ceil_div((long long)M * w, 256);
+    int grid = ceil_div((long long)M * w, 256);
+    if (grid > 2048) grid = 2048;
 #define NSP_RP(W)                                                                              \
     case W:                                                                                    \
         hipLaunchKernelGGL(k_row_products<W>, dim3(grid), dim3(256), 0, st, a->d_rpt, a->d_col, \
