@@ -44,7 +44,7 @@ struct Context {
     hipEvent_t ev_fork = nullptr;
     hipEvent_t ev_join[kMaxBins] = {};
     hipEvent_t ev_t[8] = {};            // phase timing
-    hipEvent_t ev_bin[2 * kMaxBins] = {};  // per-bin kernel timing (profiling mode)
+    hipEvent_t ev_bin[4 * kMaxBins] = {};  // per-bin begin/end: [0,2B) symbolic, [2B,4B) numeric
     int *h_pinned = nullptr;            // 256 ints of pinned host memory for small D2H
     int *d_scratch = nullptr;           // 256 ints of device scratch (counters)
     bool profiling = false;

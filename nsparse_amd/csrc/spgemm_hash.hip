@@ -772,14 +772,15 @@ __global__ __launch_bounds__(BS) void k_num_global(const int *__restrict__ arpt,
 //  host orchestration
 // ===================================================================================
 
-static void scan_exclusive(const int *in, int *out, int n, hipStream_t st)
+static void *scan_exclusive(const int *in, int *out, int n, hipStream_t st)
 {
     size_t tmp_bytes = 0;
     NSP_CHECK(rocprim::exclusive_scan(nullptr, tmp_bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), st));
     void *tmp = dev_alloc(tmp_bytes ? tmp_bytes : 1);
     NSP_CHECK(rocprim::exclusive_scan(tmp, tmp_bytes, in, out, 0, (size_t)n, rocprim::plus<int>(), st));
-    NSP_CHECK(hipStreamSynchronize(st));
-    dev_free(tmp);
+    // stream-ordered: the block returns to the cache only at the end of the call (dev_free
+    // does not touch the device), and every later use of it is ordered after this scan
+    return tmp;
 }
 
 static inline int pick_w(long long nnz, int M)
@@ -824,42 +825,40 @@ struct Timer {
 // streams: bin b runs on cx.stream[b]; stream[0] is the main line.  In profiling mode
 // everything is serialised on stream[0] and bracketed by events.
 struct BinLauncher {
-    Context &cx;
+    Context *cx;
+    hipEvent_t *ev;  // 2 * NB events: begin/end of every bin
     bool used[NB] = {};
     bool serial;  // profiling mode: one stream, bins back to back
-    explicit BinLauncher(Context &c) : cx(c), serial(c.profiling) {}
+    BinLauncher(Context &c, int phase) : cx(&c), ev(c.ev_bin + phase * 2 * NB), serial(c.profiling) {}
     void fork()
     {
-        if (!serial) NSP_CHECK(hipEventRecord(cx.ev_fork, cx.stream[0]));
+        if (!serial) NSP_CHECK(hipEventRecord(cx->ev_fork, cx->stream[0]));
     }
     // The begin/end events sit on the stream the bin's kernels are launched on, so their
     // difference is the duration of those kernels whether or not other bins overlap.
     hipStream_t begin(int b)
     {
-        hipStream_t st = serial ? cx.stream[0] : cx.stream[b];
-        if (!serial && b != 0 && !used[b]) NSP_CHECK(hipStreamWaitEvent(st, cx.ev_fork, 0));
+        hipStream_t st = serial ? cx->stream[0] : cx->stream[b];
+        if (!serial && b != 0 && !used[b]) NSP_CHECK(hipStreamWaitEvent(st, cx->ev_fork, 0));
         used[b] = true;
-        NSP_CHECK(hipEventRecord(cx.ev_bin[2 * b], st));
+        NSP_CHECK(hipEventRecord(ev[2 * b], st));
         return st;
     }
-    void end(int b)
-    {
-        NSP_CHECK(hipEventRecord(cx.ev_bin[2 * b + 1], serial ? cx.stream[0] : cx.stream[b]));
-    }
+    void end(int b) { NSP_CHECK(hipEventRecord(ev[2 * b + 1], serial ? cx->stream[0] : cx->stream[b])); }
     void join()
     {
         if (serial) return;
         for (int b = 1; b < NB; b++) {
             if (!used[b]) continue;
-            NSP_CHECK(hipEventRecord(cx.ev_join[b], cx.stream[b]));
-            NSP_CHECK(hipStreamWaitEvent(cx.stream[0], cx.ev_join[b], 0));
+            NSP_CHECK(hipEventRecord(cx->ev_join[b], cx->stream[b]));
+            NSP_CHECK(hipStreamWaitEvent(cx->stream[0], cx->ev_join[b], 0));
         }
     }
-    void collect(float *out)
+    void collect(float *out)  // call after the device is idle
     {
         for (int b = 0; b < NB; b++) {
             out[b] = 0;
-            if (used[b]) NSP_CHECK(hipEventElapsedTime(&out[b], cx.ev_bin[2 * b], cx.ev_bin[2 * b + 1]));
+            if (used[b]) NSP_CHECK(hipEventElapsedTime(&out[b], ev[2 * b], ev[2 * b + 1]));
         }
     }
 };
@@ -877,11 +876,11 @@ static int global_slab_groups(long long slice_elems, size_t bytes_per_elem, int 
     return (int)g;
 }
 
-static void symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, int *row_nz,
+static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, int *row_nz,
                            int *row_perm, const int *hist, int max_prod, BinState *d_bs,
                            Context &cx, float *ms_bin, int *fail_rows)
 {
-    BinLauncher L(cx);
+    BinLauncher L(cx, 0);
     int off[NB + 1];
     off[0] = 0;
     for (int q = 0; q < NB; q++) off[q + 1] = off[q] + hist[q];
@@ -898,9 +897,11 @@ static void symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, int *r
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
+    static const int tune_s3 = getenv("NSPARSE_SYM3_BS") ? atoi(getenv("NSPARSE_SYM3_BS")) : 512;
+    static const int tune_s2 = getenv("NSPARSE_SYM2_BS") ? atoi(getenv("NSPARSE_SYM2_BS")) : 128;
     NSP_SYM_TB(4, 1024, 32768)
-    NSP_SYM_TB(3, 256, 8192)
-    NSP_SYM_TB(2, 128, 2048)
+    if (tune_s3 == 512) { NSP_SYM_TB(3, 512, 8192) } else if (tune_s3 == 1024) { NSP_SYM_TB(3, 1024, 8192) } else { NSP_SYM_TB(3, 256, 8192) }
+    if (tune_s2 == 256) { NSP_SYM_TB(2, 256, 2048) } else { NSP_SYM_TB(2, 128, 2048) }
     NSP_SYM_TB(1, 64, 512)
 #undef NSP_SYM_TB
     if (hist[0] > 0) {
@@ -938,16 +939,15 @@ static void symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, int *r
         L.end(5);
     }
     L.join();
-    NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
-    L.collect(ms_bin);
-    if (fail_list) dev_free(fail_list);
+    if (fail_list) dev_free(fail_list);  // its kernels have completed (bin 5 synchronises)
+    return L;
 }
 
-static void numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const int *row_prod,
+static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const int *row_prod,
                           const int *row_perm, const int *hist, int max_nz, BinState *d_bs,
                           Context &cx, float *ms_bin, int write_col)
 {
-    BinLauncher L(cx);
+    BinLauncher L(cx, 1);
     int off[NB + 1];
     off[0] = 0;
     for (int q = 0; q < NB; q++) off[q + 1] = off[q] + hist[q];
@@ -998,10 +998,12 @@ static void numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const int *r
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
+    static const int tune_n2 = getenv("NSPARSE_NUM2_BS") ? atoi(getenv("NSPARSE_NUM2_BS")) : 256;
+    static const int tune_n1 = getenv("NSPARSE_NUM1_BS") ? atoi(getenv("NSPARSE_NUM1_BS")) : 64;
     NSP_NUM_TB(4, 1024, 8192, 8192)
     NSP_NUM_TB(3, 512, 4096, 4096)
-    NSP_NUM_TB(2, 256, 1024, 1024)
-    NSP_NUM_TB(1, 64, 256, 256)
+    if (tune_n2 == 128) { NSP_NUM_TB(2, 128, 1024, 1024) } else if (tune_n2 == 512) { NSP_NUM_TB(2, 512, 1024, 1024) } else { NSP_NUM_TB(2, 256, 1024, 1024) }
+    if (tune_n1 == 128) { NSP_NUM_TB(1, 128, 256, 256) } else { NSP_NUM_TB(1, 64, 256, 256) }
 #undef NSP_NUM_TB
     if (hist[0] > 0) {
         hipStream_t st = L.begin(0);
@@ -1013,8 +1015,7 @@ static void numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const int *r
         L.end(0);
     }
     L.join();
-    NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
-    L.collect(ms_bin);
+    return L;
 }
 
 static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
@@ -1034,6 +1035,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     BinState *h_num = h_sym + 1;
     static_assert(2 * sizeof(BinState) <= 128 * sizeof(int), "scratch layout");
 
+    void *scan_tmp = nullptr;
+    BinLauncher sym_used(cx, 0);
     int *row_prod = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_nz = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_perm = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
@@ -1057,11 +1060,12 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     if (!numeric_only) {
         c->M = M;
         c->N = b->N;
-        symbolic_phase(a, b, row_prod, row_nz, row_perm, h_sym->hist, h_sym->maxv, d_sym, cx,
-                       S.ms_sym_bin, &S.sym_fail_rows);
+        BinLauncher LS = symbolic_phase(a, b, row_prod, row_nz, row_perm, h_sym->hist, h_sym->maxv,
+                                        d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows);
+        sym_used = LS;
         c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
         NSP_CHECK(hipMemsetAsync(row_nz + M, 0, sizeof(int), s0));
-        scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
+        scan_tmp = scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
     } else {
         // structure given: row_nz[i] = rpt[i+1] - rpt[i] is recovered inside the kernels
         // from C.rpt; for binning we need it explicitly.
@@ -1087,16 +1091,18 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     S.nnz_c = c->nnz;
 
     // ---- numeric --------------------------------------------------------------------
-    numeric_phase(a, b, c, row_prod, row_perm, h_num->hist, h_num->maxv, d_num, cx, S.ms_num_bin,
-                  numeric_only ? 0 : 1);
+    BinLauncher LN = numeric_phase(a, b, c, row_prod, row_perm, h_num->hist, h_num->maxv, d_num, cx,
+                                   S.ms_num_bin, numeric_only ? 0 : 1);
     tm.mark(3, s0);
-    NSP_CHECK(hipStreamSynchronize(s0));
-    NSP_CHECK(hipDeviceSynchronize());  // synchronous on return, like upstream (:1287)
+    NSP_CHECK(hipStreamSynchronize(s0));  // synchronous on return, like upstream (:1287)
+    LN.collect(S.ms_num_bin);
+    sym_used.collect(S.ms_sym_bin);
     S.ms_setup = tm.ms(0, 1);
     S.ms_symbolic = tm.ms(1, 2);
     S.ms_numeric = tm.ms(2, 3);
     S.ms_total = tm.ms(0, 3);
 
+    dev_free(scan_tmp);
     dev_free(row_perm);
     dev_free(row_nz);
     dev_free(row_prod);
