@@ -106,6 +106,15 @@ __host__ __device__ __forceinline__ int bin_of(int n, const Thr &thr)
     return b;
 }
 
+// Slot of a column id.  (key * 107) >> 2: keys that differ by 1 land ~27 slots apart and keys
+// that differ by 4 land 107 slots apart -- both odd strides, so neither the lanes of a V = 1
+// walk (consecutive columns) nor the VW = 4 walk (every lane holds 4 consecutive entries, so
+// one CAS instruction sees columns of stride 4) pile up on a few of the 32 LDS banks.
+__device__ __forceinline__ int hash_slot(int key, int mask)
+{
+    return (int)((((unsigned)key * (unsigned)HASH_SCAL) >> 2) & (unsigned)mask);
+}
+
 __device__ __forceinline__ int pow2_ceil(int v) { return v <= 1 ? 1 : (1 << (32 - __clz(v - 1))); }
 
 __device__ __forceinline__ int lds_load(const int *p)
@@ -115,17 +124,18 @@ __device__ __forceinline__ int lds_load(const int *p)
 
 // Insert `key` into an open-addressing table of (mask+1) ints (empty = -1), linear
 // probing.  Returns the slot; *fresh = 1 when this call created the entry.
+// One LDS compare-and-swap per probe and nothing else: CAS(slot, -1, key) returns -1 (we
+// inserted), key (already there, nothing written) or another key (next slot).  The
+// read-then-CAS form of the reference costs three times the instructions on CDNA (nested
+// exec-mask regions) and the kernels are issue-bound, not LDS-bound.
 __device__ __forceinline__ int ht_find_or_insert(int *tab, int mask, int key, int *fresh)
 {
-    int h = (int)(((unsigned)key * (unsigned)HASH_SCAL) & (unsigned)mask);
-    *fresh = 0;
+    int h = hash_slot(key, mask);
     while (true) {
-        const int cur = lds_load(tab + h);
-        if (cur == key) return h;
-        if (cur == -1) {
-            const int old = atomicCAS(tab + h, -1, key);
-            if (old == -1) { *fresh = 1; return h; }
-            if (old == key) return h;
+        const int old = atomicCAS(tab + h, -1, key);
+        if (old == -1 || old == key) {
+            *fresh = old == -1;
+            return h;
         }
         h = (h + 1) & mask;
     }
@@ -157,9 +167,21 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
+// Every lane takes VW consecutive entries of a B row per step: one 16-byte column load and
+// VW/2 16-byte value loads instead of VW scalar pairs, and the walk's bookkeeping (the kernels
+// are instruction-issue-bound: rocprofv3 shows VALU 73 % / SALU 83 % busy, LDS 15 %) is paid
+// once per VW products.
+constexpr int VW = 4;
+struct __attribute__((aligned(4))) IVec {
+    int v[VW];
+};
+struct __attribute__((aligned(sizeof(real) < 8 ? 4 : 8))) RVec {
+    real v[VW];
+};
+
 // Lanes per B row for a C row with `np` products spread over `alen` entries of A, for a
 // workgroup of BS threads.  With g lanes per group the row takes
-//     ceil(alen / (BS/g)) * ceil(avg_len / g)   group steps,
+//     ceil(alen / (BS/g)) * ceil(avg_len / (g*VW))   group steps,
 // so g trades padding of the B rows (small g pads less) against imbalance between groups
 // (large g, few groups).  The largest g with the fewest steps wins.
 __device__ __forceinline__ int group_width(int np, int alen, int BS)
@@ -170,10 +192,16 @@ __device__ __forceinline__ int group_width(int np, int alen, int BS)
 #pragma unroll
     for (int g = 64; g >= 1; g >>= 1) {
         const int ng = BS / g;
-        const int t = ((alen + ng - 1) / ng) * ((avg + g - 1) / g);
+        const int t = ((alen + ng - 1) / ng) * ((avg + g * VW - 1) / (g * VW));
         if (t < best_t) { best_t = t; best_g = g; }
     }
     return best_g;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Walk every intermediate product of one C row with the threads of a workgroup and hand
@@ -181,65 +209,109 @@ __device__ __forceinline__ int group_width(int np, int alen, int BS)
 //
 // The naive loop (per A entry: load A.col -> load B.rpt[c], B.rpt[c+1] -> load B.col/B.val)
 // is a chain of three dependent global loads per A entry, 2-3 k cycles of latency for one or
-// two wave-steps of work.  Here each lane of a group loads ONE A entry and its B row extent,
-// so a batch of g entries costs the two dependent latencies once; the entries are then
-// broadcast inside the group with wave shuffles (ds_bpermute), and the first chunk of B row
-// t+1 is already in flight while row t is being hashed.
+// two wave-steps of work.  Here each lane of a group loads ONE A entry and its B row extent
+// and parks them in LDS (`s_ext`, `s_av`: one slot per thread), so a batch of g entries costs
+// the two dependent latencies once.  The group then runs a flat state machine over
+// (entry, chunk-of-g) steps in which the loads of step s+1 are issued before step s is
+// hashed, so every B chunk is in flight for a whole hashing step.
+// VW entries of a B row starting at i0; returns how many of them belong to the row (< ke).
+// The load is always the full 16-byte vector: elements past ke belong to the next row of B
+// (valid memory, masked out by the returned count); only the last VW-1 entries of the whole
+// array (i0 + VW > bnnz) take the element-wise path.
+template <bool WITH_VAL>
+__device__ __forceinline__ int fetch_chunk(const int *__restrict__ bcol, const real *__restrict__ bval,
+                                           int i0, int ke, int bnnz, IVec &k, RVec &v)
+{
+    int n = ke - i0;
+    n = n < 0 ? 0 : (n > VW ? VW : n);
+    if (n > 0) {
+        if (i0 + VW <= bnnz) {
+            k = *reinterpret_cast<const IVec *>(bcol + i0);
+            if (WITH_VAL) v = *reinterpret_cast<const RVec *>(bval + i0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VW; i++) {
+                const int ii = i < n ? i0 + i : i0;
+                k.v[i] = bcol[ii];
+                if (WITH_VAL) v.v[i] = bval[ii];
+            }
+        }
+    }
+    return n;
+}
+
 template <int BS, bool WITH_VAL, typename F>
 __device__ __forceinline__ void walk_products(const int *__restrict__ acol, const real *__restrict__ aval,
                                               const int *__restrict__ brpt, const int *__restrict__ bcol,
-                                              const real *__restrict__ bval, int a_beg, int a_end,
-                                              int g, F &&consume)
+                                              const real *__restrict__ bval, int bnnz, int a_beg,
+                                              int a_end, int g, int2 *s_ext, real *s_av, F &&consume)
 {
     const int ngroups = BS / g;
     const int gid = threadIdx.x / g, gl = threadIdx.x % g;
     const int first = a_beg + gid;
     const int cnt = first < a_end ? (a_end - first + ngroups - 1) / ngroups : 0;
-    // wave-uniform trip count: the first group of the wave owns the most entries
-    const int gid0 = (int)(threadIdx.x & ~63u) / g;
-    const int first0 = a_beg + gid0;
-    const int cnt_max = first0 < a_end ? (a_end - first0 + ngroups - 1) / ngroups : 0;
-    for (int b0 = 0; b0 < cnt_max; b0 += g) {
+    int2 *ext = s_ext + gid * g;
+    real *avs = s_av + gid * g;
+    const int lane_off = gl * VW;
+    const int stride = g * VW;
+    for (int b0 = 0; b0 < cnt; b0 += g) {
         const int m = b0 + gl;
-        int my_kb = 0, my_ke = 0;
-        real my_av = 0;
+        int2 e = make_int2(0, 0);
+        real av = 0;
         if (m < cnt) {
             const int j = first + m * ngroups;
             const int c = __builtin_nontemporal_load(acol + j);
-            if (WITH_VAL) my_av = __builtin_nontemporal_load(aval + j);
-            my_kb = brpt[c];
-            my_ke = brpt[c + 1];
+            if (WITH_VAL) av = __builtin_nontemporal_load(aval + j);
+            e.x = brpt[c];
+            e.y = brpt[c + 1];
         }
-        const int nb = cnt_max - b0 < g ? cnt_max - b0 : g;
-        int cur_kb = __shfl(my_kb, 0, g), cur_ke = __shfl(my_ke, 0, g);
-        real cur_av = WITH_VAL ? __shfl(my_av, 0, g) : (real)0;
-        int k = cur_kb + gl;
-        bool pre_ok = k < cur_ke;
-        int pre_key = 0;
-        real pre_val = 0;
-        if (pre_ok) {
-            pre_key = bcol[k];
-            if (WITH_VAL) pre_val = bval[k];
-        }
-        for (int t = 0; t < nb; t++) {
-            const int tn = t + 1 < nb ? t + 1 : t;
-            const int nxt_kb = __shfl(my_kb, tn, g), nxt_ke = __shfl(my_ke, tn, g);
-            const real nxt_av = WITH_VAL ? __shfl(my_av, tn, g) : (real)0;
-            const bool ok = pre_ok;
-            const int key = pre_key;
-            const real val = pre_val;
-            const int kn = nxt_kb + gl;
-            pre_ok = (t + 1 < nb) && kn < nxt_ke;
-            if (pre_ok) {
-                pre_key = bcol[kn];
-                if (WITH_VAL) pre_val = bval[kn];
+        ext[gl] = e;
+        if (WITH_VAL) avs[gl] = av;
+        wave_lds_sync();  // a group never spans wavefronts: in-order LDS is enough
+        const int nb = cnt - b0 < g ? cnt - b0 : g;
+        int t = 0;
+        int2 cur = ext[0];
+        real cav = WITH_VAL ? avs[0] : (real)0;
+        int base = cur.x;
+        IVec pk;
+        RVec pv;
+        int pn = fetch_chunk<WITH_VAL>(bcol, bval, base + lane_off, cur.y, bnnz, pk, pv);
+        while (t < nb) {
+            const IVec ck = pk;
+            const RVec cv = pv;
+            const int cn = pn;
+            const real sc = cav;
+            base += stride;
+            if (base >= cur.y) {
+                t++;
+                if (t < nb) {
+                    cur = ext[t];
+                    if (WITH_VAL) cav = avs[t];
+                    base = cur.x;
+                }
             }
-            if (ok) consume(key, cur_av * val);
-            for (int kk = cur_kb + gl + g; kk < cur_ke; kk += g) consume(bcol[kk], WITH_VAL ? cur_av * bval[kk] : (real)0);
-            cur_kb = nxt_kb;
-            cur_ke = nxt_ke;
-            cur_av = nxt_av;
+            pn = t < nb ? fetch_chunk<WITH_VAL>(bcol, bval, base + lane_off, cur.y, bnnz, pk, pv) : 0;
+            if (cn > 0) consume(ck, cv, cn, sc);
         }
+        wave_lds_sync();
+    }
+}
+
+// VW find-or-insert operations of one lane, the first probes issued back to back
+__device__ __forceinline__ void ht_insert_vec(int *tab, int mask, const IVec &k, int n, int (&h)[VW], int &fresh)
+{
+    int old[VW];
+#pragma unroll
+    for (int i = 0; i < VW; i++) h[i] = hash_slot(k.v[i], mask);
+#pragma unroll
+    for (int i = 0; i < VW; i++) old[i] = i < n ? atomicCAS(tab + h[i], -1, k.v[i]) : k.v[i];
+#pragma unroll
+    for (int i = 0; i < VW; i++) {
+        while (old[i] != -1 && old[i] != k.v[i]) {
+            h[i] = (h[i] + 1) & mask;
+            old[i] = atomicCAS(tab + h[i], -1, k.v[i]);
+        }
+        fresh += old[i] == -1;
     }
 }
 
@@ -395,10 +467,11 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                                const int *__restrict__ bcol,
                                                const int *__restrict__ row_perm,
                                                const int *__restrict__ row_prod,
-                                               int *__restrict__ row_nz, int bin_off,
+                                               int *__restrict__ row_nz, int bin_off, int bnnz,
                                                BinState *bs, int *__restrict__ fail_list)
 {
     __shared__ __attribute__((aligned(16))) int tab[TMAX];
+    __shared__ int2 s_ext[LARGE ? 1 : BS];
     __shared__ int s_nz;
     const int rid = row_perm[bin_off + blockIdx.x];
     const int np = row_prod[rid];
@@ -418,11 +491,11 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
     const int g = group_width(np, a_end - a_beg, BS);
     int cnt = 0;
     if (!LARGE) {
-        walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, a_beg,
-                                 a_end, g, [&](int key, real) {
-                                     int fresh;
-                                     ht_find_or_insert(tab, mask, key, &fresh);
-                                     cnt += fresh;
+        walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz,
+                                 a_beg, a_end, g, s_ext, (real *)nullptr,
+                                 [&](const IVec &k, const RVec &, int n, real) {
+                                     int h[VW];
+                                     ht_insert_vec(tab, mask, k, n, h, cnt);
                                  });
     } else {
         // try-in-LDS: plain walk with early exit once the table holds kSymLargeLimit keys
@@ -634,11 +707,13 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
                                                int *__restrict__ ccol, real *__restrict__ cval,
                                                const int *__restrict__ row_perm,
                                                const int *__restrict__ row_prod, int bin_off,
-                                               int write_col)
+                                               int bnnz, int write_col)
 {
     __shared__ __attribute__((aligned(16))) real vals[TMAX];
     __shared__ __attribute__((aligned(16))) int keys[TMAX];
     __shared__ __attribute__((aligned(16))) int srt[PMAX];
+    __shared__ int2 s_ext[BS];
+    __shared__ real s_av[BS];
     __shared__ int s_cnt;
     const int rid = row_perm[bin_off + blockIdx.x];
     const int off = crpt[rid];
@@ -656,11 +731,14 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
 
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
     const int g = group_width(row_prod[rid], a_end - a_beg, BS);
-    walk_products<BS, true>(acol, aval, brpt, bcol, bval, a_beg, a_end, g, [&](int key, real v) {
-        int fresh;
-        const int h = ht_find_or_insert(keys, mask, key, &fresh);
-        unsafeAtomicAdd(vals + h, v);
-    });
+    walk_products<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av,
+                            [&](const IVec &k, const RVec &v, int n, real sc) {
+                                int h[VW], fresh = 0;
+                                ht_insert_vec(keys, mask, k, n, h, fresh);
+#pragma unroll
+                                for (int i = 0; i < VW; i++)
+                                    if (i < n) unsafeAtomicAdd(vals + h[i], sc * v.v[i]);
+                            });
     __syncthreads();
 
     // compaction: ballot + popcount inside the wave, one LDS atomic per 64 slots
@@ -683,7 +761,7 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
 
     for (int i = threadIdx.x; i < n; i += BS) {
         const int key = srt[i];
-        int h = (int)(((unsigned)key * (unsigned)HASH_SCAL) & (unsigned)mask);
+        int h = hash_slot(key, mask);
         while (keys[h] != key) h = (h + 1) & mask;
         if (write_col) ccol[off + i] = key;
         cval[off + i] = vals[h];
@@ -892,7 +970,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     if (hist[BIN] > 0) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_tb<BS, TMAX, false>), dim3(hist[BIN]), dim3(BS), 0, st, arpt, \
-                           acol, brpt, bcol, row_perm, row_prod, row_nz, off[BIN], d_bs,       \
+                           acol, brpt, bcol, row_perm, row_prod, row_nz, off[BIN], b->nnz, d_bs, \
                            (int *)nullptr);                                                    \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
@@ -918,7 +996,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         hipStream_t st = L.begin(5);
         fail_list = (int *)dev_alloc(sizeof(int) * (size_t)hist[5]);
         hipLaunchKernelGGL((k_sym_tb<1024, kSymLargeT, true>), dim3(hist[5]), dim3(1024), 0, st, arpt,
-                           acol, brpt, bcol, row_perm, row_prod, row_nz, off[5], d_bs, fail_list);
+                           acol, brpt, bcol, row_perm, row_prod, row_nz, off[5], b->nnz, d_bs, fail_list);
         NSP_LAUNCH_CHECK();
         NSP_CHECK(hipMemcpyAsync(cx.h_pinned + 128, &d_bs->fail_count, sizeof(int), hipMemcpyDeviceToHost, st));
         NSP_CHECK(hipStreamSynchronize(st));
@@ -994,7 +1072,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX>), dim3(hist[BIN]), dim3(BS), 0, st, arpt,  \
                            acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, \
-                           row_prod, off[BIN], write_col);                                     \
+                           row_prod, off[BIN], b->nnz, write_col);                                     \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
