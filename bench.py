@@ -66,22 +66,21 @@ def load_or_synth(lib, name, kind, dims, seed, rows=(0, 0)):
     return synth(lib, kind, dims[0], dims[1], dims[2], seed, rows), f"synthetic {name}-class"
 
 
-def numeric_bin_bytes(A, B, crpt, thresholds, w):
+def numeric_bin_bytes(A, B, crpt, ladder, w):
     """Algorithmic bytes of each numeric-bin launch (SURVEY 8d numeric term, restricted to the
     rows of the bin): per row 12 B (C.rpt pair + permutation entry) + (12+w) per A entry
     (col, val, two B.rpt gathers) + (4+w) per intermediate product (B col, val) + (4+w) per
-    C entry written."""
+    C entry written.  Rows are assigned to bins with the library's own rule (bins_of)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import bins_of, row_windows
+    row_prod, span = row_windows(A, B)
     alen = np.diff(A["rpt"]).astype(np.int64)
-    blen = np.diff(B["rpt"]).astype(np.int64)
-    per_entry = blen[A["col"]]
-    row_prod = np.add.reduceat(np.concatenate([per_entry, [0]]), A["rpt"][:-1].astype(np.int64))
-    row_prod[alen == 0] = 0
     nzc = np.diff(crpt).astype(np.int64)
-    bins = np.searchsorted(np.asarray(thresholds, dtype=np.int64), nzc, side="left")
+    bins = bins_of(nzc, span, ladder)
     per_row = 12 + (12 + w) * alen + (4 + w) * (row_prod + nzc)
-    out = np.zeros(8)
-    prods = np.zeros(8)
-    for b in range(8):
+    out = np.zeros(12)
+    prods = np.zeros(12)
+    for b in range(12):
         sel = bins == b
         out[b] = per_row[sel].sum()
         prods[b] = row_prod[sel].sum()
@@ -149,8 +148,8 @@ def main():
     for _ in range(args.warmup):
         lib.spgemm_kernel_hash(C.byref(a), C.byref(b), C.byref(c))
         lib.release_csr(c)
-    bin_ms = np.zeros(8)
-    sym_ms = np.zeros(8)
+    bin_ms = np.zeros(12)
+    sym_ms = np.zeros(12)
     phase = np.zeros(4)
     barrier()
     t_start = time.perf_counter()
@@ -180,8 +179,8 @@ def main():
     crpt = lib.d2h(c.d_rpt, (c.M + 1,), np.int32)
     nnz_c = c.nnz
     lib.release_csr(c)
-    sym_thr = (C.c_int * 7)()
-    num_thr = (C.c_int * 7)()
+    sym_thr = (C.c_int * 9)()
+    num_thr = (C.c_int * 9)()
     lib.nsparse_get_spgemm_bins(sym_thr, num_thr)
     bytes_bin, prods_bin, row_prod = numeric_bin_bytes(A_loc, A_full, crpt, list(num_thr), w)
     dom = int(np.argmax(bin_ms))
@@ -197,7 +196,7 @@ def main():
     nnz_a = int(A_loc["rpt"][-1])
     b_spgemm = (8 + w) * n_prod + (36 + w) * nnz_a + (4 + w) * nnz_c + 40 * a.M
     roofline = {
-        "bound": "hbm", "kernel": f"k_num_tb (numeric bin {dom})", "achieved": round(achieved, 1),
+        "bound": "hbm", "kernel": f"{'k_num_dense' if dom >= 6 else 'k_num_tb'} (numeric bin {dom})", "achieved": round(achieved, 1),
         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
         "traffic": traffic,
         "bytes_per_launch": int(bytes_bin[dom]), "ms_per_launch": round(float(bin_ms[dom]), 4),
@@ -333,9 +332,9 @@ def main():
                        "timing": "whole spgemm_kernel_hash call incl. allocation (block cache on)"},
             "phase_ms": {"setup": round(float(phase[0]), 4), "symbolic": round(float(phase[1]), 4),
                          "numeric": round(float(phase[2]), 4), "total_events": round(float(phase[3]), 4),
-                         "numeric_bins": [round(float(v), 4) for v in bin_ms[:6]],
-                         "symbolic_bins": [round(float(v), 4) for v in sym_ms[:6]],
-                         "sym_bin_rows": list(st.sym_bin_size)[:6], "num_bin_rows": list(st.num_bin_size)[:6]},
+                         "numeric_bins": [round(float(v), 4) for v in bin_ms[:9]],
+                         "symbolic_bins": [round(float(v), 4) for v in sym_ms[:9]],
+                         "sym_bin_rows": list(st.sym_bin_size)[:9], "num_bin_rows": list(st.num_bin_size)[:9]},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "spmv": spmv,

@@ -220,19 +220,21 @@ typedef struct {
     int nnz_c;
     int max_prod_row;         /* longest row of intermediate products               */
     int max_nnz_row;          /* longest row of C                                   */
-    int sym_bin_size[8];      /* rows per symbolic bin                              */
-    int num_bin_size[8];      /* rows per numeric bin                               */
+    int sym_bin_size[12];     /* rows per symbolic bin (0 tiny, 1-5 hash, 6-8 dense window) */
+    int num_bin_size[12];     /* rows per numeric bin                               */
     int sym_fail_rows;        /* rows that overflowed LDS and went to the global table */
     float ms_setup;           /* products + binning              (HIP events)       */
     float ms_symbolic;        /* all symbolic kernels + scan     (HIP events)       */
     float ms_numeric;         /* numeric binning + all numeric kernels              */
     float ms_total;           /* whole call                                         */
-    float ms_sym_bin[8];      /* per-bin kernel time, HIP events on the bin's own stream */
-    float ms_num_bin[8];
+    float ms_sym_bin[12];      /* per-bin kernel time, HIP events on the bin's own stream */
+    float ms_num_bin[12];
 } nsparse_spgemm_stats;
 void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out);
 
-/* Upper thresholds of the symbolic / numeric bins (7 values each; bin 7 = above). */
+/* Bin ladder of the symbolic / numeric phase, 9 ints each: tiny, hash_t[4], dense_span[3],
+ * dense_ratio.  Row (n, span) -> bin: n <= tiny: 0; span <= dense_span[2] and
+ * span <= dense_ratio * n: 6 + #(dense_span < span); else 1 + #(hash_t < n).            */
 void nsparse_get_spgemm_bins(int *sym_thresholds, int *num_thresholds);
 
 /* 1: serialise the row bins on one stream (clean per-kernel durations for roofline work

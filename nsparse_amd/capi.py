@@ -45,10 +45,10 @@ class sfAMB(C.Structure):
 
 class SpgemmStats(C.Structure):
     _fields_ = [("n_prod", C.c_longlong), ("nnz_c", C.c_int), ("max_prod_row", C.c_int),
-                ("max_nnz_row", C.c_int), ("sym_bin_size", C.c_int * 8), ("num_bin_size", C.c_int * 8),
+                ("max_nnz_row", C.c_int), ("sym_bin_size", C.c_int * 12), ("num_bin_size", C.c_int * 12),
                 ("sym_fail_rows", C.c_int), ("ms_setup", C.c_float), ("ms_symbolic", C.c_float),
-                ("ms_numeric", C.c_float), ("ms_total", C.c_float), ("ms_sym_bin", C.c_float * 8),
-                ("ms_num_bin", C.c_float * 8)]
+                ("ms_numeric", C.c_float), ("ms_total", C.c_float), ("ms_sym_bin", C.c_float * 12),
+                ("ms_num_bin", C.c_float * 12)]
 
 
 # every entry point declared in include/nsparse.h: name -> (restype, argtypes)

@@ -101,8 +101,8 @@ Context &ctx()
         NSP_CHECK(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
         for (auto &e : c.ev_t) NSP_CHECK(hipEventCreate(&e));
         for (auto &e : c.ev_bin) NSP_CHECK(hipEventCreate(&e));
-        NSP_CHECK(hipHostMalloc((void **)&c.h_pinned, 256 * sizeof(int), hipHostMallocDefault));
-        NSP_CHECK(hipMalloc((void **)&c.d_scratch, 256 * sizeof(int)));
+        NSP_CHECK(hipHostMalloc((void **)&c.h_pinned, 512 * sizeof(int), hipHostMallocDefault));
+        NSP_CHECK(hipMalloc((void **)&c.d_scratch, 512 * sizeof(int)));
         c.ready = true;
     }
     return c;

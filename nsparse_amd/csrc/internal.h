@@ -37,7 +37,7 @@ void dev_cache_enable(bool on);
 void dev_cache_trim();
 
 // ---- per-process context ---------------------------------------------------------
-constexpr int kMaxBins = 8;
+constexpr int kMaxBins = 10;
 
 struct Context {
     hipStream_t stream[kMaxBins] = {};  // one per row bin (the reference uses 7)
@@ -45,8 +45,8 @@ struct Context {
     hipEvent_t ev_join[kMaxBins] = {};
     hipEvent_t ev_t[8] = {};            // phase timing
     hipEvent_t ev_bin[4 * kMaxBins] = {};  // per-bin begin/end: [0,2B) symbolic, [2B,4B) numeric
-    int *h_pinned = nullptr;            // 256 ints of pinned host memory for small D2H
-    int *d_scratch = nullptr;           // 256 ints of device scratch (counters)
+    int *h_pinned = nullptr;            // 512 ints of pinned host memory for small D2H
+    int *d_scratch = nullptr;           // 512 ints of device scratch (counters)
     bool profiling = false;
     bool ready = false;
 };

@@ -72,15 +72,26 @@ constexpr int NB = kMaxBins;
 //   bin 3  n <= 2730    512 threads, table <= 4096
 //   bin 4  n <= 5461    1024 threads, table <= 8192  (96 KiB fp64 + 32 KiB sort keys)
 //   bin 5  n  > 5461    global-memory tables
+// Row -> bin.  Bin 0: tiny rows (sub-wave kernels).  Bins 1..5: hash tables sized by n.
+// Bins 6..8: DENSE WINDOW rows -- the columns a C row can touch lie in [lo, lo+span) and
+// span is small enough for an LDS array indexed by (col - lo): no probing, no compare-and-swap
+// with return, no sort (see k_sym_dense / k_num_dense).  A row is dense-eligible when
+// span <= dense_span[2] and span <= dense_ratio * n (clearing and scanning the window must not
+// cost more than the products).
 struct Thr {
-    int t[NB - 1];
+    int tiny;            // n <= tiny           -> bin 0
+    int hash_t[4];       // n <= hash_t[k]      -> bin 1 + k, above -> bin 5
+    int dense_span[3];   // span <= dense_span[k] -> bin 6 + k
+    int dense_ratio;     // 0 disables the dense bins
 };
-constexpr Thr kSymThr = {{32, 512, 2048, 8192, 32768, 0x7fffffff, 0x7fffffff}};
-constexpr Thr kNumThr = {{16, 170, 682, 2730, 5461, 0x7fffffff, 0x7fffffff}};
+constexpr Thr kSymThr = {32, {512, 2048, 8192, 32768}, {4096, 16384, 65536}, 8};
+constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8};
 constexpr int kSymLargeBin = 5;
 constexpr int kNumGlobalBin = 5;
+constexpr int kDenseBin0 = 6;
 constexpr int kSymLargeT = 32768;
 constexpr int kSymLargeLimit = 24576;
+static int g_dense_enabled = -1;  // -1: read NSPARSE_DENSE on first use
 
 // device-resident counters of one binning pass (lives in Context::d_scratch)
 struct BinState {
@@ -98,11 +109,15 @@ struct Stats {
 };
 static Stats g_stats;
 
-__host__ __device__ __forceinline__ int bin_of(int n, const Thr &thr)
+__host__ __device__ __forceinline__ int bin_of(int n, int span, const Thr &thr)
 {
-    int b = 0;
+    if (n <= thr.tiny) return 0;
+    if (thr.dense_ratio > 0 && span > 0 && span <= thr.dense_span[2] &&
+        (long long)span <= (long long)thr.dense_ratio * n)
+        return kDenseBin0 + (span > thr.dense_span[0]) + (span > thr.dense_span[1]);
+    int b = 1;
 #pragma unroll
-    for (int q = 0; q < NB - 1; q++) b += (n > thr.t[q]) ? 1 : 0;
+    for (int q = 0; q < 4; q++) b += (n > thr.hash_t[q]) ? 1 : 0;
     return b;
 }
 
@@ -322,12 +337,32 @@ __device__ __forceinline__ void ht_insert_vec(int *tab, int mask, const IVec &k,
 // W lanes cooperate on one row of A (W = pow2 <= 64 chosen from the average row length so
 // that the A.col loads of a wave coalesce).  Restates set_intprod_num (:70-86) fused with
 // set_bin (:88-112) and with the flop sum of get_spgemm_flop.
+// smallest / largest column id of every row of B (rows need not be sorted): the column window
+// of a C row is the union of the windows of the B rows it touches.
+__global__ __launch_bounds__(256) void k_b_minmax(const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                  int K, int *__restrict__ bmin, int *__restrict__ bmax)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= K) return;
+    int lo = 0x7fffffff, hi = -1;
+    for (int k = brpt[r]; k < brpt[r + 1]; k++) {
+        const int c = bcol[k];
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+    bmin[r] = lo;
+    bmax[r] = hi;
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ arpt,
                                                       const int *__restrict__ acol,
-                                                      const int *__restrict__ brpt, int M,
-                                                      int *__restrict__ row_prod, Thr thr,
-                                                      BinState *bs)
+                                                      const int *__restrict__ brpt,
+                                                      const int *__restrict__ bmin,
+                                                      const int *__restrict__ bmax, int M,
+                                                      int *__restrict__ row_prod,
+                                                      int *__restrict__ row_lo,
+                                                      int *__restrict__ row_span, Thr thr, BinState *bs)
 {
     __shared__ int s_hist[NB];
     __shared__ int s_max;
@@ -341,19 +376,32 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
     // per workgroup at the end stay in the low thousands (they serialise in L2).
     for (int row = blockIdx.x * RPB + threadIdx.x / W; row - (int)(threadIdx.x / W) < M; row += gridDim.x * RPB) {
         long long n = 0;
+        int lo = 0x7fffffff, hi = -1;
         if (row < M) {
             const int e = arpt[row + 1];
             for (int j = arpt[row] + lane; j < e; j += W) {
                 const int c = __builtin_nontemporal_load(acol + j);
                 n += brpt[c + 1] - brpt[c];
+                const int l = bmin[c], h = bmax[c];
+                lo = l < lo ? l : lo;
+                hi = h > hi ? h : hi;
             }
         }
 #pragma unroll
-        for (int o = W / 2; o >= 1; o >>= 1) n += __shfl_xor(n, o);
+        for (int o = W / 2; o >= 1; o >>= 1) {
+            n += __shfl_xor(n, o);
+            const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o);
+            lo = l < lo ? l : lo;
+            hi = h > hi ? h : hi;
+        }
         if (row < M && lane == 0) {
             const int ni = n > 0x7fffffffLL ? 0x7fffffff : (int)n;  // saturate (hub rows)
+            const long long sp = hi >= lo ? (long long)hi - lo + 1 : 0;
+            const int span = sp > 0x7fffffffLL ? 0x7fffffff : (int)sp;
             row_prod[row] = ni;
-            atomicAdd(&s_hist[bin_of(ni, thr)], 1);
+            row_lo[row] = hi >= lo ? lo : 0;
+            row_span[row] = span;
+            atomicAdd(&s_hist[bin_of(ni, span, thr)], 1);
             atomicMax(&s_max, ni);
             atomicAdd(&s_total, (unsigned long long)n);
         }
@@ -367,7 +415,8 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
 }
 
 // histogram of an existing per-row count (numeric binning, set_min_bin :201-246)
-__global__ __launch_bounds__(256) void k_hist(const int *__restrict__ n, int M, Thr thr, BinState *bs)
+__global__ __launch_bounds__(256) void k_hist(const int *__restrict__ n, const int *__restrict__ span,
+                                              int M, Thr thr, BinState *bs)
 {
     __shared__ int s_hist[NB];
     __shared__ int s_max;
@@ -377,7 +426,7 @@ __global__ __launch_bounds__(256) void k_hist(const int *__restrict__ n, int M, 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < M) {
         const int v = n[i];
-        atomicAdd(&s_hist[bin_of(v, thr)], 1);
+        atomicAdd(&s_hist[bin_of(v, span[i], thr)], 1);
         atomicMax(&s_max, v);
     }
     __syncthreads();
@@ -393,7 +442,8 @@ __global__ __launch_bounds__(256) void k_row_len(const int *__restrict__ rpt, in
 
 // rows grouped by bin (set_row_perm :125-154): one LDS pass ranks the rows of a block
 // inside their bin, one global atomic per (block, bin) reserves the range.
-__global__ __launch_bounds__(256) void k_bin_scatter(const int *__restrict__ n, int M, Thr thr,
+__global__ __launch_bounds__(256) void k_bin_scatter(const int *__restrict__ n,
+                                                     const int *__restrict__ span, int M, Thr thr,
                                                      BinState *bs, int *__restrict__ perm)
 {
     __shared__ int s_cnt[NB];
@@ -403,7 +453,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const int *__restrict__ n, 
     const int i = blockIdx.x * 256 + threadIdx.x;
     int b = 0, r = 0;
     if (i < M) {
-        b = bin_of(n[i], thr);
+        b = bin_of(n[i], span[i], thr);
         r = atomicAdd(&s_cnt[b], 1);
     }
     __syncthreads();
@@ -847,6 +897,129 @@ __global__ __launch_bounds__(BS) void k_num_global(const int *__restrict__ arpt,
 }
 
 // ===================================================================================
+//  dense-window rows (bins 6..8)
+// ===================================================================================
+// The columns a C row can contain lie in [lo, lo + span) (union of the column windows of the
+// B rows it touches, computed in k_row_products).  When span fits LDS the row needs no hash
+// table: symbolic = one byte flag per column, set with a plain LDS store (idempotent, no
+// atomic, no return value to wait for), count = popcount of the flags; numeric = one real per
+// column accumulated with a no-return LDS atomic add, emitted in ascending order by scanning
+// the flags with ballot/popcount -- no compaction pass and no sort.  The reference has no such
+// path (48 KB of shared memory per block on its target); on CDNA4's 160 KiB it covers every row
+// of a banded / FEM matrix.  Wide-window rows (graphs) stay on the hash bins.
+
+template <int BS, int SPAN_MAX>
+__global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                  const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                  const int *__restrict__ row_perm,
+                                                  const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_lo,
+                                                  const int *__restrict__ row_span,
+                                                  int *__restrict__ row_nz, int bin_off, int bnnz)
+{
+    __shared__ __attribute__((aligned(16))) unsigned int flag4[SPAN_MAX / 4];
+    __shared__ int2 s_ext[BS];
+    __shared__ int s_nz;
+    const int rid = row_perm[bin_off + blockIdx.x];
+    const int lo = row_lo[rid];
+    const int words = (row_span[rid] + 3) >> 2;
+    {
+        uint4 *f4 = reinterpret_cast<uint4 *>(flag4);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < (words + 3) / 4; i += BS) f4[i] = z;
+    }
+    if (threadIdx.x == 0) s_nz = 0;
+    __syncthreads();
+    unsigned char *flag = reinterpret_cast<unsigned char *>(flag4);
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS);
+    walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
+                             a_end, g, s_ext, (real *)nullptr,
+                             [&](const IVec &k, const RVec &, int n, real) {
+#pragma unroll
+                                 for (int i = 0; i < VW; i++)
+                                     if (i < n) flag[k.v[i] - lo] = 1;
+                             });
+    __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < words; i += BS) cnt += __popc(flag4[i] & 0x01010101u);
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) row_nz[rid] = s_nz;
+}
+
+template <int BS, int SPAN_MAX>
+__global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                  const real *__restrict__ aval,
+                                                  const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                  const real *__restrict__ bval,
+                                                  const int *__restrict__ crpt, int *__restrict__ ccol,
+                                                  real *__restrict__ cval,
+                                                  const int *__restrict__ row_perm,
+                                                  const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_lo,
+                                                  const int *__restrict__ row_span, int bin_off,
+                                                  int bnnz, int write_col)
+{
+    constexpr int NW = BS / 64;
+    __shared__ __attribute__((aligned(16))) real dense[SPAN_MAX + 4];
+    __shared__ __attribute__((aligned(16))) unsigned int flag4[SPAN_MAX / 4];
+    __shared__ int2 s_ext[BS];
+    __shared__ real s_av[BS];
+    __shared__ int s_wcnt[NW];
+    const int rid = row_perm[bin_off + blockIdx.x];
+    const int off = crpt[rid];
+    const int lo = row_lo[rid];
+    const int span = row_span[rid];
+    // The VW entries a lane holds have consecutive columns inside a run, so one atomic
+    // instruction sees columns of stride VW across the lanes: the value of column idx lives at
+    // (idx & 3) * Q + (idx >> 2), which turns that stride into consecutive 8-byte slots.
+    const int Q = (span + 3) >> 2;
+    for (int i = threadIdx.x; i < 4 * Q; i += BS) dense[i] = 0;
+    for (int i = threadIdx.x; i < Q; i += BS) flag4[i] = 0;
+    __syncthreads();
+    unsigned char *flag = reinterpret_cast<unsigned char *>(flag4);
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS);
+    walk_products<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av,
+                            [&](const IVec &k, const RVec &v, int n, real sc) {
+#pragma unroll
+                                for (int i = 0; i < VW; i++)
+                                    if (i < n) {
+                                        const int idx = k.v[i] - lo;
+                                        flag[idx] = 1;
+                                        unsafeAtomicAdd(dense + (idx & 3) * Q + (idx >> 2), sc * v.v[i]);
+                                    }
+                            });
+    __syncthreads();
+    // ordered emission: wave w owns the column range [w*R, (w+1)*R)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int R = ((span + NW * 64 - 1) / (NW * 64)) * 64;
+    const int rb = w * R, re = rb + R < span ? rb + R : span;
+    int cnt = 0;
+    for (int base = rb; base < re; base += 64) {
+        const int idx = base + lane;
+        cnt += __popcll(__ballot(idx < re && flag[idx] != 0));
+    }
+    if (lane == 0) s_wcnt[w] = cnt;
+    __syncthreads();
+    int pos = off;
+    for (int u = 0; u < w; u++) pos += s_wcnt[u];
+    for (int base = rb; base < re; base += 64) {
+        const int idx = base + lane;
+        const bool occ = idx < re && flag[idx] != 0;
+        const unsigned long long m = __ballot(occ);
+        if (occ) {
+            const int p = pos + __popcll(m & ((1ull << lane) - 1ull));
+            if (write_col) ccol[p] = lo + idx;
+            cval[p] = dense[(idx & 3) * Q + (idx >> 2)];
+        }
+        pos += __popcll(m);
+    }
+}
+
+// ===================================================================================
 //  host orchestration
 // ===================================================================================
 
@@ -869,8 +1042,9 @@ static inline int pick_w(long long nnz, int M)
     return w;
 }
 
-static void launch_row_products(const sfCSR *a, const sfCSR *b, int *row_prod, BinState *d_bs,
-                                hipStream_t st)
+static void launch_row_products(const sfCSR *a, const sfCSR *b, const int *bmin, const int *bmax,
+                                int *row_prod, int *row_lo, int *row_span, const Thr &thr,
+                                BinState *d_bs, hipStream_t st)
 {
     const int M = a->M;
     const int w = pick_w(a->nnz, M);
@@ -879,7 +1053,7 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, int *row_prod, B
 #define NSP_RP(W)                                                                              \
     case W:                                                                                    \
         hipLaunchKernelGGL(k_row_products<W>, dim3(grid), dim3(256), 0, st, a->d_rpt, a->d_col, \
-                           b->d_rpt, M, row_prod, kSymThr, d_bs);                              \
+                           b->d_rpt, bmin, bmax, M, row_prod, row_lo, row_span, thr, d_bs);     \
         break;
     switch (w) {
         NSP_RP(1) NSP_RP(2) NSP_RP(4) NSP_RP(8) NSP_RP(16) NSP_RP(32) NSP_RP(64)
@@ -954,9 +1128,10 @@ static int global_slab_groups(long long slice_elems, size_t bytes_per_elem, int 
     return (int)g;
 }
 
-static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, int *row_nz,
-                           int *row_perm, const int *hist, int max_prod, BinState *d_bs,
-                           Context &cx, float *ms_bin, int *fail_rows)
+static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, const int *row_lo,
+                                  const int *row_span, int *row_nz, int *row_perm, const int *hist,
+                                  int max_prod, BinState *d_bs, Context &cx, float *ms_bin,
+                                  int *fail_rows)
 {
     BinLauncher L(cx, 0);
     int off[NB + 1];
@@ -975,6 +1150,20 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
+#define NSP_SYM_DENSE(BIN, BS, SPAN)                                                            \
+    if (hist[BIN] > 0) {                                                                       \
+        hipStream_t st = L.begin(BIN);                                                         \
+        hipLaunchKernelGGL((k_sym_dense<BS, SPAN>), dim3(hist[BIN]), dim3(BS), 0, st, arpt, acol, \
+                           brpt, bcol, row_perm, row_prod, row_lo, row_span, row_nz, off[BIN], \
+                           b->nnz);                                                            \
+        NSP_LAUNCH_CHECK();                                                                    \
+        L.end(BIN);                                                                            \
+    }
+    static const int tune_d6 = getenv("NSPARSE_SYMD6_BS") ? atoi(getenv("NSPARSE_SYMD6_BS")) : 256;
+    NSP_SYM_DENSE(8, 1024, 65536)
+    NSP_SYM_DENSE(7, 512, 16384)
+    if (tune_d6 == 128) { NSP_SYM_DENSE(6, 128, 4096) } else if (tune_d6 == 512) { NSP_SYM_DENSE(6, 512, 4096) } else { NSP_SYM_DENSE(6, 256, 4096) }
+#undef NSP_SYM_DENSE
     static const int tune_s3 = getenv("NSPARSE_SYM3_BS") ? atoi(getenv("NSPARSE_SYM3_BS")) : 512;
     static const int tune_s2 = getenv("NSPARSE_SYM2_BS") ? atoi(getenv("NSPARSE_SYM2_BS")) : 128;
     NSP_SYM_TB(4, 1024, 32768)
@@ -1022,8 +1211,9 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
 }
 
 static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const int *row_prod,
-                          const int *row_perm, const int *hist, int max_nz, BinState *d_bs,
-                          Context &cx, float *ms_bin, int write_col)
+                                 const int *row_lo, const int *row_span, const int *row_perm,
+                                 const int *hist, int max_nz, BinState *d_bs, Context &cx,
+                                 float *ms_bin, int write_col)
 {
     BinLauncher L(cx, 1);
     int off[NB + 1];
@@ -1076,6 +1266,20 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
+#define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
+    if (hist[BIN] > 0) {                                                                       \
+        hipStream_t st = L.begin(BIN);                                                         \
+        hipLaunchKernelGGL((k_num_dense<BS, SPAN>), dim3(hist[BIN]), dim3(BS), 0, st, arpt, acol, \
+                           aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm,     \
+                           row_prod, row_lo, row_span, off[BIN], b->nnz, write_col);           \
+        NSP_LAUNCH_CHECK();                                                                    \
+        L.end(BIN);                                                                            \
+    }
+    static const int tune_nd6 = getenv("NSPARSE_NUMD6_BS") ? atoi(getenv("NSPARSE_NUMD6_BS")) : 256;
+    NSP_NUM_DENSE(8, 512, 12288)
+    NSP_NUM_DENSE(7, 256, 4096)
+    if (tune_nd6 == 128) { NSP_NUM_DENSE(6, 128, 1536) } else if (tune_nd6 == 512) { NSP_NUM_DENSE(6, 512, 1536) } else { NSP_NUM_DENSE(6, 256, 1536) }
+#undef NSP_NUM_DENSE
     static const int tune_n2 = getenv("NSPARSE_NUM2_BS") ? atoi(getenv("NSPARSE_NUM2_BS")) : 256;
     static const int tune_n1 = getenv("NSPARSE_NUM1_BS") ? atoi(getenv("NSPARSE_NUM1_BS")) : 64;
     NSP_NUM_TB(4, 1024, 8192, 8192)
@@ -1118,13 +1322,26 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     int *row_prod = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_nz = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_perm = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
+    int *row_lo = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
+    int *row_span = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
+    const int K = b->M;
+    int *bmin = (int *)dev_alloc(sizeof(int) * 2 * (size_t)(K > 0 ? K : 1));
+    int *bmax = bmin + (K > 0 ? K : 1);
+    if (g_dense_enabled < 0) {
+        const char *e = getenv("NSPARSE_DENSE");
+        g_dense_enabled = !(e && e[0] == '0');
+    }
+    Thr sym_thr = kSymThr, num_thr = kNumThr;
+    if (!g_dense_enabled) sym_thr.dense_ratio = num_thr.dense_ratio = 0;
+    NSP_CHECK(hipStreamSynchronize(0));  // inputs queued on the null stream by the caller
     NSP_CHECK(hipMemsetAsync(d_sym, 0, 2 * sizeof(BinState), s0));
 
-    // ---- setup: products per row (+ symbolic bins) ------------------------------------
-    launch_row_products(a, b, row_prod, d_sym, s0);
+    // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
+    hipLaunchKernelGGL(k_b_minmax, dim3(ceil_div(K, 256)), dim3(256), 0, s0, b->d_rpt, b->d_col, K, bmin, bmax);
+    launch_row_products(a, b, bmin, bmax, row_prod, row_lo, row_span, sym_thr, d_sym, s0);
     const int grid_m = ceil_div(M, 256);
     if (!numeric_only) {
-        hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_prod, M, kSymThr, d_sym, row_perm);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_prod, row_span, M, sym_thr, d_sym, row_perm);
         NSP_LAUNCH_CHECK();
     }
     NSP_CHECK(hipMemcpyAsync(h_sym, d_sym, sizeof(BinState), hipMemcpyDeviceToHost, s0));
@@ -1138,8 +1355,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     if (!numeric_only) {
         c->M = M;
         c->N = b->N;
-        BinLauncher LS = symbolic_phase(a, b, row_prod, row_nz, row_perm, h_sym->hist, h_sym->maxv,
-                                        d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows);
+        BinLauncher LS = symbolic_phase(a, b, row_prod, row_lo, row_span, row_nz, row_perm, h_sym->hist,
+                                        h_sym->maxv, d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows);
         sym_used = LS;
         c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
         NSP_CHECK(hipMemsetAsync(row_nz + M, 0, sizeof(int), s0));
@@ -1153,8 +1370,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     tm.mark(2, s0);
 
     // ---- numeric binning ------------------------------------------------------------
-    hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(256), 0, s0, row_nz, M, kNumThr, d_num);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_nz, M, kNumThr, d_num, row_perm);
+    hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(256), 0, s0, row_nz, row_span, M, num_thr, d_num);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_nz, row_span, M, num_thr, d_num, row_perm);
     NSP_LAUNCH_CHECK();
     NSP_CHECK(hipMemcpyAsync(&d_num->nnz, c->d_rpt + M, sizeof(int), hipMemcpyDeviceToDevice, s0));
     NSP_CHECK(hipMemcpyAsync(h_num, d_num, sizeof(BinState), hipMemcpyDeviceToHost, s0));
@@ -1169,8 +1386,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     S.nnz_c = c->nnz;
 
     // ---- numeric --------------------------------------------------------------------
-    BinLauncher LN = numeric_phase(a, b, c, row_prod, row_perm, h_num->hist, h_num->maxv, d_num, cx,
-                                   S.ms_num_bin, numeric_only ? 0 : 1);
+    BinLauncher LN = numeric_phase(a, b, c, row_prod, row_lo, row_span, row_perm, h_num->hist,
+                                   h_num->maxv, d_num, cx, S.ms_num_bin, numeric_only ? 0 : 1);
     tm.mark(3, s0);
     NSP_CHECK(hipStreamSynchronize(s0));  // synchronous on return, like upstream (:1287)
     LN.collect(S.ms_num_bin);
@@ -1181,6 +1398,9 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     S.ms_total = tm.ms(0, 3);
 
     dev_free(scan_tmp);
+    dev_free(bmin);
+    dev_free(row_span);
+    dev_free(row_lo);
     dev_free(row_perm);
     dev_free(row_nz);
     dev_free(row_prod);
@@ -1212,9 +1432,18 @@ void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out) { *out = nsp::spgemm::g
 
 void nsparse_get_spgemm_bins(int *sym, int *num)
 {
-    for (int q = 0; q < nsp::spgemm::NB - 1; q++) {
-        sym[q] = nsp::spgemm::kSymThr.t[q];
-        num[q] = nsp::spgemm::kNumThr.t[q];
+    // 9 ints each: tiny, hash_t[4], dense_span[3], dense_ratio (0 when NSPARSE_DENSE=0)
+    const nsp::spgemm::Thr *t[2] = {&nsp::spgemm::kSymThr, &nsp::spgemm::kNumThr};
+    int *out[2] = {sym, num};
+    if (nsp::spgemm::g_dense_enabled < 0) {
+        const char *e = getenv("NSPARSE_DENSE");
+        nsp::spgemm::g_dense_enabled = !(e && e[0] == '0');
+    }
+    for (int p = 0; p < 2; p++) {
+        out[p][0] = t[p]->tiny;
+        for (int q = 0; q < 4; q++) out[p][1 + q] = t[p]->hash_t[q];
+        for (int q = 0; q < 3; q++) out[p][5 + q] = t[p]->dense_span[q];
+        out[p][8] = nsp::spgemm::g_dense_enabled ? t[p]->dense_ratio : 0;
     }
 }
 

@@ -85,3 +85,50 @@ def synth(lib, kind, p0, p1=0, p2=0, seed=1, rows=(0, 0)):
     A = lib.csr_host_to_numpy(m)
     lib.release_cpu_csr(m)
     return A
+
+
+def row_windows(A, B):
+    """Per row of C = A B: (products, column span) -- numpy restatement used by tests/bench to
+    predict the bin of every row."""
+    alen = np.diff(A["rpt"]).astype(np.int64)
+    blen = np.diff(B["rpt"]).astype(np.int64)
+    K = len(blen)
+    bmin = np.full(K, np.iinfo(np.int64).max, dtype=np.int64)
+    bmax = np.full(K, -1, dtype=np.int64)
+    nz = blen > 0
+    starts = B["rpt"][:-1].astype(np.int64)
+    if len(B["col"]):
+        bmin[nz] = np.minimum.reduceat(B["col"].astype(np.int64), starts[nz])
+        bmax[nz] = np.maximum.reduceat(B["col"].astype(np.int64), starts[nz])
+    M = len(alen)
+    prod = np.zeros(M, dtype=np.int64)
+    lo = np.full(M, np.iinfo(np.int64).max, dtype=np.int64)
+    hi = np.full(M, -1, dtype=np.int64)
+    ne = alen > 0
+    if len(A["col"]):
+        st = A["rpt"][:-1].astype(np.int64)[ne]
+        ac = A["col"].astype(np.int64)
+        prod[ne] = np.add.reduceat(blen[ac], st)
+        lo[ne] = np.minimum.reduceat(bmin[ac], st)
+        hi[ne] = np.maximum.reduceat(bmax[ac], st)
+    span = np.where(hi >= lo, hi - lo + 1, 0)
+    return prod, span
+
+
+def bins_of(n, span, ladder):
+    """numpy twin of bin_of() in spgemm_hash.hip; ladder = 9 ints from nsparse_get_spgemm_bins."""
+    n = np.asarray(n, dtype=np.int64)
+    span = np.asarray(span, dtype=np.int64)
+    tiny, hash_t, dspan, ratio = ladder[0], ladder[1:5], ladder[5:8], ladder[8]
+    b = 1 + sum((n > t).astype(np.int64) for t in hash_t)
+    if ratio > 0:
+        dense = (span > 0) & (span <= dspan[2]) & (span <= ratio * n)
+        b = np.where(dense, 6 + (span > dspan[0]) + (span > dspan[1]), b)
+    return np.where(n <= tiny, 0, b)
+
+
+def ladders(lib):
+    sym = (C.c_int * 9)()
+    num = (C.c_int * 9)()
+    lib.nsparse_get_spgemm_bins(sym, num)
+    return list(sym), list(num)

@@ -10,7 +10,7 @@ import pytest
 
 import nsparse_amd as ns
 from conftest import GOLDEN, TEST_MTX, load_golden
-from gpu_util import spgemm, synth
+from gpu_util import bins_of, ladders, row_windows, spgemm, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -57,12 +57,13 @@ def test_golden_vectors(name, prec, lib_d, lib_s, oracle_d, oracle_s):
                                atol=1e-12 if prec == "d" else 1e-5)
 
 
-def _bins_match(orc, st, row_prod, row_nz, lib):
-    sym = (C.c_int * 7)()
-    num = (C.c_int * 7)()
-    lib.nsparse_get_spgemm_bins(sym, num)
-    assert list(st.sym_bin_size) == orc.bin_hist_thr(row_prod, list(sym)).tolist()
-    assert list(st.num_bin_size) == orc.bin_hist_thr(row_nz, list(num)).tolist()
+def _bins_match(orc, st, row_prod, row_nz, lib, A, B=None):
+    B = A if B is None else B
+    sym, num = ladders(lib)
+    prod, span = row_windows(A, B)
+    assert np.array_equal(prod, row_prod)
+    assert list(st.sym_bin_size)[:9] == np.bincount(bins_of(row_prod, span, sym), minlength=9).tolist()
+    assert list(st.num_bin_size)[:9] == np.bincount(bins_of(row_nz, span, num), minlength=9).tolist()
 
 
 @pytest.mark.parametrize("kind,p,prec", [
@@ -81,7 +82,7 @@ def test_synthetic_vs_oracle(kind, p, prec, lib_d, lib_s, oracle_d, oracle_s):
     rp, tot, mx = orc.nprod(A["rpt"], A["col"], A["rpt"])
     assert st.n_prod == tot and st.max_prod_row == mx and st.nnz_c == ref["nnz"]
     assert st.max_nnz_row == int(ref["row_nz"].max())
-    _bins_match(orc, st, rp, ref["row_nz"], lib)
+    _bins_match(orc, st, rp, ref["row_nz"], lib, A)
 
 
 def test_rectangular_and_empty_rows(lib_d, oracle_d):
@@ -123,7 +124,7 @@ def test_every_bin_is_exercised(lib_d, oracle_d):
     """Rows sized to land in every symbolic bin (0-5, incl. the try-in-LDS bin) and every numeric
     bin incl. the global-table bin; structure must still be exact."""
     rng = np.random.default_rng(11)
-    n = 40000
+    n = 100000  # wider than the largest dense window (65536): the big rows must use the hash bins
     hub_cols = np.sort(rng.choice(n, 3500, replace=False))
     big_cols = np.sort(rng.choice(n, 400, replace=False))
     A = _force_rows(n, n, 12, rng, extra={0: hub_cols, 1: big_cols, 2: big_cols[:150], 3: big_cols[:60]})
@@ -131,10 +132,10 @@ def test_every_bin_is_exercised(lib_d, oracle_d):
     got, st = spgemm(lib_d, A)
     assert_parity(oracle_d, got, ref)
     rp, _, _ = oracle_d.nprod(A["rpt"], A["col"], A["rpt"])
-    _bins_match(oracle_d, st, rp, ref["row_nz"], lib_d)
+    _bins_match(oracle_d, st, rp, ref["row_nz"], lib_d, A)
     assert st.sym_bin_size[5] >= 1, "no row reached the try-in-LDS symbolic bin"
     assert st.num_bin_size[5] >= 1, "no row reached the global numeric bin"
-    assert sum(1 for b in list(st.num_bin_size)[:6] if b > 0) >= 4
+    assert sum(1 for b in list(st.num_bin_size)[:9] if b > 0) >= 4
 
 
 def test_symbolic_overflow_falls_back_to_global_table(lib_d, oracle_d):
@@ -148,6 +149,31 @@ def test_symbolic_overflow_falls_back_to_global_table(lib_d, oracle_d):
     got, st = spgemm(lib_d, A)
     assert st.sym_fail_rows >= 1
     assert_parity(oracle_d, got, ref)
+
+
+def test_dense_window_and_hash_paths_agree(lib_d, oracle_d):
+    """Banded / FEM rows take the dense-window bins (6-8); NSPARSE_DENSE=0 (separate process) sends
+    the same rows through the hash bins.  Both must give the oracle's structure."""
+    import subprocess, sys, json
+    A = synth(lib_d, 0, 6, 6, 20, seed=5)
+    got, st = spgemm(lib_d, A)
+    ref = oracle_d.spgemm(A, A)
+    assert_parity(oracle_d, got, ref)
+    assert sum(list(st.sym_bin_size)[6:9]) > 0 and sum(list(st.num_bin_size)[6:9]) > 0
+    code = ("import sys, json, numpy as np; sys.path.insert(0, 'tests'); import nsparse_amd as ns;"
+            "from gpu_util import spgemm, synth; lib = ns.load('d'); A = synth(lib, 0, 6, 6, 20, seed=5);"
+            "got, st = spgemm(lib, A);"
+            "print(json.dumps(dict(rpt=got['rpt'].tolist(), col=got['col'].tolist(), val=got['val'].tolist(),"
+            "dense=int(sum(list(st.sym_bin_size)[6:9]) + sum(list(st.num_bin_size)[6:9])))))")
+    from conftest import ROOT
+    import os
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True,
+                       env=dict(os.environ, NSPARSE_DENSE="0"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    h = json.loads(r.stdout.strip().splitlines()[-1])
+    assert h["dense"] == 0
+    assert h["rpt"] == got["rpt"].tolist() and h["col"] == got["col"].tolist()
+    np.testing.assert_allclose(np.array(h["val"]), got["val"], rtol=1e-9)
 
 
 def test_workspace_cache_off_is_identical(lib_d, oracle_d):

@@ -14,7 +14,7 @@ for p in ("p1","p2"):
     for f in glob.glob("$OUT/%s/**/*counter_collection.csv" % p, recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
-            if not any(s in k for s in ("k_num_tb","k_sym_tb","k_spmv_amb")): continue
+            if not any(s in k for s in ("k_num_","k_sym_","k_spmv_amb","k_row_prod","k_b_minmax")): continue
             k = k.split("(")[0].replace("void nsp::spgemm::","").replace("void nsp::spmv::","")
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, d in agg.items():
