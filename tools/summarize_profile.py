@@ -59,20 +59,35 @@ def main():
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, (None, 0)), write.get(k, (None, 0))
         e = {"launches_sampled": max(f[1], w[1])}
+        # calibrated on this box (profiles/r01_pmc_calibration.txt, tools/pmc_calib): 1 GiB streams
+        # read at 2/4/8/16 B per lane all give 2048 B per FETCH_SIZE unit (KiB unit x the gfx950
+        # half-count), writes 1024 B per WRITE_SIZE unit.
         if f[0] is not None:
             e["FETCH_SIZE_raw_per_launch"] = f[0]
-            e["fetch_bytes_x1024"] = f[0] * 1024
-            e["fetch_bytes_x1024_x2_gfx950"] = f[0] * 2048
+            e["fetch_bytes"] = f[0] * 2048
         if w[0] is not None:
             e["WRITE_SIZE_raw_per_launch"] = w[0]
-            e["write_bytes_x1024"] = w[0] * 1024
+            e["write_bytes"] = w[0] * 1024
+        if f[0] is not None and w[0] is not None:
+            e["hbm_bytes_per_launch"] = f[0] * 2048 + w[0] * 1024
         out[k] = e
     json.dump(out, open(os.path.join("profiles", f"{tag}_pmc.json"), "w"), indent=1)
+    # what bench.py reads back as roofline.traffic: the numeric kernel of every bin + SpMV
+    latest = {"source": f"profiles/{tag}_pmc.json"}
+    for k, e in out.items():
+        if "hbm_bytes_per_launch" not in e:
+            continue
+        m = re.match(r"k_num_(tb|dense)<(\d+), (\d+)", k)
+        if m:
+            latest["spgemm_" + k.replace(" ", "")] = e["hbm_bytes_per_launch"]
+        if k.startswith("k_spmv_amb"):
+            latest["spmv_" + k.replace(" ", "")] = e["hbm_bytes_per_launch"]
+    json.dump(latest, open(os.path.join("profiles", "pmc_latest.json"), "w"), indent=1)
     if rows:
         for r in rows[:14]:
             print(f"{r[3] / 1e3:10.1f} us avg  x{r[1]:5d}  {100.0 * r[2] / sum(x[2] for x in rows):5.1f}%  {r[0]}")
     for k, e in out.items():
-        if any(s in k for s in ("k_num_tb", "k_sym_tb", "k_spmv")):
+        if any(s in k for s in ("k_num_", "k_sym_", "k_spmv")):
             print(k, {a: round(b) for a, b in e.items()})
 
 
