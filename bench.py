@@ -66,17 +66,17 @@ def load_or_synth(lib, name, kind, dims, seed, rows=(0, 0)):
     return synth(lib, kind, dims[0], dims[1], dims[2], seed, rows), f"synthetic {name}-class"
 
 
-def numeric_bin_bytes(A, B, crpt, ladder, w):
+def numeric_bin_bytes(A, B, crpt, sym_ladder, ladder, w):
     """Algorithmic bytes of each numeric-bin launch (SURVEY 8d numeric term, restricted to the
     rows of the bin): per row 12 B (C.rpt pair + permutation entry) + (12+w) per A entry
     (col, val, two B.rpt gathers) + (4+w) per intermediate product (B col, val) + (4+w) per
     C entry written.  Rows are assigned to bins with the library's own rule (bins_of)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from gpu_util import bins_of, row_windows
+    from gpu_util import numeric_bins, row_windows
     row_prod, span = row_windows(A, B)
     alen = np.diff(A["rpt"]).astype(np.int64)
     nzc = np.diff(crpt).astype(np.int64)
-    bins = bins_of(nzc, span, ladder)
+    bins = numeric_bins(nzc, row_prod, span, sym_ladder, ladder)
     per_row = 12 + (12 + w) * alen + (4 + w) * (row_prod + nzc)
     out = np.zeros(12)
     prods = np.zeros(12)
@@ -182,7 +182,7 @@ def main():
     sym_thr = (C.c_int * 9)()
     num_thr = (C.c_int * 9)()
     lib.nsparse_get_spgemm_bins(sym_thr, num_thr)
-    bytes_bin, prods_bin, row_prod = numeric_bin_bytes(A_loc, A_full, crpt, list(num_thr), w)
+    bytes_bin, prods_bin, row_prod = numeric_bin_bytes(A_loc, A_full, crpt, list(sym_thr), list(num_thr), w)
     dom = int(np.argmax(bin_ms))
     achieved = bytes_bin[dom] / (bin_ms[dom] * 1e-3) / 1e9 if bin_ms[dom] > 0 else 0.0
     dom_kernel = {1: "k_num_tb<64,256,256>", 2: "k_num_tb<256,1024,1024>", 3: "k_num_tb<512,4096,4096>",

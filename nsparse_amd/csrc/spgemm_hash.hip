@@ -104,6 +104,7 @@ struct BinState {
     int queue_head;
     int nnz;
     long long total;
+    long long bm_total;  // words of column bitmaps (dense window rows)
 };
 
 struct Stats {
@@ -389,14 +390,16 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
                                                       const BInfo *__restrict__ binfo, int M,
                                                       int *__restrict__ row_prod,
                                                       int *__restrict__ row_lo,
-                                                      int *__restrict__ row_span, Thr thr,
-                                                      long long *__restrict__ partial)
+                                                      int *__restrict__ row_span,
+                                                      int *__restrict__ bm_words, int bm_span_max,
+                                                      Thr thr, long long *__restrict__ partial)
 {
     __shared__ int s_hist[NB];
     __shared__ int s_max;
     __shared__ unsigned long long s_total;
+    __shared__ unsigned long long s_bm;
     if (threadIdx.x < NB) s_hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_max = 0; s_total = 0; }
+    if (threadIdx.x == 0) { s_max = 0; s_total = 0; s_bm = 0; }
     __syncthreads();
     const int lane = threadIdx.x % W;
     constexpr int RPB = 256 / W;
@@ -429,6 +432,10 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             row_prod[row] = ni;
             row_lo[row] = hi >= lo ? lo : 0;
             row_span[row] = span;
+            // words of the column bitmap the symbolic dense kernel hands to the numeric one
+            const int bw = (span > 0 && span <= bm_span_max) ? (span + 31) >> 5 : 0;
+            bm_words[row] = bw;
+            if (bw) atomicAdd(&s_bm, (unsigned long long)bw);
             atomicAdd(&s_hist[bin_of(ni, span, thr)], 1);
             atomicMax(&s_max, ni);
             atomicAdd(&s_total, (unsigned long long)n);
@@ -443,6 +450,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
     if (threadIdx.x == 0) {
         out[NB] = s_max;
         out[NB + 1] = (long long)s_total;
+        out[NB + 2] = (long long)s_bm;
     }
 }
 
@@ -459,7 +467,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const long long *__rest
     const int per = (nblocks + gridDim.x - 1) / gridDim.x;
     const int b0 = blockIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
     const int f = threadIdx.x & 15;
-    if (f < NB + 2) {
+    if (f < NB + 3) {
         long long acc = 0;
         for (int b = b0 + (threadIdx.x >> 4); b < b1; b += 16) {
             const long long v = partial[(long long)b * kPartialStride + f];
@@ -473,6 +481,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const long long *__rest
     if (threadIdx.x == 0) {
         if (s_max) atomicMax(&bs->maxv, s_max);
         if (s_acc[NB + 1]) atomicAdd((unsigned long long *)&bs->total, s_acc[NB + 1]);
+        if (s_acc[NB + 2]) atomicAdd((unsigned long long *)&bs->bm_total, s_acc[NB + 2]);
     }
 }
 
@@ -982,20 +991,23 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
                                                   const int *__restrict__ row_lo,
                                                   const int *__restrict__ row_span,
                                                   int *__restrict__ row_nz, int bin_off, int bin_size,
-                                                  int bnnz)
+                                                  int bnnz, const int *__restrict__ bm_off,
+                                                  unsigned int *__restrict__ bm,
+                                                  int *__restrict__ row_span_num)
 {
-    __shared__ __attribute__((aligned(16))) unsigned int flag4[SPAN_MAX / 4];
+    __shared__ __attribute__((aligned(16))) unsigned int flag4[SPAN_MAX / 4 + 8];
     __shared__ int2 s_ext[BS];
     __shared__ int s_nz;
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
     const int rid = row_perm[bin_off + slot];
     const int lo = row_lo[rid];
-    const int words = (row_span[rid] + 3) >> 2;
+    const int span = row_span[rid];
+    const int words = (span + 3) >> 2;
     {
         uint4 *f4 = reinterpret_cast<uint4 *>(flag4);
         const uint4 z = make_uint4(0, 0, 0, 0);
-        for (int i = threadIdx.x; i < (words + 3) / 4; i += BS) f4[i] = z;
+        for (int i = threadIdx.x; i < (words + 3) / 4 + 2; i += BS) f4[i] = z;  // + bitmap tail
     }
     if (threadIdx.x == 0) s_nz = 0;
     __syncthreads();
@@ -1014,11 +1026,28 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
     for (int i = threadIdx.x; i < words; i += BS) cnt += __popc(flag4[i] & 0x01010101u);
     cnt = wave_sum(cnt);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
+    // Hand the structure to the numeric phase: 1 bit per column of the window, 32 flag bytes
+    // -> one word.  The numeric dense kernel then needs no flags of its own (one LDS atomic
+    // per product instead of an atomic and a store) and no sort.
+    if (bm != nullptr) {
+        const int bw = bm_off[rid + 1] - bm_off[rid];
+        unsigned int *dst = bm + bm_off[rid];
+        for (int wi = threadIdx.x; wi < bw; wi += BS) {
+            unsigned int bits = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const unsigned int x = flag4[wi * 8 + q] & 0x01010101u;
+                bits |= ((x * 0x01020408u) >> 24) << (4 * q);
+            }
+            dst[wi] = bits;
+        }
+        if (threadIdx.x == 0) row_span_num[rid] = bw > 0 ? span : 0;
+    }
     __syncthreads();
     if (threadIdx.x == 0) row_nz[rid] = s_nz;
 }
 
-template <int BS, int SPAN_MAX>
+template <int BS, int SPAN_MAX, int MODE>
 __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                   const real *__restrict__ aval,
                                                   const int *__restrict__ brpt, const int *__restrict__ bcol,
@@ -1029,11 +1058,15 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
                                                   const int *__restrict__ row_prod,
                                                   const int *__restrict__ row_lo,
                                                   const int *__restrict__ row_span, int bin_off,
-                                                  int bin_size, int bnnz, int write_col)
+                                                  int bin_size, int bnnz,
+                                                  const int *__restrict__ bm_off,
+                                                  const unsigned int *__restrict__ bm)
 {
+    // MODE 1: full call -- the column structure of the row comes from the bitmap written by
+    //         k_sym_dense; columns and values are emitted in ascending order.
+    // MODE 2: numeric-only re-run -- C.col exists; values are gathered at its columns.
     constexpr int NW = BS / 64;
     __shared__ __attribute__((aligned(16))) real dense[SPAN_MAX + 4];
-    __shared__ __attribute__((aligned(16))) unsigned int flag4[SPAN_MAX / 4];
     __shared__ int2 s_ext[BS];
     __shared__ real s_av[BS];
     __shared__ int s_wcnt[NW];
@@ -1048,9 +1081,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
     // (idx & 3) * Q + (idx >> 2), which turns that stride into consecutive 8-byte slots.
     const int Q = (span + 3) >> 2;
     for (int i = threadIdx.x; i < 4 * Q; i += BS) dense[i] = 0;
-    for (int i = threadIdx.x; i < Q; i += BS) flag4[i] = 0;
     __syncthreads();
-    unsigned char *flag = reinterpret_cast<unsigned char *>(flag4);
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
     const int g = group_width(row_prod[rid], a_end - a_beg, BS);
     walk_products<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av,
@@ -1059,19 +1090,28 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
                                 for (int i = 0; i < VW; i++)
                                     if (i < n) {
                                         const int idx = k.v[i] - lo;
-                                        flag[idx] = 1;
                                         unsafeAtomicAdd(dense + (idx & 3) * Q + (idx >> 2), sc * v.v[i]);
                                     }
                             });
     __syncthreads();
+    if (MODE == 2) {
+        const int n = crpt[rid + 1] - off;
+        for (int p = threadIdx.x; p < n; p += BS) {
+            const int idx = ccol[off + p] - lo;
+            cval[off + p] = dense[(idx & 3) * Q + (idx >> 2)];
+        }
+        return;
+    }
     // ordered emission: wave w owns the column range [w*R, (w+1)*R)
+    const unsigned int *bits = bm + bm_off[rid];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int R = ((span + NW * 64 - 1) / (NW * 64)) * 64;
     const int rb = w * R, re = rb + R < span ? rb + R : span;
     int cnt = 0;
     for (int base = rb; base < re; base += 64) {
         const int idx = base + lane;
-        cnt += __popcll(__ballot(idx < re && flag[idx] != 0));
+        const bool occ = idx < re && ((bits[idx >> 5] >> (idx & 31)) & 1u);
+        cnt += __popcll(__ballot(occ));
     }
     if (lane == 0) s_wcnt[w] = cnt;
     __syncthreads();
@@ -1079,11 +1119,11 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
     for (int u = 0; u < w; u++) pos += s_wcnt[u];
     for (int base = rb; base < re; base += 64) {
         const int idx = base + lane;
-        const bool occ = idx < re && flag[idx] != 0;
+        const bool occ = idx < re && ((bits[idx >> 5] >> (idx & 31)) & 1u);
         const unsigned long long m = __ballot(occ);
         if (occ) {
             const int p = pos + __popcll(m & ((1ull << lane) - 1ull));
-            if (write_col) ccol[p] = lo + idx;
+            ccol[p] = lo + idx;
             cval[p] = dense[(idx & 3) * Q + (idx >> 2)];
         }
         pos += __popcll(m);
@@ -1114,8 +1154,9 @@ static inline int pick_w(long long nnz, int M)
 }
 
 static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *binfo,
-                                int *row_prod, int *row_lo, int *row_span, const Thr &thr,
-                                BinState *d_bs, long long *partial, hipStream_t st)
+                                int *row_prod, int *row_lo, int *row_span, int *bm_words,
+                                int bm_span_max, const Thr &thr, BinState *d_bs, long long *partial,
+                                hipStream_t st)
 {
     const int M = a->M;
     const int w = pick_w(a->nnz, M);
@@ -1124,7 +1165,8 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *bin
 #define NSP_RP(W)                                                                              \
     case W:                                                                                    \
         hipLaunchKernelGGL(k_row_products<W>, dim3(grid), dim3(256), 0, st, a->d_rpt, a->d_col, \
-                           binfo, M, row_prod, row_lo, row_span, thr, partial);                \
+                           binfo, M, row_prod, row_lo, row_span, bm_words, bm_span_max, thr,   \
+                           partial);                                                           \
         break;
     switch (w) {
         NSP_RP(1) NSP_RP(2) NSP_RP(4) NSP_RP(8) NSP_RP(16) NSP_RP(32) NSP_RP(64)
@@ -1203,7 +1245,8 @@ static int global_slab_groups(long long slice_elems, size_t bytes_per_elem, int 
 static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, const int *row_lo,
                                   const int *row_span, int *row_nz, int *row_perm, const int *hist,
                                   int max_prod, BinState *d_bs, Context &cx, float *ms_bin,
-                                  int *fail_rows)
+                                  int *fail_rows, const int *bm_off, unsigned int *bm,
+                                  int *row_span_num)
 {
     BinLauncher L(cx, 0);
     int off[NB + 1];
@@ -1228,7 +1271,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_dense<BS, SPAN>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
                            arpt, acol, brpt, bcol, row_perm, row_prod, row_lo, row_span, row_nz, \
-                           off[BIN], hist[BIN], b->nnz);                                       \
+                           off[BIN], hist[BIN], b->nnz, bm_off, bm, row_span_num);             \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -1286,7 +1329,8 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
 static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const int *row_prod,
                                  const int *row_lo, const int *row_span, const int *row_perm,
                                  const int *hist, int max_nz, BinState *d_bs, Context &cx,
-                                 float *ms_bin, int write_col)
+                                 float *ms_bin, int write_col, const int *bm_off,
+                                 const unsigned int *bm)
 {
     BinLauncher L(cx, 1);
     int off[NB + 1];
@@ -1342,10 +1386,16 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
 #define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
     if (hist[BIN] > 0) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
-        hipLaunchKernelGGL((k_num_dense<BS, SPAN>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
-                           arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val,   \
-                           row_perm, row_prod, row_lo, row_span, off[BIN], hist[BIN], b->nnz,  \
-                           write_col);                                                         \
+        if (write_col)                                                                         \
+            hipLaunchKernelGGL((k_num_dense<BS, SPAN, 1>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
+                               0, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
+                               c->d_val, row_perm, row_prod, row_lo, row_span, off[BIN],       \
+                               hist[BIN], b->nnz, bm_off, bm);                                 \
+        else                                                                                   \
+            hipLaunchKernelGGL((k_num_dense<BS, SPAN, 2>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
+                               0, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
+                               c->d_val, row_perm, row_prod, row_lo, row_span, off[BIN],       \
+                               hist[BIN], b->nnz, bm_off, bm);                                 \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -1392,6 +1442,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     static_assert(2 * sizeof(BinState) <= 128 * sizeof(int), "scratch layout");
 
     void *scan_tmp = nullptr;
+    unsigned int *bm = nullptr;
     BinLauncher sym_used(cx, 0);
     int *row_prod = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_nz = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
@@ -1412,7 +1463,19 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
     hipLaunchKernelGGL(k_b_info, dim3(ceil_div(K, 256)), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo);
     long long *partial = (long long *)dev_alloc(sizeof(long long) * kPartialStride * kSetupMaxGrid);
-    launch_row_products(a, b, binfo, row_prod, row_lo, row_span, sym_thr, d_sym, partial, s0);
+    // column bitmaps handed from the symbolic to the numeric dense kernels
+    int *bm_words = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
+    int *bm_off = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
+    int *row_span_num = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
+    const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
+    launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
+                        use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, s0);
+    void *bm_scan_tmp = nullptr;
+    if (use_bm) {
+        NSP_CHECK(hipMemsetAsync(bm_words + M, 0, sizeof(int), s0));
+        NSP_CHECK(hipMemsetAsync(row_span_num, 0, sizeof(int) * (size_t)(M > 0 ? M : 1), s0));
+        bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
+    }
     const int grid_m = ceil_div(M, 256);
     if (!numeric_only) {
         hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_prod, row_span, M, sym_thr, d_sym, row_perm);
@@ -1429,8 +1492,13 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     if (!numeric_only) {
         c->M = M;
         c->N = b->N;
+        // bitmaps only when they fit int offsets comfortably; otherwise the dense window is
+        // used by the symbolic phase alone and the numeric phase hashes
+        if (use_bm && h_sym->bm_total > 0 && h_sym->bm_total < (1LL << 30))
+            bm = (unsigned int *)dev_alloc(sizeof(unsigned int) * (size_t)h_sym->bm_total);
         BinLauncher LS = symbolic_phase(a, b, row_prod, row_lo, row_span, row_nz, row_perm, h_sym->hist,
-                                        h_sym->maxv, d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows);
+                                        h_sym->maxv, d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows,
+                                        bm_off, bm, row_span_num);
         sym_used = LS;
         c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
         NSP_CHECK(hipMemsetAsync(row_nz + M, 0, sizeof(int), s0));
@@ -1444,8 +1512,11 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     tm.mark(2, s0);
 
     // ---- numeric binning ------------------------------------------------------------
-    hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(256), 0, s0, row_nz, row_span, M, num_thr, d_num);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_nz, row_span, M, num_thr, d_num, row_perm);
+    // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
+    const int *num_span = numeric_only ? row_span : row_span_num;
+    if (!numeric_only && bm == nullptr) num_thr.dense_ratio = 0;
+    hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(256), 0, s0, row_nz, num_span, M, num_thr, d_num);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_nz, num_span, M, num_thr, d_num, row_perm);
     NSP_LAUNCH_CHECK();
     NSP_CHECK(hipMemcpyAsync(&d_num->nnz, c->d_rpt + M, sizeof(int), hipMemcpyDeviceToDevice, s0));
     NSP_CHECK(hipMemcpyAsync(h_num, d_num, sizeof(BinState), hipMemcpyDeviceToHost, s0));
@@ -1461,7 +1532,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
 
     // ---- numeric --------------------------------------------------------------------
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_lo, row_span, row_perm, h_num->hist,
-                                   h_num->maxv, d_num, cx, S.ms_num_bin, numeric_only ? 0 : 1);
+                                   h_num->maxv, d_num, cx, S.ms_num_bin, numeric_only ? 0 : 1, bm_off, bm);
     tm.mark(3, s0);
     NSP_CHECK(hipStreamSynchronize(s0));  // synchronous on return, like upstream (:1287)
     LN.collect(S.ms_num_bin);
@@ -1472,6 +1543,11 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     S.ms_total = tm.ms(0, 3);
 
     dev_free(scan_tmp);
+    dev_free(bm);
+    dev_free(bm_scan_tmp);
+    dev_free(row_span_num);
+    dev_free(bm_off);
+    dev_free(bm_words);
     dev_free(partial);
     dev_free(binfo);
     dev_free(row_span);

@@ -127,6 +127,15 @@ def bins_of(n, span, ladder):
     return np.where(n <= tiny, 0, b)
 
 
+def numeric_bins(row_nz, row_prod, span, sym, num):
+    """Numeric bin of every row in a FULL spgemm_kernel_hash call: a row can use the numeric dense
+    window only if the symbolic dense kernel wrote its column bitmap (symbolic bin >= 6) and the
+    window fits the numeric ladder; everything else is binned by nnz alone."""
+    span = np.asarray(span, dtype=np.int64)
+    has_bm = (bins_of(row_prod, span, sym) >= 6) & (span <= num[7])
+    return bins_of(row_nz, np.where(has_bm, span, 0), num)
+
+
 def ladders(lib):
     sym = (C.c_int * 9)()
     num = (C.c_int * 9)()

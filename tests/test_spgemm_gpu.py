@@ -10,7 +10,7 @@ import pytest
 
 import nsparse_amd as ns
 from conftest import GOLDEN, TEST_MTX, load_golden
-from gpu_util import bins_of, ladders, row_windows, spgemm, synth
+from gpu_util import bins_of, ladders, numeric_bins, row_windows, spgemm, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -63,7 +63,7 @@ def _bins_match(orc, st, row_prod, row_nz, lib, A, B=None):
     prod, span = row_windows(A, B)
     assert np.array_equal(prod, row_prod)
     assert list(st.sym_bin_size)[:9] == np.bincount(bins_of(row_prod, span, sym), minlength=9).tolist()
-    assert list(st.num_bin_size)[:9] == np.bincount(bins_of(row_nz, span, num), minlength=9).tolist()
+    assert list(st.num_bin_size)[:9] == np.bincount(numeric_bins(row_nz, row_prod, span, sym, num), minlength=9).tolist()
 
 
 @pytest.mark.parametrize("kind,p,prec", [
