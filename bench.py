@@ -104,11 +104,21 @@ def main():
 
     import torch
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NSPARSE_BENCH_BACKEND=gloo: smoke-test the multi-rank path on a box with fewer GPUs than
+    # ranks (ranks share devices; RCCL refuses that).  Never used for reported numbers.
+    backend = os.environ.get("NSPARSE_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    red_dev = dev if backend == "nccl" else torch.device("cpu")
 
     def barrier():
         if world > 1:
@@ -162,8 +172,8 @@ def main():
         lib.release_csr(c)
     barrier()
     elapsed = time.perf_counter() - t_start
-    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    flops_all = torch.tensor([float(flop.value)], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    flops_all = torch.tensor([float(flop.value)], dtype=torch.float64, device=red_dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(flops_all, op=dist.ReduceOp.SUM)
@@ -236,7 +246,7 @@ def main():
             op(x, gather=gather)
         e1.record()
         barrier()
-        el = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=dev)
+        el = torch.tensor([time.perf_counter() - t], dtype=torch.float64, device=red_dev)
         if world > 1:
             dist.all_reduce(el, op=dist.ReduceOp.MAX)
         return float(el.item()) * 1e3 / steps, e0.elapsed_time(e1) / steps
@@ -247,7 +257,7 @@ def main():
         fp = int(lib.nsparse_amb_footprint_bytes(C.byref(op.amb)))
         # x is counted once over N instead of the reference's second M*w term
         b_amb = fp - A_rows["M"] * w + N_cols * w
-        fp_all = torch.tensor([float(b_amb)], dtype=torch.float64, device=dev)
+        fp_all = torch.tensor([float(b_amb)], dtype=torch.float64, device=red_dev)
         if world > 1:
             dist.all_reduce(fp_all, op=dist.ReduceOp.SUM)
         ms_c, ms_c_ev = time_spmv(op, x, args.spmv_steps, gather=False)
@@ -290,7 +300,7 @@ def main():
         rpr, blocks = row_partition(M2, world)
         t0 = time.time()
         A2, src2 = load_or_synth(lib, "nlpkkt120", 1, (gx, gy, gz), 0x5EED0044, rows=blocks[rank] if world > 1 else (0, 0))
-        nnz2 = torch.tensor([float(A2["rpt"][-1])], dtype=torch.float64, device=dev)
+        nnz2 = torch.tensor([float(A2["rpt"][-1])], dtype=torch.float64, device=red_dev)
         if world > 1:
             dist.all_reduce(nnz2, op=dist.ReduceOp.SUM)
         log(f"[rank {rank}] {src2}: rows {A2['M']} nnz {A2['rpt'][-1]} ({time.time() - t0:.1f}s)")
@@ -342,6 +352,7 @@ def main():
             "value": round(gflops, 2), "unit": "GFLOPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if "synthetic" in src else "file",
+            **({"backend_override": backend} if backend != "nccl" else {}),
             "config": {"workload": f"{src}: 3-dof 27-pt FEM brick 9x9x{nz}, {M_glob} rows, C=A^2 by 1-D row blocks of 62451 rows"
                                    if "synthetic" in src else src,
                        "rows_per_gpu": int(a.M), "nnz_A_per_gpu": nnz_a, "n_prod_per_gpu": n_prod,

@@ -90,7 +90,13 @@ def make_gpu_sharded_spmv(lib, A_local, M_global, rank, world_size, device, plan
         return torch.zeros(n, dtype=tdtype, device=device)
 
     def all_gather(out, inp):
-        dist.all_gather_into_tensor(out, inp)
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(out, inp)  # RCCL, device buffers, in stream order
+        else:  # smoke-test backends (gloo) gather through host memory
+            torch.cuda.synchronize()
+            parts = [torch.empty(inp.numel(), dtype=inp.dtype) for _ in range(world_size)]
+            dist.all_gather(parts, inp.cpu())
+            out.copy_(torch.cat(parts).to(out.device))
 
     op = ShardedSpMV(M_global, rank, world_size, local_spmv, make_buffer, all_gather)
     assert m_local == op.end - op.begin

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""BASELINE configs 3 and 5 (and any synthetic kind) through the C-ABI: timing, bin histograms and
+structure parity against the OpenMP oracle.  Usage on the GPU box:
+   python tools/run_configs.py webbase | rmat18 | rmat20 | cant | all
+"""
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import nsparse_amd as ns  # noqa: E402
+from gpu_util import synth  # noqa: E402
+from oracle.oracle import Oracle  # noqa: E402
+
+CASES = {
+    "webbase": ("s", 2, (1000005, 3105536, 0)),
+    "webbase_d": ("d", 2, (1000005, 3105536, 0)),
+    "rmat16": ("d", 3, (16, 16, 0)),
+    "rmat18": ("d", 3, (18, 16, 0)),
+    "rmat20": ("d", 3, (20, 8, 0)),
+    "cant": ("d", 0, (9, 9, 257)),
+    "stencil": ("d", 1, (100, 100, 100)),
+}
+
+
+def run(name, check=True, reps=5):
+    prec, kind, p = CASES[name]
+    lib, orc = ns.load(prec), Oracle(prec)
+    t = time.time()
+    A = synth(lib, kind, *p, seed=0x5EED0022)
+    gen = time.time() - t
+    a = lib.csr_from_numpy(A["rpt"], A["col"], A["val"], A["N"])
+    b = lib.csr_from_numpy(A["rpt"], A["col"], A["val"], A["N"])
+    lib.csr_memcpy(C.byref(a))
+    lib.csr_memcpy(C.byref(b))
+    c = ns.sfCSR()
+    st = ns.SpgemmStats()
+    ms = []
+    for i in range(reps + 1):
+        t = time.perf_counter()
+        lib.spgemm_kernel_hash(C.byref(a), C.byref(b), C.byref(c))
+        ms.append((time.perf_counter() - t) * 1e3)
+        lib.nsparse_get_spgemm_stats(C.byref(st))
+        if i < reps:
+            lib.release_csr(c)
+    out = dict(case=name, prec=prec, M=A["M"], nnzA=int(A["rpt"][-1]), n_prod=int(st.n_prod), nnzC=int(st.nnz_c),
+               max_prod_row=st.max_prod_row, max_nnz_row=st.max_nnz_row, gen_s=round(gen, 1),
+               ms_first=round(ms[0], 3), ms=round(float(np.mean(ms[1:])), 3),
+               gflops=round(2 * st.n_prod / (np.mean(ms[1:]) * 1e6), 1),
+               phase=[round(v, 3) for v in (st.ms_setup, st.ms_symbolic, st.ms_numeric)],
+               sym_bins=list(st.sym_bin_size)[:9], num_bins=list(st.num_bin_size)[:9],
+               sym_ms=[round(v, 3) for v in list(st.ms_sym_bin)[:9]],
+               num_ms=[round(v, 3) for v in list(st.ms_num_bin)[:9]], fails=st.sym_fail_rows)
+    if check:
+        lib.csr_memcpyDtH(C.byref(c))
+        got = lib.csr_host_to_numpy(c)
+        lib.release_cpu_csr(c)
+        t = time.time()
+        ref = orc.spgemm_omp(A, A)
+        out["oracle_s"] = round(time.time() - t, 1)
+        out["rpt_ok"] = bool(np.array_equal(got["rpt"], ref["rpt"]))
+        out["col_ok"] = bool(np.array_equal(got["col"], ref["col"]))
+        out["val_fails"] = orc.check_spgemm(got, dict(ref, M=A["M"])) if out["col_ok"] else -9
+    lib.release_csr(c)
+    lib.release_csr(a)
+    lib.release_csr(b)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or ["webbase", "rmat16"]
+    if names == ["all"]:
+        names = list(CASES)
+    for n in names:
+        run(n)
