@@ -189,8 +189,8 @@ def main():
     crpt = lib.d2h(c.d_rpt, (c.M + 1,), np.int32)
     nnz_c = c.nnz
     lib.release_csr(c)
-    sym_thr = (C.c_int * 9)()
-    num_thr = (C.c_int * 9)()
+    sym_thr = (C.c_int * 13)()
+    num_thr = (C.c_int * 13)()
     lib.nsparse_get_spgemm_bins(sym_thr, num_thr)
     bytes_bin, prods_bin, row_prod = numeric_bin_bytes(A_loc, A_full, crpt, list(sym_thr), list(num_thr), w)
     dom = int(np.argmax(bin_ms))
@@ -360,9 +360,9 @@ def main():
                        "timing": "whole spgemm_kernel_hash call incl. allocation (block cache on)"},
             "phase_ms": {"setup": round(float(phase[0]), 4), "symbolic": round(float(phase[1]), 4),
                          "numeric": round(float(phase[2]), 4), "total_events": round(float(phase[3]), 4),
-                         "numeric_bins": [round(float(v), 4) for v in bin_ms[:9]],
-                         "symbolic_bins": [round(float(v), 4) for v in sym_ms[:9]],
-                         "sym_bin_rows": list(st.sym_bin_size)[:9], "num_bin_rows": list(st.num_bin_size)[:9]},
+                         "numeric_bins": [round(float(v), 4) for v in bin_ms[:11]],
+                         "symbolic_bins": [round(float(v), 4) for v in sym_ms[:11]],
+                         "sym_bin_rows": list(st.sym_bin_size)[:11], "num_bin_rows": list(st.num_bin_size)[:11]},
             "roofline": roofline,
             "cpu_baseline": cpu,
             "spmv": spmv,

@@ -220,7 +220,7 @@ typedef struct {
     int nnz_c;
     int max_prod_row;         /* longest row of intermediate products               */
     int max_nnz_row;          /* longest row of C                                   */
-    int sym_bin_size[12];     /* rows per symbolic bin (0 tiny, 1-5 hash, 6-8 dense window) */
+    int sym_bin_size[12];     /* rows per symbolic bin (0 tiny, 1-5 hash, 6-8 dense window, 9-10 bit window) */
     int num_bin_size[12];     /* rows per numeric bin                               */
     int sym_fail_rows;        /* rows that overflowed LDS and went to the global table */
     float ms_setup;           /* products + binning              (HIP events)       */
@@ -232,9 +232,11 @@ typedef struct {
 } nsparse_spgemm_stats;
 void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out);
 
-/* Bin ladder of the symbolic / numeric phase, 9 ints each: tiny, hash_t[4], dense_span[3],
- * dense_ratio.  Row (n, span) -> bin: n <= tiny: 0; span <= dense_span[2] and
- * span <= dense_ratio * n: 6 + #(dense_span < span); else 1 + #(hash_t < n).            */
+/* Bin ladder of the symbolic / numeric phase, 13 ints each: tiny, hash_t[4], dense_span[3],
+ * dense_ratio, bits_span[2], bits_ratio, bits_min.  Row (n, span) -> bin: n <= tiny: 0;
+ * span <= dense_span[2] and span <= dense_ratio * n: 6 + #(dense_span < span);
+ * n > bits_min and span <= bits_span[1] and span <= bits_ratio * n: 9 + (span > bits_span[0]);
+ * else 1 + #(hash_t < n).                                                               */
 void nsparse_get_spgemm_bins(int *sym_thresholds, int *num_thresholds);
 
 /* 1: serialise the row bins on one stream (clean per-kernel durations for roofline work

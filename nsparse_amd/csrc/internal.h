@@ -37,7 +37,7 @@ void dev_cache_enable(bool on);
 void dev_cache_trim();
 
 // ---- per-process context ---------------------------------------------------------
-constexpr int kMaxBins = 10;
+constexpr int kMaxBins = 12;
 
 struct Context {
     hipStream_t stream[kMaxBins] = {};  // one per row bin (the reference uses 7)

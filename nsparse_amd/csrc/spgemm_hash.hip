@@ -73,6 +73,8 @@ constexpr int NB = kMaxBins;
 //   bin 4  n <= 5461    1024 threads, table <= 8192  (96 KiB fp64 + 32 KiB sort keys)
 //   bin 5  n  > 5461    global-memory tables
 // Row -> bin.  Bin 0: tiny rows (sub-wave kernels).  Bins 1..5: hash tables sized by n.
+// Bins 9..10 (symbolic only): BIT WINDOW rows -- same idea with one bit per column, for rows
+// with many products whose window is too wide for byte flags (up to 2^20 columns = 128 KiB).
 // Bins 6..8: DENSE WINDOW rows -- the columns a C row can touch lie in [lo, lo+span) and
 // span is small enough for an LDS array indexed by (col - lo): no probing, no compare-and-swap
 // with return, no sort (see k_sym_dense / k_num_dense).  A row is dense-eligible when
@@ -83,12 +85,16 @@ struct Thr {
     int hash_t[4];       // n <= hash_t[k]      -> bin 1 + k, above -> bin 5
     int dense_span[3];   // span <= dense_span[k] -> bin 6 + k
     int dense_ratio;     // 0 disables the dense bins
+    int bits_span[2];    // symbolic only: span <= bits_span[k] -> bin 9 + k (1 bit per column)
+    int bits_ratio;      // span <= bits_ratio * n; 0 disables
+    int bits_min;        // only rows with n > bits_min (small rows hash faster than they clear)
 };
-constexpr Thr kSymThr = {32, {512, 2048, 8192, 32768}, {4096, 16384, 65536}, 8};
-constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8};
+constexpr Thr kSymThr = {32, {512, 2048, 8192, 32768}, {4096, 16384, 65536}, 8, {262144, 1048576}, 64, 2048};
+constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8, {0, 0}, 0, 0};
 constexpr int kSymLargeBin = 5;
 constexpr int kNumGlobalBin = 5;
 constexpr int kDenseBin0 = 6;
+constexpr int kBitsBin0 = 9;
 constexpr int kSetupMaxGrid = 16384;
 constexpr int kPartialStride = 16;  // long longs per block: hist[NB], max, total
 constexpr int kSymLargeT = 32768;
@@ -118,6 +124,9 @@ __host__ __device__ __forceinline__ int bin_of(int n, int span, const Thr &thr)
     if (thr.dense_ratio > 0 && span > 0 && span <= thr.dense_span[2] &&
         (long long)span <= (long long)thr.dense_ratio * n)
         return kDenseBin0 + (span > thr.dense_span[0]) + (span > thr.dense_span[1]);
+    if (thr.bits_ratio > 0 && n > thr.bits_min && span > 0 && span <= thr.bits_span[1] &&
+        (long long)span <= (long long)thr.bits_ratio * n)
+        return kBitsBin0 + (span > thr.bits_span[0]);
     int b = 1;
 #pragma unroll
     for (int q = 0; q < 4; q++) b += (n > thr.hash_t[q]) ? 1 : 0;
@@ -1047,6 +1056,56 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
     if (threadIdx.x == 0) row_nz[rid] = s_nz;
 }
 
+// Symbolic for rows with many products and a wide window: one BIT per column of the window in
+// LDS (128 KiB cover 2^20 columns), set with a no-return LDS atomic OR.  Replaces the 32768-key
+// hash table (1 workgroup per CU, CAS with return per product) and the try-in-LDS / global
+// table detour for every row of a matrix with up to a million columns.
+template <int BS, int WORDS_MAX>
+__global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                 const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                 const int *__restrict__ row_perm,
+                                                 const int *__restrict__ row_prod,
+                                                 const int *__restrict__ row_lo,
+                                                 const int *__restrict__ row_span,
+                                                 int *__restrict__ row_nz, int bin_off, int bin_size,
+                                                 int bnnz)
+{
+    __shared__ __attribute__((aligned(16))) unsigned int bits[WORDS_MAX];
+    __shared__ int2 s_ext[BS];
+    __shared__ int s_nz;
+    const int slot = xcd_row_slot(bin_size);
+    if (slot < 0) return;
+    const int rid = row_perm[bin_off + slot];
+    const int lo = row_lo[rid];
+    const int words = (row_span[rid] + 31) >> 5;
+    {
+        uint4 *b4 = reinterpret_cast<uint4 *>(bits);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < (words + 3) / 4; i += BS) b4[i] = z;
+    }
+    if (threadIdx.x == 0) s_nz = 0;
+    __syncthreads();
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS);
+    walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
+                             a_end, g, s_ext, (real *)nullptr,
+                             [&](const IVec &k, const RVec &, int n, real) {
+#pragma unroll
+                                 for (int i = 0; i < VW; i++)
+                                     if (i < n) {
+                                         const int idx = k.v[i] - lo;
+                                         atomicOr(bits + (idx >> 5), 1u << (idx & 31));
+                                     }
+                             });
+    __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < words; i += BS) cnt += __popc(bits[i]);
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) row_nz[rid] = s_nz;
+}
+
 template <int BS, int SPAN_MAX, int MODE>
 __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                   const real *__restrict__ aval,
@@ -1275,6 +1334,18 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
+#define NSP_SYM_BITS(BIN, BS, WORDS)                                                           \
+    if (hist[BIN] > 0) {                                                                       \
+        hipStream_t st = L.begin(BIN);                                                         \
+        hipLaunchKernelGGL((k_sym_bits<BS, WORDS>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
+                           arpt, acol, brpt, bcol, row_perm, row_prod, row_lo, row_span, row_nz, \
+                           off[BIN], hist[BIN], b->nnz);                                       \
+        NSP_LAUNCH_CHECK();                                                                    \
+        L.end(BIN);                                                                            \
+    }
+    NSP_SYM_BITS(10, 1024, 32768)
+    NSP_SYM_BITS(9, 512, 8192)
+#undef NSP_SYM_BITS
     static const int tune_d6 = getenv("NSPARSE_SYMD6_BS") ? atoi(getenv("NSPARSE_SYMD6_BS")) : 128;
     NSP_SYM_DENSE(8, 1024, 65536)
     NSP_SYM_DENSE(7, 512, 16384)
@@ -1456,7 +1527,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
         g_dense_enabled = !(e && e[0] == '0');
     }
     Thr sym_thr = kSymThr, num_thr = kNumThr;
-    if (!g_dense_enabled) sym_thr.dense_ratio = num_thr.dense_ratio = 0;
+    if (!g_dense_enabled) sym_thr.dense_ratio = num_thr.dense_ratio = sym_thr.bits_ratio = 0;
     NSP_CHECK(hipStreamSynchronize(0));  // inputs queued on the null stream by the caller
     NSP_CHECK(hipMemsetAsync(d_sym, 0, 2 * sizeof(BinState), s0));
 
@@ -1583,7 +1654,8 @@ void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out) { *out = nsp::spgemm::g
 
 void nsparse_get_spgemm_bins(int *sym, int *num)
 {
-    // 9 ints each: tiny, hash_t[4], dense_span[3], dense_ratio (0 when NSPARSE_DENSE=0)
+    // 13 ints each: tiny, hash_t[4], dense_span[3], dense_ratio, bits_span[2], bits_ratio,
+    // bits_min (ratios are 0 when NSPARSE_DENSE=0)
     const nsp::spgemm::Thr *t[2] = {&nsp::spgemm::kSymThr, &nsp::spgemm::kNumThr};
     int *out[2] = {sym, num};
     if (nsp::spgemm::g_dense_enabled < 0) {
@@ -1595,6 +1667,10 @@ void nsparse_get_spgemm_bins(int *sym, int *num)
         for (int q = 0; q < 4; q++) out[p][1 + q] = t[p]->hash_t[q];
         for (int q = 0; q < 3; q++) out[p][5 + q] = t[p]->dense_span[q];
         out[p][8] = nsp::spgemm::g_dense_enabled ? t[p]->dense_ratio : 0;
+        out[p][9] = t[p]->bits_span[0];
+        out[p][10] = t[p]->bits_span[1];
+        out[p][11] = nsp::spgemm::g_dense_enabled ? t[p]->bits_ratio : 0;
+        out[p][12] = t[p]->bits_min;
     }
 }
 

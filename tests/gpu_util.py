@@ -121,6 +121,10 @@ def bins_of(n, span, ladder):
     span = np.asarray(span, dtype=np.int64)
     tiny, hash_t, dspan, ratio = ladder[0], ladder[1:5], ladder[5:8], ladder[8]
     b = 1 + sum((n > t).astype(np.int64) for t in hash_t)
+    if len(ladder) > 9 and ladder[11] > 0:
+        bspan, bratio, bmin = ladder[9:11], ladder[11], ladder[12]
+        bits = (n > bmin) & (span > 0) & (span <= bspan[1]) & (span <= bratio * n)
+        b = np.where(bits, 9 + (span > bspan[0]), b)
     if ratio > 0:
         dense = (span > 0) & (span <= dspan[2]) & (span <= ratio * n)
         b = np.where(dense, 6 + (span > dspan[0]) + (span > dspan[1]), b)
@@ -137,7 +141,35 @@ def numeric_bins(row_nz, row_prod, span, sym, num):
 
 
 def ladders(lib):
-    sym = (C.c_int * 9)()
-    num = (C.c_int * 9)()
+    sym = (C.c_int * 13)()
+    num = (C.c_int * 13)()
     lib.nsparse_get_spgemm_bins(sym, num)
     return list(sym), list(num)
+
+
+def spgemm_subprocess(A, env, prec="d"):
+    """Run spgemm() on A in a fresh interpreter with extra environment (the library reads its
+    tuning switches once per process).  Returns (C dict, dict of stats lists)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "a.npz"), rpt=A["rpt"], col=A["col"], val=A["val"], M=A["M"], N=A["N"])
+        code = (
+            "import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+            "import nsparse_amd as ns; from gpu_util import spgemm;"
+            "z = np.load(%r); A = dict(rpt=z['rpt'], col=z['col'], val=z['val'], M=int(z['M']), N=int(z['N']));"
+            "got, st = spgemm(ns.load(%r), A);"
+            "np.savez(%r, rpt=got['rpt'], col=got['col'], val=got['val']);"
+            "print(json.dumps(dict(sym=list(st.sym_bin_size), num=list(st.num_bin_size), fails=st.sym_fail_rows)))"
+        ) % (root, os.path.join(root, "tests"), os.path.join(td, "a.npz"), prec, os.path.join(td, "c.npz"))
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stderr[-3000:]
+        stats = json.loads(r.stdout.strip().splitlines()[-1])
+        z = np.load(os.path.join(td, "c.npz"))
+        got = dict(M=A["M"], N=A["N"], nnz=int(z["rpt"][-1]), rpt=z["rpt"], col=z["col"], val=z["val"])
+    return got, stats

@@ -10,7 +10,7 @@ import pytest
 
 import nsparse_amd as ns
 from conftest import GOLDEN, TEST_MTX, load_golden
-from gpu_util import bins_of, ladders, numeric_bins, row_windows, spgemm, synth
+from gpu_util import bins_of, ladders, numeric_bins, row_windows, spgemm, spgemm_subprocess, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -62,7 +62,7 @@ def _bins_match(orc, st, row_prod, row_nz, lib, A, B=None):
     sym, num = ladders(lib)
     prod, span = row_windows(A, B)
     assert np.array_equal(prod, row_prod)
-    assert list(st.sym_bin_size)[:9] == np.bincount(bins_of(row_prod, span, sym), minlength=9).tolist()
+    assert list(st.sym_bin_size)[:11] == np.bincount(bins_of(row_prod, span, sym), minlength=11).tolist()
     assert list(st.num_bin_size)[:9] == np.bincount(numeric_bins(row_nz, row_prod, span, sym, num), minlength=9).tolist()
 
 
@@ -133,13 +133,15 @@ def test_every_bin_is_exercised(lib_d, oracle_d):
     assert_parity(oracle_d, got, ref)
     rp, _, _ = oracle_d.nprod(A["rpt"], A["col"], A["rpt"])
     _bins_match(oracle_d, st, rp, ref["row_nz"], lib_d, A)
-    assert st.sym_bin_size[5] >= 1, "no row reached the try-in-LDS symbolic bin"
+    assert st.sym_bin_size[5] + st.sym_bin_size[9] + st.sym_bin_size[10] >= 1, "no big symbolic row"
     assert st.num_bin_size[5] >= 1, "no row reached the global numeric bin"
     assert sum(1 for b in list(st.num_bin_size)[:9] if b > 0) >= 4
 
 
 def test_symbolic_overflow_falls_back_to_global_table(lib_d, oracle_d):
-    """A row with > 24576 distinct output columns must fail over from LDS to the global table."""
+    """A row with > 24576 distinct output columns.  Default build: the LDS bit window counts it
+    (bin 9).  NSPARSE_DENSE=0: it must fail over from the 32768-key LDS table to the global table.
+    Both give the oracle's structure."""
     rng = np.random.default_rng(5)
     n = 120000
     cols = np.sort(rng.choice(n, 3000, replace=False))
@@ -147,33 +149,25 @@ def test_symbolic_overflow_falls_back_to_global_table(lib_d, oracle_d):
     ref = oracle_d.spgemm(A, A)
     assert ref["row_nz"][7] > 24576
     got, st = spgemm(lib_d, A)
-    assert st.sym_fail_rows >= 1
+    assert st.sym_bin_size[9] >= 1 and st.sym_fail_rows == 0
     assert_parity(oracle_d, got, ref)
+    got0, st0 = spgemm_subprocess(A, {"NSPARSE_DENSE": "0"})
+    assert st0["fails"] >= 1 and st0["sym"][5] >= 1 and sum(st0["sym"][6:]) == 0
+    assert_parity(oracle_d, got0, ref)
 
 
 def test_dense_window_and_hash_paths_agree(lib_d, oracle_d):
     """Banded / FEM rows take the dense-window bins (6-8); NSPARSE_DENSE=0 (separate process) sends
     the same rows through the hash bins.  Both must give the oracle's structure."""
-    import subprocess, sys, json
     A = synth(lib_d, 0, 6, 6, 20, seed=5)
     got, st = spgemm(lib_d, A)
     ref = oracle_d.spgemm(A, A)
     assert_parity(oracle_d, got, ref)
     assert sum(list(st.sym_bin_size)[6:9]) > 0 and sum(list(st.num_bin_size)[6:9]) > 0
-    code = ("import sys, json, numpy as np; sys.path.insert(0, 'tests'); import nsparse_amd as ns;"
-            "from gpu_util import spgemm, synth; lib = ns.load('d'); A = synth(lib, 0, 6, 6, 20, seed=5);"
-            "got, st = spgemm(lib, A);"
-            "print(json.dumps(dict(rpt=got['rpt'].tolist(), col=got['col'].tolist(), val=got['val'].tolist(),"
-            "dense=int(sum(list(st.sym_bin_size)[6:9]) + sum(list(st.num_bin_size)[6:9])))))")
-    from conftest import ROOT
-    import os
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True,
-                       env=dict(os.environ, NSPARSE_DENSE="0"))
-    assert r.returncode == 0, r.stderr[-2000:]
-    h = json.loads(r.stdout.strip().splitlines()[-1])
-    assert h["dense"] == 0
-    assert h["rpt"] == got["rpt"].tolist() and h["col"] == got["col"].tolist()
-    np.testing.assert_allclose(np.array(h["val"]), got["val"], rtol=1e-9)
+    got0, st0 = spgemm_subprocess(A, {"NSPARSE_DENSE": "0"})
+    assert sum(st0["sym"][6:]) == 0 and sum(st0["num"][6:]) == 0
+    assert_parity(oracle_d, got0, ref)
+    np.testing.assert_allclose(got0["val"], got["val"], rtol=1e-9)
 
 
 def test_workspace_cache_off_is_identical(lib_d, oracle_d):

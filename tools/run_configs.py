@@ -54,9 +54,9 @@ def run(name, check=True, reps=5):
                ms_first=round(ms[0], 3), ms=round(float(np.mean(ms[1:])), 3),
                gflops=round(2 * st.n_prod / (np.mean(ms[1:]) * 1e6), 1),
                phase=[round(v, 3) for v in (st.ms_setup, st.ms_symbolic, st.ms_numeric)],
-               sym_bins=list(st.sym_bin_size)[:9], num_bins=list(st.num_bin_size)[:9],
-               sym_ms=[round(v, 3) for v in list(st.ms_sym_bin)[:9]],
-               num_ms=[round(v, 3) for v in list(st.ms_num_bin)[:9]], fails=st.sym_fail_rows)
+               sym_bins=list(st.sym_bin_size)[:11], num_bins=list(st.num_bin_size)[:11],
+               sym_ms=[round(v, 3) for v in list(st.ms_sym_bin)[:11]],
+               num_ms=[round(v, 3) for v in list(st.ms_num_bin)[:11]], fails=st.sym_fail_rows)
     if check:
         lib.csr_memcpyDtH(C.byref(c))
         got = lib.csr_host_to_numpy(c)
