@@ -202,7 +202,10 @@ def main():
     pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     if os.path.exists(pmc_path):
         try:
-            traffic = json.load(open(pmc_path)).get("spgemm_" + dom_kernel)
+            pm = json.load(open(pmc_path))
+            key = "spgemm_" + dom_kernel.rstrip(">")
+            hits = [v for k, v in pm.items() if k.startswith(key)]
+            traffic = hits[0] if hits else None
         except Exception:
             traffic = None
     n_prod = int(flop.value // 2)

@@ -20,6 +20,8 @@
 //   * reads of x are clamped to N-1 and rows >= M are not written, so neither the
 //     N + MAX_BLOCK_SIZE / M + WARP over-allocation of the reference's callers
 //     (spmv_amb.cu:32-33) nor the uninitialised tail of x can influence the result.
+#include <cstdlib>
+
 #include "internal.h"
 
 namespace nsp {
@@ -27,7 +29,7 @@ namespace spmv {
 
 static float g_last_ms = 0.f;
 
-template <int BSZ, int C, bool ATOMIC>
+template <int BSZ, int C, bool ATOMIC, bool NT>
 __global__ __launch_bounds__(1024) void k_spmv_amb(real *__restrict__ y, const real *__restrict__ val,
                                                    const unsigned short *__restrict__ col,
                                                    const unsigned int *__restrict__ cl,
@@ -38,7 +40,7 @@ __global__ __launch_bounds__(1024) void k_spmv_amb(real *__restrict__ y, const r
                                                    int rows, int seg_size, int M, int N, int nb8)
 {
     // XCD-aware remap: hardware block b -> logical block (b % 8) * nb8 + b / 8
-    const int lb = (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3);
+    const int lb = nb8 > 0 ? (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     const long long i = (long long)lb * blockDim.x + threadIdx.x;
     if (i >= rows) return;
     const int c = (int)(i / C);
@@ -54,11 +56,11 @@ __global__ __launch_bounds__(1024) void k_spmv_amb(real *__restrict__ y, const r
     real acc = 0;
 #pragma unroll 4
     for (int h = 0; h <= width; h++) {
-        const int cc = (int)__builtin_nontemporal_load(cp) + c_off;
+        const int cc = (int)(NT ? __builtin_nontemporal_load(cp) : *cp) + c_off;
 #pragma unroll
         for (int b = 0; b < BSZ; b++) {
             const int xi = cc + b < nmax ? cc + b : nmax;
-            acc += __builtin_nontemporal_load(v) * x[xi];
+            acc += (NT ? __builtin_nontemporal_load(v) : *v) * x[xi];
             v += C;
         }
         cp += C;
@@ -76,15 +78,23 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
     const int nb = ceil_div(rows, tb);
     const int nb8 = ceil_div(nb, 8);
     const bool atomic = mat->seg_num > 1;
-    const dim3 grid(nb8 * 8), block(tb);
+    static const int no_remap = getenv("NSPARSE_SPMV_NOREMAP") ? 1 : 0;
+    static const int plain = getenv("NSPARSE_SPMV_PLAIN") ? 1 : 0;
+    const dim3 grid(no_remap ? nb : nb8 * 8), block(tb);
+    const int nb8_arg = no_remap ? 0 : nb8;
 #define NSP_GO(CC, AT)                                                                          \
-    hipLaunchKernelGGL((k_spmv_amb<BSZ, CC, AT>), grid, block, 0, st, d_y, mat->d_sellcs_val,      \
-                       mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
-                       mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8)
+    if (plain)                                                                                  \
+        hipLaunchKernelGGL((k_spmv_amb<BSZ, CC, AT, false>), grid, block, 0, st, d_y, mat->d_sellcs_val, \
+                           mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
+                           mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg); \
+    else                                                                                        \
+        hipLaunchKernelGGL((k_spmv_amb<BSZ, CC, AT, true>), grid, block, 0, st, d_y, mat->d_sellcs_val, \
+                           mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
+                           mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg)
     if (mat->chunk == 64) {
-        if (atomic) NSP_GO(64, true); else NSP_GO(64, false);
+        if (atomic) { NSP_GO(64, true); } else { NSP_GO(64, false); }
     } else {
-        if (atomic) NSP_GO(32, true); else NSP_GO(32, false);
+        if (atomic) { NSP_GO(32, true); } else { NSP_GO(32, false); }
     }
 #undef NSP_GO
 }
