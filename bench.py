@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--spmv-steps", type=int, default=100)  # TRI_NUM - 1
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-large", action="store_true", help="skip the nlpkkt-class SpMV")
+    ap.add_argument("--no-vendor", action="store_true", help="skip the rocSPARSE (torch.sparse) baseline")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -313,6 +314,45 @@ def main():
     else:
         A2_host = None
 
+    # ------------------------------------------------ vendor baseline (rocSPARSE) ----
+    # The reference samples print their numbers next to cuSPARSE (spgemm_cu_csr / spmv_cu_csr,
+    # SURVEY 8f rank 3).  rocSPARSE is reached through torch.sparse: CSR @ CSR is
+    # rocsparse_spgemm, CSR @ vector is rocsparse_spmv.  Informational only.
+    vendor = None
+    if rank == 0 and world == 1 and not args.no_vendor:
+        try:
+            import warnings
+            warnings.filterwarnings("ignore")
+            crow = torch.from_numpy(A_loc["rpt"].astype(np.int32)).to(dev)
+            ccol = torch.from_numpy(A_loc["col"].astype(np.int32)).to(dev)
+            cval = torch.from_numpy(A_loc["val"].astype(np.float64)).to(dev)
+            At = torch.sparse_csr_tensor(crow, ccol, cval, size=(A_loc["M"], A_full["N"]))
+            for _ in range(2):
+                Ct = torch.sparse.mm(At, At)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            reps_v = 5
+            for _ in range(reps_v):
+                Ct = torch.sparse.mm(At, At)
+            torch.cuda.synchronize()
+            ms_v = (time.perf_counter() - t) * 1e3 / reps_v
+            xv = torch.rand(A_full["N"], dtype=torch.float64, device=dev)
+            for _ in range(3):
+                yv = At @ xv
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(50):
+                yv = At @ xv
+            torch.cuda.synchronize()
+            ms_s = (time.perf_counter() - t) * 1e3 / 50
+            vendor = {"library": "rocSPARSE via torch.sparse (torch %s)" % torch.__version__,
+                      "spgemm_ms": round(ms_v, 3), "spgemm_gflops": round(flop.value / (ms_v * 1e6), 1),
+                      "spgemm_nnz_c": int(Ct._nnz()), "spmv_ms": round(ms_s, 4),
+                      "spmv_gbs_csr_model": round((nnz_a * 12 + 4 * (a.M + 1) + 16 * a.M) / (ms_s * 1e-3) / 1e9, 1)}
+            del At, Ct
+        except Exception as e:  # torch build without sparse CSR matmul
+            vendor = {"error": repr(e)[:200]}
+
     # ----------------------------------------------------------- CPU baseline ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -368,6 +408,7 @@ def main():
                          "sym_bin_rows": list(st.sym_bin_size)[:11], "num_bin_rows": list(st.num_bin_size)[:11]},
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "vendor_baseline": vendor,
             "spmv": spmv,
             "spmv_hbm": spmv_hbm,
         }

@@ -214,6 +214,12 @@ long long nsparse_amb_footprint_bytes(const sfAMB *mat);
  * is recomputed (the cuda-cpp tree's SpGEMM_Hash_Numeric, HashSpGEMM_volta.hpp:1018-1031). */
 void nsparse_spgemm_hash_numeric(sfCSR *a, sfCSR *b, sfCSR *c);
 
+/* 1 (default): columns of every C row ascend, as check_spgemm_answer requires.  0: rows that
+ * went through a hash table are written in table order (the cuda-cpp tree's template<bool sort>,
+ * HashSpGEMM_volta.hpp:585-604); dense-window rows stay ordered.  rpt and the SET of columns of
+ * each row are unchanged.  Numeric-only re-runs need the sorted structure.  Returns the old value. */
+int nsparse_spgemm_set_sorted(int on);
+
 /* Statistics of the last spgemm_kernel_hash call. */
 typedef struct {
     long long n_prod;         /* intermediate products                              */

@@ -80,6 +80,7 @@ SIGNATURES = {
     "nsparse_amb_footprint_bytes": (C.c_longlong, [_P(sfAMB)]),
     "nsparse_spgemm_hash_numeric": (None, [_P(sfCSR), _P(sfCSR), _P(sfCSR)]),
     "nsparse_get_spgemm_stats": (None, [_P(SpgemmStats)]),
+    "nsparse_spgemm_set_sorted": (C.c_int, [C.c_int]),
     "nsparse_get_spgemm_bins": (None, [c_int_p, c_int_p]),
     "nsparse_set_profiling": (None, [C.c_int]),
     "nsparse_set_workspace_cache": (None, [C.c_int]),

@@ -100,6 +100,7 @@ constexpr int kPartialStride = 16;  // long longs per block: hist[NB], max, tota
 constexpr int kSymLargeT = 32768;
 constexpr int kSymLargeLimit = 24576;
 static int g_dense_enabled = -1;  // -1: read NSPARSE_DENSE on first use
+static int g_sorted = 1;          // 0: hash rows are written in table order (nsparse_spgemm_set_sorted)
 
 // device-resident counters of one binning pass (lives in Context::d_scratch)
 struct BinState {
@@ -771,7 +772,7 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
                 const int o = kt[u];
                 rank += (o != -1 && o < key) ? 1 : 0;
             }
-            if (write_col) ccol[off + rank] = key;
+            if (write_col & 1) ccol[off + rank] = key;
             cval[off + rank] = vt[s];
         }
     }
@@ -891,13 +892,15 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     const int P = pow2_ceil(n);
     for (int i = n + threadIdx.x; i < P; i += BS) srt[i] = 0x7fffffff;
     __syncthreads();
-    if (P > 1) bitonic_sort_lds<BS>(srt, P);
+    // write_col bit 1: unsorted output requested (cuda-cpp template<bool sort>,
+    // HashSpGEMM_volta.hpp:585-604): columns leave in compaction order
+    if (P > 1 && !(write_col & 2)) bitonic_sort_lds<BS>(srt, P);
 
     for (int i = threadIdx.x; i < n; i += BS) {
         const int key = srt[i];
         int h = hash_slot(key, mask);
         while (keys[h] != key) h = (h + 1) & mask;
-        if (write_col) ccol[off + i] = key;
+        if (write_col & 1) ccol[off + i] = key;
         cval[off + i] = vals[h];
     }
 }
@@ -1422,12 +1425,14 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         real *tval = (real *)dev_alloc(sizeof(real) * (size_t)c->nnz);
         int *seg = (int *)dev_alloc(sizeof(int) * 2 * (size_t)rows);
         // when the structure is kept (numeric-only re-run) sort into scratch columns
-        int *out_col = write_col ? c->d_col : (int *)dev_alloc(sizeof(int) * (size_t)c->nnz);
+        const bool unsorted = (write_col & 2) != 0;  // only honoured together with bit 0
+        int *out_col = (write_col & 1) ? c->d_col : (int *)dev_alloc(sizeof(int) * (size_t)c->nnz);
         hipLaunchKernelGGL((k_num_global<512>), dim3(groups), dim3(512), 0, st, arpt, acol, aval, brpt,
-                           bcol, bval, c->d_rpt, tcol, tval, row_perm, off[kNumGlobalBin], rows, d_bs,
-                           kslab, vslab, slice, seg, seg + rows);
+                           bcol, bval, c->d_rpt, unsorted ? c->d_col : tcol, unsorted ? c->d_val : tval,
+                           row_perm, off[kNumGlobalBin], rows, d_bs, kslab, vslab, slice, seg, seg + rows);
         NSP_LAUNCH_CHECK();
         size_t tmp_bytes = 0;
+        if (!unsorted) {
         NSP_CHECK(rocprim::segmented_radix_sort_pairs(nullptr, tmp_bytes, tcol, out_col, tval, c->d_val,
                                                       (unsigned)c->nnz, (unsigned)rows, seg, seg + rows,
                                                       0, 32, st));
@@ -1435,10 +1440,11 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         NSP_CHECK(rocprim::segmented_radix_sort_pairs(tmp, tmp_bytes, tcol, out_col, tval, c->d_val,
                                                       (unsigned)c->nnz, (unsigned)rows, seg, seg + rows,
                                                       0, 32, st));
+        dev_free(tmp);
+        }
         NSP_CHECK(hipStreamSynchronize(st));
         L.end(kNumGlobalBin);
-        dev_free(tmp);
-        if (!write_col) dev_free(out_col);
+        if (!(write_col & 1)) dev_free(out_col);
         dev_free(seg);
         dev_free(tval);
         dev_free(tcol);
@@ -1457,7 +1463,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
 #define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
     if (hist[BIN] > 0) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
-        if (write_col)                                                                         \
+        if (write_col & 1)                                                                     \
             hipLaunchKernelGGL((k_num_dense<BS, SPAN, 1>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
                                0, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
                                c->d_val, row_perm, row_prod, row_lo, row_span, off[BIN],       \
@@ -1603,7 +1609,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
 
     // ---- numeric --------------------------------------------------------------------
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_lo, row_span, row_perm, h_num->hist,
-                                   h_num->maxv, d_num, cx, S.ms_num_bin, numeric_only ? 0 : 1, bm_off, bm);
+                                   h_num->maxv, d_num, cx, S.ms_num_bin,
+                                   numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm);
     tm.mark(3, s0);
     NSP_CHECK(hipStreamSynchronize(s0));  // synchronous on return, like upstream (:1287)
     LN.collect(S.ms_num_bin);
@@ -1651,6 +1658,13 @@ void spgemm_kernel_hash(sfCSR *a, sfCSR *b, sfCSR *c) { nsp::spgemm::run(a, b, c
 void nsparse_spgemm_hash_numeric(sfCSR *a, sfCSR *b, sfCSR *c) { nsp::spgemm::run(a, b, c, true); }
 
 void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out) { *out = nsp::spgemm::g_stats.s; }
+
+int nsparse_spgemm_set_sorted(int on)
+{
+    const int old = nsp::spgemm::g_sorted;
+    nsp::spgemm::g_sorted = on ? 1 : 0;
+    return old;
+}
 
 void nsparse_get_spgemm_bins(int *sym, int *num)
 {

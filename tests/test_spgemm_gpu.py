@@ -170,6 +170,25 @@ def test_dense_window_and_hash_paths_agree(lib_d, oracle_d):
     np.testing.assert_allclose(got0["val"], got["val"], rtol=1e-9)
 
 
+@pytest.mark.parametrize("kind,p", [(2, (40000, 130000, 0)), (3, (11, 8, 0)), (0, (5, 5, 12))])
+def test_unsorted_output_mode(kind, p, lib_d, oracle_d):
+    """nsparse_spgemm_set_sorted(0): same rpt, same SET of (col, val) per row, order free."""
+    A = synth(lib_d, kind, *p, seed=21)
+    ref = oracle_d.spgemm(A, A)
+    old = lib_d.nsparse_spgemm_set_sorted(0)
+    try:
+        got, st = spgemm(lib_d, A)
+    finally:
+        lib_d.nsparse_spgemm_set_sorted(old)
+    assert np.array_equal(got["rpt"], ref["rpt"])
+    # sort every row by column, then the usual rule applies
+    order = np.lexsort((got["col"], np.repeat(np.arange(A["M"]), np.diff(got["rpt"]))))
+    canon = dict(got, col=got["col"][order], val=got["val"][order])
+    assert_parity(oracle_d, canon, ref)
+    if kind != 0:
+        assert not np.array_equal(got["col"], ref["col"]), "expected at least one unsorted row"
+
+
 def test_workspace_cache_off_is_identical(lib_d, oracle_d):
     g = load_golden("banded2k")
     lib_d.nsparse_set_workspace_cache(0)
