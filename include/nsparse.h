@@ -266,6 +266,12 @@ float nsparse_last_spmv_ms(void);
  * to overlap with RCCL.                                                        */
 void nsparse_spmv_amb_async(real *d_y, sfAMB *mat, real *d_x, sfPlan *plan, void *stream);
 
+/* Binary image of a host CSR (exactly what init_csr_matrix_from_file produces).  0 on success.
+ * With NSPARSE_BIN_CACHE=1 the loader reads / writes `<file>.csr.bin` by itself.  An image
+ * written by the other precision build is rejected (-2).                                   */
+int nsparse_save_csr_bin(const sfCSR *mat, const char *path);
+int nsparse_load_csr_bin(sfCSR *mat, const char *path);
+
 /* Synthetic stand-ins for the SuiteSparse inputs named in BASELINE.md (there is
  * no network on the GPU box).  Each fills the HOST side of *mat with malloc'd
  * arrays (free with release_cpu_csr); columns ascend inside every row.

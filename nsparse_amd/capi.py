@@ -87,6 +87,8 @@ SIGNATURES = {
     "nsparse_trim_workspace": (None, []),
     "nsparse_last_spmv_ms": (C.c_float, []),
     "nsparse_spmv_amb_async": (None, [C.c_void_p, _P(sfAMB), C.c_void_p, _P(sfPlan), C.c_void_p]),
+    "nsparse_save_csr_bin": (C.c_int, [_P(sfCSR), C.c_char_p]),
+    "nsparse_load_csr_bin": (C.c_int, [_P(sfCSR), C.c_char_p]),
     "nsparse_synth_csr": (None, [_P(sfCSR), C.c_int, C.c_longlong, C.c_longlong, C.c_longlong,
                                  C.c_ulonglong, C.c_longlong, C.c_longlong]),
 }

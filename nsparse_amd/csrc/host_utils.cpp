@@ -8,6 +8,8 @@
 //   release_cpu_csr / release_cpu_amb              cuda-c/src/nsparse.cu:202-224
 //   csr_kernel                                     cuda-c/src/nsparse.cu:240-259
 //   ans_check / check_spgemm_answer                cuda-c/src/nsparse.cu:261-353
+#include <sys/stat.h>
+
 #include <cctype>
 #include <cstring>
 #include <ctime>
@@ -41,6 +43,9 @@ void clear_error()
 
 extern "C" {
 
+int nsparse_save_csr_bin(const sfCSR *mat, const char *path);
+int nsparse_load_csr_bin(sfCSR *mat, const char *path);
+
 int nsparse_last_error(void) { return nsp::g_err; }
 const char *nsparse_last_error_string(void) { return nsp::g_err_msg.c_str(); }
 
@@ -65,8 +70,24 @@ static inline const char *parse_int(const char *p, const char *end, int *out)
     return p;
 }
 
+static bool bin_cache_on()
+{
+    const char *e = getenv("NSPARSE_BIN_CACHE");
+    return e && e[0] == '1';
+}
+
 void init_csr_matrix_from_file(sfCSR *mat, char *file_name)
 {
+    std::string bin_path = std::string(file_name) + ".csr.bin";
+    if (bin_cache_on()) {
+        struct stat sm, sb;
+        if (stat(file_name, &sm) == 0 && stat(bin_path.c_str(), &sb) == 0 && sb.st_mtime >= sm.st_mtime &&
+            nsparse_load_csr_bin(mat, bin_path.c_str()) == 0) {
+            printf("Read mtx file: %s\n", file_name);  // same line as the text path
+            mat->matrix_name = file_name;
+            return;
+        }
+    }
     FILE *fp = fopen(file_name, "rb");
     if (fp == NULL) {
         printf("Cannot find file\n");  // reference nsparse.cu:35-38
@@ -173,6 +194,69 @@ void init_csr_matrix_from_file(sfCSR *mat, char *file_name)
     mat->nnz = (int)total;
     mat->nnz_max = nnz_max;
     mat->matrix_name = file_name;  // borrowed, like upstream (nsparse.cu:143)
+    mat->d_rpt = nullptr;
+    mat->d_col = nullptr;
+    mat->d_val = nullptr;
+    if (bin_cache_on()) (void)nsparse_save_csr_bin(mat, bin_path.c_str());
+}
+
+/* ------------------------------------------------- binary matrix cache ---- */
+// parsing nlpkkt120's 1.5 GB of text dominates wall-clock.  A .csr.bin image
+// holds exactly what the loader produces (same array contents, same in-row order), so loading
+// it is interchangeable with parsing the .mtx.  With NSPARSE_BIN_CACHE=1 the loader itself
+// reads `<file>.csr.bin` when it exists and is not older than the .mtx, and writes it otherwise.
+
+namespace {
+struct BinHeader {
+    char magic[8];       // "NSPCSR01"
+    int real_bytes;      // sizeof(real) of the writer
+    int M, N, nnz, nnz_max;
+    int reserved[3];
+};
+}  // namespace
+
+int nsparse_save_csr_bin(const sfCSR *mat, const char *path)
+{
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return -1;
+    BinHeader h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "NSPCSR01", 8);
+    h.real_bytes = (int)sizeof(real);
+    h.M = mat->M; h.N = mat->N; h.nnz = mat->nnz; h.nnz_max = mat->nnz_max;
+    bool ok = fwrite(&h, sizeof h, 1, fp) == 1;
+    ok = ok && fwrite(mat->rpt, sizeof(int), (size_t)mat->M + 1, fp) == (size_t)mat->M + 1;
+    ok = ok && fwrite(mat->col, sizeof(int), (size_t)mat->nnz, fp) == (size_t)mat->nnz;
+    ok = ok && fwrite(mat->val, sizeof(real), (size_t)mat->nnz, fp) == (size_t)mat->nnz;
+    fclose(fp);
+    return ok ? 0 : -2;
+}
+
+int nsparse_load_csr_bin(sfCSR *mat, const char *path)
+{
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return -1;
+    BinHeader h;
+    if (fread(&h, sizeof h, 1, fp) != 1 || memcmp(h.magic, "NSPCSR01", 8) != 0 ||
+        h.real_bytes != (int)sizeof(real) || h.M < 0 || h.nnz < 0) {
+        fclose(fp);
+        return -2;  // not ours / written by the other precision build
+    }
+    int *rpt = (int *)malloc(sizeof(int) * ((size_t)h.M + 1));
+    int *col = (int *)malloc(sizeof(int) * (size_t)(h.nnz > 0 ? h.nnz : 1));
+    real *val = (real *)malloc(sizeof(real) * (size_t)(h.nnz > 0 ? h.nnz : 1));
+    bool ok = fread(rpt, sizeof(int), (size_t)h.M + 1, fp) == (size_t)h.M + 1;
+    ok = ok && fread(col, sizeof(int), (size_t)h.nnz, fp) == (size_t)h.nnz;
+    ok = ok && fread(val, sizeof(real), (size_t)h.nnz, fp) == (size_t)h.nnz;
+    fclose(fp);
+    if (!ok || rpt[h.M] != h.nnz) {
+        free(rpt); free(col); free(val);
+        return -3;
+    }
+    mat->rpt = rpt; mat->col = col; mat->val = val;
+    mat->M = h.M; mat->N = h.N; mat->nnz = h.nnz; mat->nnz_max = h.nnz_max;
+    mat->d_rpt = nullptr; mat->d_col = nullptr; mat->d_val = nullptr;
+    return 0;
 }
 
 /* ------------------------------------------------------------------ plan --- */

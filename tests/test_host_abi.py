@@ -202,3 +202,33 @@ def test_synth_generators(lib_d, kind, p, expect_m):
         assert np.array_equal(B["val"], A["val"][A["rpt"][lo]:A["rpt"][hi]])
         lib_d.release_cpu_csr(b)
     lib_d.release_cpu_csr(m)
+
+
+def test_binary_matrix_cache(tmp_path, lib_d, lib_s):
+    """.csr.bin image == what the text loader produces; wrong-precision images are rejected;
+    NSPARSE_BIN_CACHE=1 makes the loader write and then reuse the image."""
+    import subprocess, sys
+    path = _write(tmp_path, "sym.mtx", CASES["symmetric.mtx"])
+    m = ns.sfCSR()
+    lib_d.init_csr_matrix_from_file(C.byref(m), path)
+    A = lib_d.csr_host_to_numpy(m)
+    img = str(tmp_path / "a.bin").encode()
+    assert lib_d.nsparse_save_csr_bin(C.byref(m), img) == 0
+    lib_d.release_cpu_csr(m)
+    b = ns.sfCSR()
+    assert lib_d.nsparse_load_csr_bin(C.byref(b), img) == 0
+    B = lib_d.csr_host_to_numpy(b)
+    lib_d.release_cpu_csr(b)
+    for k in ("M", "N", "nnz", "nnz_max"):
+        assert A[k] == B[k]
+    assert all(np.array_equal(A[k], B[k]) for k in ("rpt", "col", "val"))
+    s = ns.sfCSR()
+    assert lib_s.nsparse_load_csr_bin(C.byref(s), img) == -2
+    assert lib_d.nsparse_load_csr_bin(C.byref(s), b"/nonexistent.bin") == -1
+    code = ("import ctypes as C, nsparse_amd as ns; L = ns.load('d'); m = ns.sfCSR();"
+            "L.init_csr_matrix_from_file(C.byref(m), %r); print(m.M, m.nnz, m.nnz_max)" % path)
+    env = dict(os.environ, NSPARSE_BIN_CACHE="1")
+    r1 = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=env)
+    assert r1.returncode == 0 and os.path.exists(path.decode() + ".csr.bin")
+    r2 = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=env)
+    assert r2.stdout.splitlines()[-1] == r1.stdout.splitlines()[-1] == f"{A['M']} {A['nnz']} {A['nnz_max']}"
