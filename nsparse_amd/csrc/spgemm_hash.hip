@@ -96,7 +96,7 @@ constexpr int kNumGlobalBin = 5;
 constexpr int kDenseBin0 = 6;
 constexpr int kBitsBin0 = 9;
 constexpr int kSetupMaxGrid = 16384;
-constexpr int kPartialStride = 16;  // long longs per block: hist[NB], max, total
+constexpr int kPartialStride = 16;  // long longs per block: hist[NB], max, total, bm, alen
 constexpr int kSymLargeT = 32768;
 constexpr int kSymLargeLimit = 24576;
 static int g_dense_enabled = -1;  // -1: read NSPARSE_DENSE on first use
@@ -112,6 +112,9 @@ struct BinState {
     int nnz;
     long long total;
     long long bm_total;  // words of column bitmaps (dense window rows)
+    long long max_alen;  // longest row of A
+    int b_unsorted;      // some row of B does not have strictly ascending columns
+    int pad;
 };
 
 struct Stats {
@@ -375,17 +378,21 @@ struct __attribute__((aligned(16))) BInfo {
 };
 
 __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, const int *__restrict__ bcol,
-                                                int K, BInfo *__restrict__ info)
+                                                int K, BInfo *__restrict__ info, BinState *bs)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
     if (r >= K) return;
     const int b = brpt[r], e = brpt[r + 1];
-    int lo = 0x7fffffff, hi = -1;
+    int lo = 0x7fffffff, hi = -1, prev = -1;
+    bool bad = false;
     for (int k = b; k < e; k++) {
         const int c = bcol[k];
+        bad |= c <= prev;
+        prev = c;
         lo = c < lo ? c : lo;
         hi = c > hi ? c : hi;
     }
+    if (bad) atomicOr(&bs->b_unsorted, 1);
     BInfo o;
     o.start = b;
     o.len = e - b;
@@ -408,8 +415,9 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
     __shared__ int s_max;
     __shared__ unsigned long long s_total;
     __shared__ unsigned long long s_bm;
+    __shared__ int s_alen;
     if (threadIdx.x < NB) s_hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_max = 0; s_total = 0; s_bm = 0; }
+    if (threadIdx.x == 0) { s_max = 0; s_total = 0; s_bm = 0; s_alen = 0; }
     __syncthreads();
     const int lane = threadIdx.x % W;
     constexpr int RPB = 256 / W;
@@ -448,6 +456,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             if (bw) atomicAdd(&s_bm, (unsigned long long)bw);
             atomicAdd(&s_hist[bin_of(ni, span, thr)], 1);
             atomicMax(&s_max, ni);
+            atomicMax(&s_alen, arpt[row + 1] - arpt[row]);
             atomicAdd(&s_total, (unsigned long long)n);
         }
     }
@@ -461,6 +470,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
         out[NB] = s_max;
         out[NB + 1] = (long long)s_total;
         out[NB + 2] = (long long)s_bm;
+        out[NB + 3] = s_alen;
     }
 }
 
@@ -469,21 +479,23 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const long long *__rest
 {
     __shared__ unsigned long long s_acc[kPartialStride];
     __shared__ int s_max;
+    __shared__ int s_alen;
     if (threadIdx.x < kPartialStride) s_acc[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_max = 0;
+    if (threadIdx.x == 0) { s_max = 0; s_alen = 0; }
     __syncthreads();
     // a few dozen workgroups, each folds a slice of the partials and issues one global atomic
     // per field: thread t handles field (t % 16) of partials t/16, t/16 + 16, ... of its slice
     const int per = (nblocks + gridDim.x - 1) / gridDim.x;
     const int b0 = blockIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
     const int f = threadIdx.x & 15;
-    if (f < NB + 3) {
+    if (f < NB + 4) {
         long long acc = 0;
         for (int b = b0 + (threadIdx.x >> 4); b < b1; b += 16) {
             const long long v = partial[(long long)b * kPartialStride + f];
-            acc = f == NB ? (v > acc ? v : acc) : acc + v;
+            acc = (f == NB || f == NB + 3) ? (v > acc ? v : acc) : acc + v;
         }
         if (f == NB) atomicMax(&s_max, (int)acc);
+        else if (f == NB + 3) atomicMax(&s_alen, (int)acc);
         else if (acc) atomicAdd(&s_acc[f], (unsigned long long)acc);
     }
     __syncthreads();
@@ -492,6 +504,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const long long *__rest
         if (s_max) atomicMax(&bs->maxv, s_max);
         if (s_acc[NB + 1]) atomicAdd((unsigned long long *)&bs->total, s_acc[NB + 1]);
         if (s_acc[NB + 2]) atomicAdd((unsigned long long *)&bs->bm_total, s_acc[NB + 2]);
+        if (s_alen) atomicMax((unsigned long long *)&bs->max_alen, (unsigned long long)s_alen);
     }
 }
 
@@ -1193,6 +1206,165 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
 }
 
 // ===================================================================================
+//  heavy numeric rows: column-tiled dense windows
+// ===================================================================================
+// Rows with more than 5461 non-zeros do not fit an LDS hash table, and on power-law inputs
+// they carry most of the products (R-MAT-18: 59 K such rows, 2.7 G products).  Hashing them in
+// global memory means two random HBM round trips per product.  Instead the row's column window
+// is cut into tiles of W columns that DO fit LDS as a dense array.  Rows of B are sorted, so
+// the part of B row k that falls into a tile is contiguous: every A entry keeps a cursor
+// (position, end, next column, a value) in a per-workgroup global scratch slice, and for each
+// tile every lane advances the cursors of its entries while the column stays inside the tile,
+// accumulating into LDS.  The tile is then emitted in ascending order (byte flags + ballot /
+// popcount), so the row leaves sorted without a sort.  One pass over the products, no global
+// atomics.  Persistent workgroups pull rows from a queue.  Needs sorted rows of B (checked by
+// the caller through the B-info pass: unsorted B falls back to the global hash table).
+template <int BS, int W>
+__global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                  const real *__restrict__ aval,
+                                                  const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                  const real *__restrict__ bval,
+                                                  const int *__restrict__ crpt, int *__restrict__ ccol,
+                                                  real *__restrict__ cval,
+                                                  const int *__restrict__ row_perm, int bin_off, int count,
+                                                  BinState *bs, const int *__restrict__ row_lo,
+                                                  const int *__restrict__ row_span, int *__restrict__ slab,
+                                                  long long stride_ints, int amax, int write_col,
+                                                  int LONG_LEN)
+{
+    constexpr int NW = BS / 64;
+    constexpr int LCAP = 1024;      // long B rows tracked per C row (the rest stay lane-serial)
+    // LONG_LEN: a B row longer than this is swept by a whole wavefront
+    __shared__ __attribute__((aligned(16))) real dense[W];
+    __shared__ __attribute__((aligned(16))) unsigned int flag4[W / 4];
+    __shared__ int l_cur[LCAP];
+    __shared__ int l_end[LCAP];
+    __shared__ real l_av[LCAP];
+    __shared__ int s_row;
+    __shared__ int s_nlong;
+    __shared__ int s_wcnt[NW];
+    unsigned char *flag = reinterpret_cast<unsigned char *>(flag4);
+    int *st_cur = slab + (long long)blockIdx.x * stride_ints;
+    int *st_end = st_cur + amax;
+    int *st_next = st_end + amax;
+    real *st_av = reinterpret_cast<real *>(st_next + amax);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_row = atomicAdd(&bs->queue_head, 1);
+            s_nlong = 0;
+        }
+        __syncthreads();
+        const int q = s_row;
+        if (q >= count) break;
+        const int rid = row_perm[bin_off + q];
+        const int lo = row_lo[rid], span = row_span[rid];
+        const int a_beg = arpt[rid], alen = arpt[rid + 1] - a_beg;
+        // cursors: entry e is always handled by thread e % BS, so its state needs no
+        // cross-thread visibility.  Long B rows go to the LDS list instead.
+        for (int e = threadIdx.x; e < alen; e += BS) {
+            const int c = acol[a_beg + e];
+            const int cur = brpt[c], end = brpt[c + 1];
+            const real av = aval[a_beg + e];
+            int li = -1;
+            if (end - cur > LONG_LEN) {
+                li = atomicAdd(&s_nlong, 1);
+                if (li < LCAP) {
+                    l_cur[li] = cur;
+                    l_end[li] = end;
+                    l_av[li] = av;
+                }
+            }
+            const bool serial = li < 0 || li >= LCAP;
+            st_cur[e] = cur;
+            st_end[e] = end;
+            st_next[e] = (serial && cur < end) ? bcol[cur] : 0x7fffffff;
+            st_av[e] = av;
+        }
+        __syncthreads();
+        const int nlong = s_nlong < LCAP ? s_nlong : LCAP;
+        int pos = crpt[rid];
+        for (int t0 = 0; t0 < span; t0 += W) {
+            const int tw = span - t0 < W ? span - t0 : W;  // columns in this tile
+            const int c0 = lo + t0, c1 = c0 + tw;
+            for (int i = threadIdx.x; i < tw; i += BS) dense[i] = 0;
+            for (int i = threadIdx.x; i < (tw + 3) / 4; i += BS) flag4[i] = 0;
+            __syncthreads();
+            // long B rows: one wavefront per row, 64 consecutive (sorted) entries per step; the
+            // entries inside the tile are a prefix of the 64
+            for (int i = w; i < nlong; i += NW) {
+                int cur = l_cur[i];
+                const int end = l_end[i];
+                const real av = l_av[i];
+                while (true) {
+                    const int k = cur + lane;
+                    const int col = k < end ? bcol[k] : 0x7fffffff;
+                    const bool in = col < c1;
+                    const int n = __popcll(__ballot(in));
+                    if (in) {
+                        const int idx = col - c0;
+                        flag[idx] = 1;
+                        unsafeAtomicAdd(dense + idx, av * bval[k]);
+                    }
+                    cur += n;
+                    if (n < 64) break;
+                }
+                if (lane == 0) l_cur[i] = cur;
+            }
+            // everything else: every lane advances the cursors of its own entries
+            for (int e = threadIdx.x; e < alen; e += BS) {
+                int col = st_next[e];
+                if (col < c1) {
+                    int cur = st_cur[e];
+                    const int end = st_end[e];
+                    const real av = st_av[e];
+                    do {
+                        const int idx = col - c0;
+                        flag[idx] = 1;
+                        unsafeAtomicAdd(dense + idx, av * bval[cur]);
+                        cur++;
+                        col = cur < end ? bcol[cur] : 0x7fffffff;
+                    } while (col < c1);
+                    st_cur[e] = cur;
+                    st_next[e] = col;
+                }
+            }
+            __syncthreads();
+            // ordered emission of the tile: wave w owns [w*R, (w+1)*R)
+            const int R = ((tw + NW * 64 - 1) / (NW * 64)) * 64;
+            const int rb = w * R, re = rb + R < tw ? rb + R : tw;
+            int cnt = 0;
+            for (int base = rb; base < re; base += 64) {
+                const int idx = base + lane;
+                cnt += __popcll(__ballot(idx < re && flag[idx] != 0));
+            }
+            if (lane == 0) s_wcnt[w] = cnt;
+            __syncthreads();
+            int wpos = pos, total = 0;
+            for (int u = 0; u < NW; u++) {
+                const int c = s_wcnt[u];
+                if (u < w) wpos += c;
+                total += c;
+            }
+            for (int base = rb; base < re; base += 64) {
+                const int idx = base + lane;
+                const bool occ = idx < re && flag[idx] != 0;
+                const unsigned long long m = __ballot(occ);
+                if (occ) {
+                    const int p = wpos + __popcll(m & ((1ull << lane) - 1ull));
+                    if (write_col & 1) ccol[p] = c0 + idx;
+                    cval[p] = dense[idx];
+                }
+                wpos += __popcll(m);
+            }
+            pos += total;
+            __syncthreads();
+        }
+    }
+}
+
+// ===================================================================================
 //  host orchestration
 // ===================================================================================
 
@@ -1404,7 +1576,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                                  const int *row_lo, const int *row_span, const int *row_perm,
                                  const int *hist, int max_nz, BinState *d_bs, Context &cx,
                                  float *ms_bin, int write_col, const int *bm_off,
-                                 const unsigned int *bm)
+                                 const unsigned int *bm, int max_alen, bool b_sorted)
 {
     BinLauncher L(cx, 1);
     int off[NB + 1];
@@ -1413,7 +1585,34 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     const int *arpt = a->d_rpt, *acol = a->d_col, *brpt = b->d_rpt, *bcol = b->d_col;
     const real *aval = a->d_val, *bval = b->d_val;
     L.fork();
-    if (hist[kNumGlobalBin] > 0) {
+    constexpr int kTileW = sizeof(real) == 8 ? 12288 : 24576;
+    static const int tiled_on = !(getenv("NSPARSE_TILED") && getenv("NSPARSE_TILED")[0] == '0');
+    static const int long_len = getenv("NSPARSE_TILED_LONG") ? atoi(getenv("NSPARSE_TILED_LONG")) : 128;
+    static const int tile_sel = getenv("NSPARSE_TILED_W") ? atoi(getenv("NSPARSE_TILED_W")) : 0;
+    // tiles per row <= 1024 keeps the fixed per-tile cost bounded; wider matrices hash globally
+    const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
+                           (long long)b->N <= (long long)kTileW * 1024;
+    if (use_tiled) {
+        hipStream_t st = L.begin(kNumGlobalBin);
+        const int rows = hist[kNumGlobalBin];
+        const int amax = (max_alen + 1) & ~1;  // even: the value slice stays 8-byte aligned
+        const long long stride_ints = 3LL * amax + (long long)amax * (sizeof(real) / sizeof(int));
+        const int groups = rows < 1024 ? rows : 1024;
+        int *slab = (int *)dev_alloc(sizeof(int) * (size_t)stride_ints * groups);
+#define NSP_TILED(BSX, WX)                                                                     \
+    hipLaunchKernelGGL((k_num_tiled<BSX, WX>), dim3(groups), dim3(BSX), 0, st, arpt, acol, aval, brpt, \
+                       bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows,   \
+                       d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len)
+        if (tile_sel == 1) { NSP_TILED(1024, kTileW / 2); }
+        else if (tile_sel == 2) { NSP_TILED(512, kTileW / 2); }
+        else if (tile_sel == 3) { NSP_TILED(512, kTileW / 4); }
+        else { NSP_TILED(1024, kTileW); }
+#undef NSP_TILED
+        NSP_LAUNCH_CHECK();
+        NSP_CHECK(hipStreamSynchronize(st));
+        L.end(kNumGlobalBin);
+        dev_free(slab);
+    } else if (hist[kNumGlobalBin] > 0) {
         hipStream_t st = L.begin(kNumGlobalBin);
         const int rows = hist[kNumGlobalBin];
         long long slice = 64;
@@ -1517,6 +1716,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     BinState *h_sym = reinterpret_cast<BinState *>(cx.h_pinned);
     BinState *h_num = h_sym + 1;
     static_assert(2 * sizeof(BinState) <= 128 * sizeof(int), "scratch layout");
+    const int b_unsorted_seen = 0; (void)b_unsorted_seen;
 
     void *scan_tmp = nullptr;
     unsigned int *bm = nullptr;
@@ -1538,7 +1738,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     NSP_CHECK(hipMemsetAsync(d_sym, 0, 2 * sizeof(BinState), s0));
 
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
-    hipLaunchKernelGGL(k_b_info, dim3(ceil_div(K, 256)), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo);
+    hipLaunchKernelGGL(k_b_info, dim3(ceil_div(K, 256)), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym);
     long long *partial = (long long *)dev_alloc(sizeof(long long) * kPartialStride * kSetupMaxGrid);
     // column bitmaps handed from the symbolic to the numeric dense kernels
     int *bm_words = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
@@ -1610,7 +1810,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     // ---- numeric --------------------------------------------------------------------
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
-                                   numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm);
+                                   numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
+                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0);
     tm.mark(3, s0);
     NSP_CHECK(hipStreamSynchronize(s0));  // synchronous on return, like upstream (:1287)
     LN.collect(S.ms_num_bin);

@@ -136,6 +136,29 @@ def test_every_bin_is_exercised(lib_d, oracle_d):
     assert st.sym_bin_size[5] + st.sym_bin_size[9] + st.sym_bin_size[10] >= 1, "no big symbolic row"
     assert st.num_bin_size[5] >= 1, "no row reached the global numeric bin"
     assert sum(1 for b in list(st.num_bin_size)[:9] if b > 0) >= 4
+    # same rows through the global-memory hash table instead of the column-tiled LDS windows
+    got_g, st_g = spgemm_subprocess(A, {"NSPARSE_TILED": "0"})
+    assert st_g["num"][5] >= 1
+    assert_parity(oracle_d, got_g, ref)
+
+
+def test_unsorted_rows_of_b(lib_d, oracle_d):
+    """Rows of B in arbitrary column order (legal CSR; the loader does not sort): windows come from
+    min/max, the product walk does not care, the tiled kernel (needs sorted B) must step aside."""
+    rng = np.random.default_rng(13)
+    n = 30000
+    hub = np.sort(rng.choice(n, 2500, replace=False))
+    A = _force_rows(n, n, 10, rng, extra={3: hub})
+    B = dict(A, col=A["col"].copy(), val=A["val"].copy())
+    for i in range(n):
+        b, e = B["rpt"][i], B["rpt"][i + 1]
+        p = rng.permutation(e - b)
+        B["col"][b:e], B["val"][b:e] = B["col"][b:e][p], B["val"][b:e][p]
+    ref = oracle_d.spgemm(A, B)
+    assert ref["row_nz"][3] > 5461
+    got, st = spgemm(lib_d, A, B)
+    assert st.num_bin_size[5] >= 1
+    assert_parity(oracle_d, got, ref)
 
 
 def test_symbolic_overflow_falls_back_to_global_table(lib_d, oracle_d):
