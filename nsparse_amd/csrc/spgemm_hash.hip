@@ -269,8 +269,9 @@ __device__ __forceinline__ int fetch_chunk(const int *__restrict__ bcol, const r
     n = n < 0 ? 0 : (n > VW ? VW : n);
     if (n > 0) {
         if (i0 + VW <= bnnz) {
-            k = *reinterpret_cast<const IVec *>(bcol + i0);
-            if (WITH_VAL) v = *reinterpret_cast<const RVec *>(bval + i0);
+            // unsigned index: zero-extension is free, so the loads use base + 32-bit offset
+            k = *reinterpret_cast<const IVec *>(bcol + (unsigned)i0);
+            if (WITH_VAL) v = *reinterpret_cast<const RVec *>(bval + (unsigned)i0);
         } else {
 #pragma unroll
             for (int i = 0; i < VW; i++) {
@@ -1165,7 +1166,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
                                 for (int i = 0; i < VW; i++)
                                     if (i < n) {
                                         const int idx = k.v[i] - lo;
-                                        unsafeAtomicAdd(dense + (idx & 3) * Q + (idx >> 2), sc * v.v[i]);
+                                        unsafeAtomicAdd(dense + __mul24(idx & 3, Q) + (idx >> 2), sc * v.v[i]);
                                     }
                             });
     __syncthreads();
@@ -1173,7 +1174,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
         const int n = crpt[rid + 1] - off;
         for (int p = threadIdx.x; p < n; p += BS) {
             const int idx = ccol[off + p] - lo;
-            cval[off + p] = dense[(idx & 3) * Q + (idx >> 2)];
+            cval[off + p] = dense[__mul24(idx & 3, Q) + (idx >> 2)];
         }
         return;
     }
@@ -1199,7 +1200,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
         if (occ) {
             const int p = pos + __popcll(m & ((1ull << lane) - 1ull));
             ccol[p] = lo + idx;
-            cval[p] = dense[(idx & 3) * Q + (idx >> 2)];
+            cval[p] = dense[__mul24(idx & 3, Q) + (idx >> 2)];
         }
         pos += __popcll(m);
     }
