@@ -4,6 +4,8 @@
 // Replaces (reference file:line):
 //   csr_memcpy / csr_memcpyDtH     cuda-c/src/nsparse.cu:146-168
 //   release_csr / release_amb      cuda-c/src/nsparse.cu:209-235
+#include <chrono>
+#include <cstring>
 #include <map>
 #include <unordered_map>
 
@@ -90,6 +92,22 @@ void dev_cache_trim()
     c.idle_bytes = 0;
 }
 
+void wait_published(int slot, int seq, hipStream_t st)
+{
+    Context &c = ctx();
+    volatile int *p = c.h_mapped + slot;
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (__atomic_load_n(p, __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xffff) == 0 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) {
+            NSP_CHECK(hipStreamSynchronize(st));  // surfaces a device error, if any
+            if (__atomic_load_n(p, __ATOMIC_ACQUIRE) != seq) set_error(-30, "publish flag never arrived", __FILE__, __LINE__);
+            return;
+        }
+    }
+}
+
 Context &ctx()
 {
     static Context c;
@@ -103,6 +121,9 @@ Context &ctx()
         for (auto &e : c.ev_bin) NSP_CHECK(hipEventCreate(&e));
         NSP_CHECK(hipHostMalloc((void **)&c.h_pinned, 512 * sizeof(int), hipHostMallocDefault));
         NSP_CHECK(hipMalloc((void **)&c.d_scratch, 512 * sizeof(int)));
+        NSP_CHECK(hipHostMalloc((void **)&c.h_mapped, 256 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(c.h_mapped, 0, 256 * sizeof(int));
+        NSP_CHECK(hipHostGetDevicePointer((void **)&c.d_mapped, c.h_mapped, 0));
         c.ready = true;
     }
     return c;

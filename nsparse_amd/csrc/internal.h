@@ -47,10 +47,17 @@ struct Context {
     hipEvent_t ev_bin[4 * kMaxBins] = {};  // per-bin begin/end: [0,2B) symbolic, [2B,4B) numeric
     int *h_pinned = nullptr;            // 512 ints of pinned host memory for small D2H
     int *d_scratch = nullptr;           // 512 ints of device scratch (counters)
+    int *h_mapped = nullptr;            // 256 ints of mapped, coherent host memory (GPU writes, host polls)
+    int *d_mapped = nullptr;            // device address of h_mapped
+    int seq = 0;                        // publish sequence number
     bool profiling = false;
     bool ready = false;
 };
 Context &ctx();
+
+// Block until the GPU has stored `seq` at h_mapped[slot] (see k_publish); falls back to a stream
+// synchronisation after a generous timeout.
+void wait_published(int slot, int seq, hipStream_t st);
 
 inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -410,8 +410,14 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
                                                       int *__restrict__ row_lo,
                                                       int *__restrict__ row_span,
                                                       int *__restrict__ bm_words, int bm_span_max,
-                                                      Thr thr, long long *__restrict__ partial)
+                                                      Thr thr, long long *__restrict__ partial,
+                                                      int *__restrict__ row_span_num,
+                                                      int *__restrict__ row_nz)
 {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // scan tails (instead of two memset launches)
+        bm_words[M] = 0;
+        row_nz[M] = 0;
+    }
     __shared__ int s_hist[NB];
     __shared__ int s_max;
     __shared__ unsigned long long s_total;
@@ -454,6 +460,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             // words of the column bitmap the symbolic dense kernel hands to the numeric one
             const int bw = (span > 0 && span <= bm_span_max) ? (span + 31) >> 5 : 0;
             bm_words[row] = bw;
+            row_span_num[row] = 0;  // set by k_sym_dense when it hands a bitmap over
             if (bw) atomicAdd(&s_bm, (unsigned long long)bw);
             atomicAdd(&s_hist[bin_of(ni, span, thr)], 1);
             atomicMax(&s_max, ni);
@@ -507,6 +514,19 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const long long *__rest
         if (s_acc[NB + 2]) atomicAdd((unsigned long long *)&bs->bm_total, s_acc[NB + 2]);
         if (s_alen) atomicMax((unsigned long long *)&bs->max_alen, (unsigned long long)s_alen);
     }
+}
+
+// Copy a counter block to mapped host memory and raise a sequence flag: the host polls the
+// flag instead of paying hipMemcpyAsync + hipStreamSynchronize (~40 us per round trip here).
+__global__ __launch_bounds__(64) void k_publish(const BinState *__restrict__ src, int *dst, int words,
+                                                const int *__restrict__ nnz_src, int *flag, int seq)
+{
+    const int *s = reinterpret_cast<const int *>(src);
+    for (int i = threadIdx.x; i < words; i += 64) dst[i] = s[i];
+    if (nnz_src && threadIdx.x == 0) reinterpret_cast<BinState *>(dst)->nnz = *nnz_src;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // histogram of an existing per-row count (numeric binning, set_min_bin :201-246)
@@ -1391,7 +1411,7 @@ static inline int pick_w(long long nnz, int M)
 static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *binfo,
                                 int *row_prod, int *row_lo, int *row_span, int *bm_words,
                                 int bm_span_max, const Thr &thr, BinState *d_bs, long long *partial,
-                                hipStream_t st)
+                                int *row_span_num, int *row_nz, hipStream_t st)
 {
     const int M = a->M;
     const int w = pick_w(a->nnz, M);
@@ -1401,7 +1421,7 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *bin
     case W:                                                                                    \
         hipLaunchKernelGGL(k_row_products<W>, dim3(grid), dim3(256), 0, st, a->d_rpt, a->d_col, \
                            binfo, M, row_prod, row_lo, row_span, bm_words, bm_span_max, thr,   \
-                           partial);                                                           \
+                           partial, row_span_num, row_nz);                                     \
         break;
     switch (w) {
         NSP_RP(1) NSP_RP(2) NSP_RP(4) NSP_RP(8) NSP_RP(16) NSP_RP(32) NSP_RP(64)
@@ -1429,8 +1449,18 @@ struct BinLauncher {
     Context *cx;
     hipEvent_t *ev;  // 2 * NB events: begin/end of every bin
     bool used[NB] = {};
-    bool serial;  // profiling mode: one stream, bins back to back
-    BinLauncher(Context &c, int phase) : cx(&c), ev(c.ev_bin + phase * 2 * NB), serial(c.profiling) {}
+    bool serial;     // profiling mode: one stream, bins back to back
+    int main_bin;    // the bin with the most rows runs on the main stream itself (no fork/join)
+    BinLauncher(Context &c, int phase, const int *hist = nullptr)
+        : cx(&c), ev(c.ev_bin + phase * 2 * NB), serial(c.profiling), main_bin(-1)
+    {
+        if (hist) {
+            int best = 0;
+            for (int b = 0; b < NB; b++)
+                if (hist[b] > best) { best = hist[b]; main_bin = b; }
+        }
+    }
+    hipStream_t stream_of(int b) const { return (serial || b == main_bin) ? cx->stream[0] : cx->stream[b]; }
     void fork()
     {
         if (!serial) NSP_CHECK(hipEventRecord(cx->ev_fork, cx->stream[0]));
@@ -1439,18 +1469,17 @@ struct BinLauncher {
     // difference is the duration of those kernels whether or not other bins overlap.
     hipStream_t begin(int b)
     {
-        hipStream_t st = serial ? cx->stream[0] : cx->stream[b];
-        if (!serial && b != 0 && !used[b]) NSP_CHECK(hipStreamWaitEvent(st, cx->ev_fork, 0));
+        hipStream_t st = stream_of(b);
+        if (st != cx->stream[0] && !used[b]) NSP_CHECK(hipStreamWaitEvent(st, cx->ev_fork, 0));
         used[b] = true;
         NSP_CHECK(hipEventRecord(ev[2 * b], st));
         return st;
     }
-    void end(int b) { NSP_CHECK(hipEventRecord(ev[2 * b + 1], serial ? cx->stream[0] : cx->stream[b])); }
+    void end(int b) { NSP_CHECK(hipEventRecord(ev[2 * b + 1], stream_of(b))); }
     void join()
     {
-        if (serial) return;
-        for (int b = 1; b < NB; b++) {
-            if (!used[b]) continue;
+        for (int b = 0; b < NB; b++) {
+            if (!used[b] || stream_of(b) == cx->stream[0]) continue;
             NSP_CHECK(hipEventRecord(cx->ev_join[b], cx->stream[b]));
             NSP_CHECK(hipStreamWaitEvent(cx->stream[0], cx->ev_join[b], 0));
         }
@@ -1483,7 +1512,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
                                   int *fail_rows, const int *bm_off, unsigned int *bm,
                                   int *row_span_num)
 {
-    BinLauncher L(cx, 0);
+    BinLauncher L(cx, 0, hist);
     int off[NB + 1];
     off[0] = 0;
     for (int q = 0; q < NB; q++) off[q + 1] = off[q] + hist[q];
@@ -1579,7 +1608,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                                  float *ms_bin, int write_col, const int *bm_off,
                                  const unsigned int *bm, int max_alen, bool b_sorted)
 {
-    BinLauncher L(cx, 1);
+    BinLauncher L(cx, 1, hist);
     int off[NB + 1];
     off[0] = 0;
     for (int q = 0; q < NB; q++) off[q + 1] = off[q] + hist[q];
@@ -1714,10 +1743,10 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
 
     BinState *d_sym = reinterpret_cast<BinState *>(cx.d_scratch);
     BinState *d_num = d_sym + 1;
-    BinState *h_sym = reinterpret_cast<BinState *>(cx.h_pinned);
+    BinState *h_sym = reinterpret_cast<BinState *>(cx.h_mapped);
     BinState *h_num = h_sym + 1;
-    static_assert(2 * sizeof(BinState) <= 128 * sizeof(int), "scratch layout");
-    const int b_unsorted_seen = 0; (void)b_unsorted_seen;
+    BinState *h_num_dev = reinterpret_cast<BinState *>(cx.d_mapped) + 1;
+    static_assert(2 * sizeof(BinState) <= 120 * sizeof(int), "scratch layout");
 
     void *scan_tmp = nullptr;
     unsigned int *bm = nullptr;
@@ -1747,20 +1776,21 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     int *row_span_num = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
     launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
-                        use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, s0);
+                        use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, row_span_num, row_nz, s0);
     void *bm_scan_tmp = nullptr;
-    if (use_bm) {
-        NSP_CHECK(hipMemsetAsync(bm_words + M, 0, sizeof(int), s0));
-        NSP_CHECK(hipMemsetAsync(row_span_num, 0, sizeof(int) * (size_t)(M > 0 ? M : 1), s0));
-        bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
-    }
+    if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
     const int grid_m = ceil_div(M, 256);
     if (!numeric_only) {
         hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_prod, row_span, M, sym_thr, d_sym, row_perm);
         NSP_LAUNCH_CHECK();
     }
-    NSP_CHECK(hipMemcpyAsync(h_sym, d_sym, sizeof(BinState), hipMemcpyDeviceToHost, s0));
-    NSP_CHECK(hipStreamSynchronize(s0));
+    {
+        const int seq = ++cx.seq;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s0, d_sym, cx.d_mapped, (int)(sizeof(BinState) / 4),
+                           (const int *)nullptr, cx.d_mapped + 120, seq);
+        NSP_LAUNCH_CHECK();
+        wait_published(120, seq, s0);
+    }
     S.n_prod = h_sym->total;
     S.max_prod_row = h_sym->maxv;
     for (int q = 0; q < NB; q++) S.sym_bin_size[q] = h_sym->hist[q];
@@ -1779,7 +1809,6 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
                                         bm_off, bm, row_span_num);
         sym_used = LS;
         c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
-        NSP_CHECK(hipMemsetAsync(row_nz + M, 0, sizeof(int), s0));
         scan_tmp = scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
     } else {
         // structure given: row_nz[i] = rpt[i+1] - rpt[i] is recovered inside the kernels
@@ -1796,9 +1825,13 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(256), 0, s0, row_nz, num_span, M, num_thr, d_num);
     hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_nz, num_span, M, num_thr, d_num, row_perm);
     NSP_LAUNCH_CHECK();
-    NSP_CHECK(hipMemcpyAsync(&d_num->nnz, c->d_rpt + M, sizeof(int), hipMemcpyDeviceToDevice, s0));
-    NSP_CHECK(hipMemcpyAsync(h_num, d_num, sizeof(BinState), hipMemcpyDeviceToHost, s0));
-    NSP_CHECK(hipStreamSynchronize(s0));
+    {
+        const int seq = ++cx.seq;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s0, d_num, reinterpret_cast<int *>(h_num_dev),
+                           (int)(sizeof(BinState) / 4), c->d_rpt + M, cx.d_mapped + 121, seq);
+        NSP_LAUNCH_CHECK();
+        wait_published(121, seq, s0);
+    }
     for (int q = 0; q < NB; q++) S.num_bin_size[q] = h_num->hist[q];
     S.max_nnz_row = h_num->maxv;
     if (!numeric_only) {
@@ -1814,7 +1847,13 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
                                    (int)h_sym->max_alen, h_sym->b_unsorted == 0);
     tm.mark(3, s0);
-    NSP_CHECK(hipStreamSynchronize(s0));  // synchronous on return, like upstream (:1287)
+    {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
+        const int seq = ++cx.seq;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s0, d_num, cx.d_mapped + 128, 0, (const int *)nullptr,
+                           cx.d_mapped + 122, seq);
+        NSP_LAUNCH_CHECK();
+        wait_published(122, seq, s0);
+    }
     LN.collect(S.ms_num_bin);
     sym_used.collect(S.ms_sym_bin);
     S.ms_setup = tm.ms(0, 1);
