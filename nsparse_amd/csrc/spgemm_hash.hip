@@ -378,28 +378,41 @@ struct __attribute__((aligned(16))) BInfo {
     int start, len, lo, hi;
 };
 
+template <int W>
 __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                 int K, BInfo *__restrict__ info, BinState *bs)
 {
-    const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= K) return;
-    const int b = brpt[r], e = brpt[r + 1];
-    int lo = 0x7fffffff, hi = -1, prev = -1;
+    // W lanes per row of B (W from the average row length, so the column loads coalesce)
+    const int r = (blockIdx.x * 256 + threadIdx.x) / W;
+    const int lane = threadIdx.x % W;
+    int lo = 0x7fffffff, hi = -1;
     bool bad = false;
-    for (int k = b; k < e; k++) {
-        const int c = bcol[k];
-        bad |= c <= prev;
-        prev = c;
-        lo = c < lo ? c : lo;
-        hi = c > hi ? c : hi;
+    int b = 0, e = 0;
+    if (r < K) {
+        b = brpt[r];
+        e = brpt[r + 1];
+        for (int k = b + lane; k < e; k += W) {
+            const int c = bcol[k];
+            if (k > b) bad |= c <= bcol[k - 1];  // strictly ascending?  (neighbour is in cache)
+            lo = c < lo ? c : lo;
+            hi = c > hi ? c : hi;
+        }
+    }
+#pragma unroll
+    for (int o = W / 2; o >= 1; o >>= 1) {
+        const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o);
+        lo = l < lo ? l : lo;
+        hi = h > hi ? h : hi;
     }
     if (bad) atomicOr(&bs->b_unsorted, 1);
-    BInfo o;
-    o.start = b;
-    o.len = e - b;
-    o.lo = lo;
-    o.hi = hi;
-    info[r] = o;
+    if (r < K && lane == 0) {
+        BInfo o;
+        o.start = b;
+        o.len = e - b;
+        o.lo = lo;
+        o.hi = hi;
+        info[r] = o;
+    }
 }
 
 template <int W>
@@ -1768,7 +1781,18 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     NSP_CHECK(hipMemsetAsync(d_sym, 0, 2 * sizeof(BinState), s0));
 
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
-    hipLaunchKernelGGL(k_b_info, dim3(ceil_div(K, 256)), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym);
+    {
+        const int wb = pick_w(b->nnz, K);
+        const int gb = ceil_div((long long)K * wb, 256);
+#define NSP_BI(W)                                                                              \
+    case W:                                                                                    \
+        hipLaunchKernelGGL(k_b_info<W>, dim3(gb), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym); \
+        break;
+        switch (wb) {
+            NSP_BI(1) NSP_BI(2) NSP_BI(4) NSP_BI(8) NSP_BI(16) NSP_BI(32) NSP_BI(64)
+        }
+#undef NSP_BI
+    }
     long long *partial = (long long *)dev_alloc(sizeof(long long) * kPartialStride * kSetupMaxGrid);
     // column bitmaps handed from the symbolic to the numeric dense kernels
     int *bm_words = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
