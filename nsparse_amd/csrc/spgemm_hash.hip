@@ -215,7 +215,7 @@ struct __attribute__((aligned(sizeof(real) < 8 ? 4 : 8))) RVec {
 //     ceil(alen / (BS/g)) * ceil(avg_len / (g*VW))   group steps,
 // so g trades padding of the B rows (small g pads less) against imbalance between groups
 // (large g, few groups).  The largest g with the fewest steps wins.
-__device__ __forceinline__ int group_width(int np, int alen, int BS)
+__device__ __forceinline__ int group_width(int np, int alen, int BS, int maxb = 0)
 {
     if (alen <= 0) return 64;
     const int avg = (np + alen - 1) / alen;
@@ -223,7 +223,12 @@ __device__ __forceinline__ int group_width(int np, int alen, int BS)
 #pragma unroll
     for (int g = 64; g >= 1; g >>= 1) {
         const int ng = BS / g;
-        const int t = ((alen + ng - 1) / ng) * ((avg + g * VW - 1) / (g * VW));
+        int t = ((alen + ng - 1) / ng) * ((avg + g * VW - 1) / (g * VW));
+        // the group that owns the longest B row of this C row (maxb entries) cannot finish
+        // earlier than that row alone takes: on power-law inputs (hub rows of hundreds of entries
+        // among rows of three) this term, not the average, decides
+        const int tl = (maxb + g * VW - 1) / (g * VW);
+        t = t > tl ? t : tl;
         if (t < best_t) { best_t = t; best_g = g; }
     }
     return best_g;
@@ -425,7 +430,8 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
                                                       int *__restrict__ bm_words, int bm_span_max,
                                                       Thr thr, long long *__restrict__ partial,
                                                       int *__restrict__ row_span_num,
-                                                      int *__restrict__ row_nz)
+                                                      int *__restrict__ row_nz,
+                                                      int *__restrict__ row_maxb)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // scan tails (instead of two memset launches)
         bm_words[M] = 0;
@@ -441,17 +447,21 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
     __syncthreads();
     const int lane = threadIdx.x % W;
     constexpr int RPB = 256 / W;
-    // grid-stride over rows: the grid is capped so that the ~10 same-address global atomics
-    // per workgroup at the end stay in the low thousands (they serialise in L2).
+    // per-thread statistics, folded once per wave at the end: one LDS atomic per row would
+    // serialise when (almost) every row falls into the same bin (1 M-row power-law inputs)
+    int t_max = 0, t_alen = 0;
+    unsigned long long t_total = 0, t_bm = 0;
+    // grid-stride over rows
     for (int row = blockIdx.x * RPB + threadIdx.x / W; row - (int)(threadIdx.x / W) < M; row += gridDim.x * RPB) {
         long long n = 0;
-        int lo = 0x7fffffff, hi = -1;
+        int lo = 0x7fffffff, hi = -1, mb = 0;
         if (row < M) {
             const int e = arpt[row + 1];
             for (int j = arpt[row] + lane; j < e; j += W) {
                 const int c = __builtin_nontemporal_load(acol + j);
                 const BInfo bi = binfo[c];
                 n += bi.len;
+                mb = bi.len > mb ? bi.len : mb;
                 lo = bi.lo < lo ? bi.lo : lo;
                 hi = bi.hi > hi ? bi.hi : hi;
             }
@@ -459,10 +469,12 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
 #pragma unroll
         for (int o = W / 2; o >= 1; o >>= 1) {
             n += __shfl_xor(n, o);
-            const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o);
+            const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o), m2 = __shfl_xor(mb, o);
             lo = l < lo ? l : lo;
             hi = h > hi ? h : hi;
+            mb = m2 > mb ? m2 : mb;
         }
+        int bin = -1;
         if (row < M && lane == 0) {
             const int ni = n > 0x7fffffffLL ? 0x7fffffff : (int)n;  // saturate (hub rows)
             const long long sp = hi >= lo ? (long long)hi - lo + 1 : 0;
@@ -470,15 +482,52 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             row_prod[row] = ni;
             row_lo[row] = hi >= lo ? lo : 0;
             row_span[row] = span;
+            row_maxb[row] = mb;
             // words of the column bitmap the symbolic dense kernel hands to the numeric one
             const int bw = (span > 0 && span <= bm_span_max) ? (span + 31) >> 5 : 0;
             bm_words[row] = bw;
             row_span_num[row] = 0;  // set by k_sym_dense when it hands a bitmap over
-            if (bw) atomicAdd(&s_bm, (unsigned long long)bw);
-            atomicAdd(&s_hist[bin_of(ni, span, thr)], 1);
-            atomicMax(&s_max, ni);
-            atomicMax(&s_alen, arpt[row + 1] - arpt[row]);
-            atomicAdd(&s_total, (unsigned long long)n);
+            bin = bin_of(ni, span, thr);
+            const int al = arpt[row + 1] - arpt[row];
+            if (W >= 16) {  // at most 4 rows per wave: direct LDS atomics are cheapest
+                atomicAdd(&s_hist[bin], 1);
+                atomicMax(&s_max, ni);
+                atomicMax(&s_alen, al);
+                atomicAdd(&s_total, (unsigned long long)n);
+                if (bw) atomicAdd(&s_bm, (unsigned long long)bw);
+            } else {
+                t_max = ni > t_max ? ni : t_max;
+                t_alen = al > t_alen ? al : t_alen;
+                t_total += (unsigned long long)n;
+                t_bm += (unsigned long long)bw;
+            }
+        }
+        if (W < 16) {
+            // histogram: one LDS atomic per (wave, bin present in the wave)
+            unsigned long long todo = __ballot(bin >= 0);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int b = __shfl(bin, leader);
+                const unsigned long long same = __ballot(bin == b);
+                if ((threadIdx.x & 63) == leader) atomicAdd(&s_hist[b], __popcll(same));
+                todo &= ~same;
+            }
+        }
+    }
+    if (W < 16) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int m1 = __shfl_xor(t_max, o), m2 = __shfl_xor(t_alen, o);
+            t_max = m1 > t_max ? m1 : t_max;
+            t_alen = m2 > t_alen ? m2 : t_alen;
+            t_total += __shfl_xor(t_total, o);
+            t_bm += __shfl_xor(t_bm, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&s_max, t_max);
+            atomicMax(&s_alen, t_alen);
+            atomicAdd(&s_total, t_total);
+            atomicAdd(&s_bm, t_bm);
         }
     }
     __syncthreads();
@@ -552,11 +601,25 @@ __global__ __launch_bounds__(256) void k_hist(const int *__restrict__ n, const i
     if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
+    int bin = -1, v = 0;
     if (i < M) {
-        const int v = n[i];
-        atomicAdd(&s_hist[bin_of(v, span[i], thr)], 1);
-        atomicMax(&s_max, v);
+        v = n[i];
+        bin = bin_of(v, span[i], thr);
     }
+    unsigned long long todo = __ballot(bin >= 0);
+    while (todo) {  // one LDS atomic per (wave, bin present in the wave)
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b = __shfl(bin, leader);
+        const unsigned long long same = __ballot(bin == b);
+        if ((threadIdx.x & 63) == leader) atomicAdd(&s_hist[b], __popcll(same));
+        todo &= ~same;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int m = __shfl_xor(v, o);
+        v = m > v ? m : v;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, v);
     __syncthreads();
     if (threadIdx.x < NB && s_hist[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], s_hist[threadIdx.x]);
     if (threadIdx.x == 0) atomicMax(&bs->maxv, s_max);
@@ -579,11 +642,22 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const int *__restrict__ n,
     if (threadIdx.x < NB) s_cnt[threadIdx.x] = 0;
     __syncthreads();
     const int i = blockIdx.x * 256 + threadIdx.x;
-    int b = 0, r = 0;
-    if (i < M) {
-        b = bin_of(n[i], span[i], thr);
-        r = atomicAdd(&s_cnt[b], 1);
+    int b = -1, r = 0;
+    if (i < M) b = bin_of(n[i], span[i], thr);
+    // rank inside the block: ballot + popcount inside the wave, one LDS atomic per (wave, bin)
+    unsigned long long todo = __ballot(b >= 0);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int bb = __shfl(b, leader);
+        const unsigned long long same = __ballot(b == bb);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&s_cnt[bb], __popcll(same));
+        base = __shfl(base, leader);
+        if (b == bb) r = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
     }
+    if (b < 0) b = 0;
     __syncthreads();
     if (threadIdx.x < NB) {
         int off = 0;
@@ -645,6 +719,7 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                                const int *__restrict__ bcol,
                                                const int *__restrict__ row_perm,
                                                const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb,
                                                int *__restrict__ row_nz, int bin_off, int bin_size,
                                                int bnnz, BinState *bs, int *__restrict__ fail_list)
 {
@@ -668,7 +743,7 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
     __syncthreads();
 
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(np, a_end - a_beg, BS);
+    const int g = group_width(np, a_end - a_beg, BS, row_maxb[rid]);
     int cnt = 0;
     if (!LARGE) {
         walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz,
@@ -717,6 +792,7 @@ __global__ __launch_bounds__(BS) void k_sym_global(const int *__restrict__ arpt,
                                                    const int *__restrict__ bcol,
                                                    const int *__restrict__ fail_list, int count,
                                                    const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb,
                                                    int *__restrict__ row_nz, int ncols,
                                                    BinState *bs, int *__restrict__ slab,
                                                    long long slice)
@@ -886,7 +962,8 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
                                                const int *__restrict__ crpt,
                                                int *__restrict__ ccol, real *__restrict__ cval,
                                                const int *__restrict__ row_perm,
-                                               const int *__restrict__ row_prod, int bin_off,
+                                               const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb, int bin_off,
                                                int bin_size, int bnnz, int write_col)
 {
     __shared__ __attribute__((aligned(16))) real vals[TMAX];
@@ -912,7 +989,7 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     __syncthreads();
 
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(row_prod[rid], a_end - a_beg, BS);
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
     walk_products<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av,
                             [&](const IVec &k, const RVec &v, int n, real sc) {
                                 int h[VW], fresh = 0;
@@ -1047,6 +1124,7 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
                                                   const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                   const int *__restrict__ row_perm,
                                                   const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb,
                                                   const int *__restrict__ row_lo,
                                                   const int *__restrict__ row_span,
                                                   int *__restrict__ row_nz, int bin_off, int bin_size,
@@ -1072,7 +1150,7 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
     __syncthreads();
     unsigned char *flag = reinterpret_cast<unsigned char *>(flag4);
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(row_prod[rid], a_end - a_beg, BS);
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
     walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
                              a_end, g, s_ext, (real *)nullptr,
                              [&](const IVec &k, const RVec &, int n, real) {
@@ -1115,6 +1193,7 @@ __global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, c
                                                  const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                  const int *__restrict__ row_perm,
                                                  const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb,
                                                  const int *__restrict__ row_lo,
                                                  const int *__restrict__ row_span,
                                                  int *__restrict__ row_nz, int bin_off, int bin_size,
@@ -1136,7 +1215,7 @@ __global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, c
     if (threadIdx.x == 0) s_nz = 0;
     __syncthreads();
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(row_prod[rid], a_end - a_beg, BS);
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
     walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
                              a_end, g, s_ext, (real *)nullptr,
                              [&](const IVec &k, const RVec &, int n, real) {
@@ -1165,6 +1244,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
                                                   real *__restrict__ cval,
                                                   const int *__restrict__ row_perm,
                                                   const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb,
                                                   const int *__restrict__ row_lo,
                                                   const int *__restrict__ row_span, int bin_off,
                                                   int bin_size, int bnnz,
@@ -1192,7 +1272,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
     for (int i = threadIdx.x; i < 4 * Q; i += BS) dense[i] = 0;
     __syncthreads();
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(row_prod[rid], a_end - a_beg, BS);
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
     walk_products<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av,
                             [&](const IVec &k, const RVec &v, int n, real sc) {
 #pragma unroll
@@ -1424,7 +1504,7 @@ static inline int pick_w(long long nnz, int M)
 static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *binfo,
                                 int *row_prod, int *row_lo, int *row_span, int *bm_words,
                                 int bm_span_max, const Thr &thr, BinState *d_bs, long long *partial,
-                                int *row_span_num, int *row_nz, hipStream_t st)
+                                int *row_span_num, int *row_nz, int *row_maxb, hipStream_t st)
 {
     const int M = a->M;
     const int w = pick_w(a->nnz, M);
@@ -1434,7 +1514,7 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *bin
     case W:                                                                                    \
         hipLaunchKernelGGL(k_row_products<W>, dim3(grid), dim3(256), 0, st, a->d_rpt, a->d_col, \
                            binfo, M, row_prod, row_lo, row_span, bm_words, bm_span_max, thr,   \
-                           partial, row_span_num, row_nz);                                     \
+                           partial, row_span_num, row_nz, row_maxb);                           \
         break;
     switch (w) {
         NSP_RP(1) NSP_RP(2) NSP_RP(4) NSP_RP(8) NSP_RP(16) NSP_RP(32) NSP_RP(64)
@@ -1451,6 +1531,7 @@ struct Timer {
     float ms(int i, int j)
     {
         float v = 0;
+        NSP_CHECK(hipEventSynchronize(cx.ev_t[j]));
         NSP_CHECK(hipEventElapsedTime(&v, cx.ev_t[i], cx.ev_t[j]));
         return v;
     }
@@ -1501,7 +1582,11 @@ struct BinLauncher {
     {
         for (int b = 0; b < NB; b++) {
             out[b] = 0;
-            if (used[b]) NSP_CHECK(hipEventElapsedTime(&out[b], ev[2 * b], ev[2 * b + 1]));
+            if (used[b]) {
+                // the flag poll proves the GPU is done, not that the runtime has retired the event
+                NSP_CHECK(hipEventSynchronize(ev[2 * b + 1]));
+                NSP_CHECK(hipEventElapsedTime(&out[b], ev[2 * b], ev[2 * b + 1]));
+            }
         }
     }
 };
@@ -1519,7 +1604,8 @@ static int global_slab_groups(long long slice_elems, size_t bytes_per_elem, int 
     return (int)g;
 }
 
-static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, const int *row_lo,
+static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, const int *row_maxb,
+                                  const int *row_lo,
                                   const int *row_span, int *row_nz, int *row_perm, const int *hist,
                                   int max_prod, BinState *d_bs, Context &cx, float *ms_bin,
                                   int *fail_rows, const int *bm_off, unsigned int *bm,
@@ -1537,7 +1623,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     if (hist[BIN] > 0) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_tb<BS, TMAX, false>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, \
-                           st, arpt, acol, brpt, bcol, row_perm, row_prod, row_nz, off[BIN],   \
+                           st, arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[BIN],   \
                            hist[BIN], b->nnz, d_bs,                                            \
                            (int *)nullptr);                                                    \
         NSP_LAUNCH_CHECK();                                                                    \
@@ -1547,7 +1633,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     if (hist[BIN] > 0) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_dense<BS, SPAN>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
-                           arpt, acol, brpt, bcol, row_perm, row_prod, row_lo, row_span, row_nz, \
+                           arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_lo, row_span, row_nz, \
                            off[BIN], hist[BIN], b->nnz, bm_off, bm, row_span_num);             \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
@@ -1556,7 +1642,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     if (hist[BIN] > 0) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_bits<BS, WORDS>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
-                           arpt, acol, brpt, bcol, row_perm, row_prod, row_lo, row_span, row_nz, \
+                           arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_lo, row_span, row_nz, \
                            off[BIN], hist[BIN], b->nnz);                                       \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
@@ -1590,7 +1676,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         hipStream_t st = L.begin(5);
         fail_list = (int *)dev_alloc(sizeof(int) * (size_t)hist[5]);
         hipLaunchKernelGGL((k_sym_tb<1024, kSymLargeT, true>), dim3(8 * ceil_div(hist[5], 8)), dim3(1024), 0, st, arpt,
-                           acol, brpt, bcol, row_perm, row_prod, row_nz, off[5], hist[5], b->nnz, d_bs, fail_list);
+                           acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[5], hist[5], b->nnz, d_bs, fail_list);
         NSP_LAUNCH_CHECK();
         NSP_CHECK(hipMemcpyAsync(cx.h_pinned + 128, &d_bs->fail_count, sizeof(int), hipMemcpyDeviceToHost, st));
         NSP_CHECK(hipStreamSynchronize(st));
@@ -1603,7 +1689,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
             const int groups = global_slab_groups(slice, sizeof(int), fails);
             int *slab = (int *)dev_alloc(sizeof(int) * (size_t)slice * groups);
             hipLaunchKernelGGL((k_sym_global<512>), dim3(groups), dim3(512), 0, st, arpt, acol, brpt,
-                               bcol, fail_list, fails, row_prod, row_nz, b->N, d_bs, slab, slice);
+                               bcol, fail_list, fails, row_prod, row_maxb, row_nz, b->N, d_bs, slab, slice);
             NSP_LAUNCH_CHECK();
             NSP_CHECK(hipStreamSynchronize(st));
             dev_free(slab);
@@ -1616,6 +1702,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
 }
 
 static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const int *row_prod,
+                                 const int *row_maxb,
                                  const int *row_lo, const int *row_span, const int *row_perm,
                                  const int *hist, int max_nz, BinState *d_bs, Context &cx,
                                  float *ms_bin, int write_col, const int *bm_off,
@@ -1628,6 +1715,54 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     const int *arpt = a->d_rpt, *acol = a->d_col, *brpt = b->d_rpt, *bcol = b->d_col;
     const real *aval = a->d_val, *bval = b->d_val;
     L.fork();
+#define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
+    if (hist[BIN] > 0) {                                                                       \
+        hipStream_t st = L.begin(BIN);                                                         \
+        hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, arpt,  \
+                           acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, \
+                           row_prod, row_maxb, off[BIN], hist[BIN], b->nnz, write_col);                                     \
+        NSP_LAUNCH_CHECK();                                                                    \
+        L.end(BIN);                                                                            \
+    }
+#define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
+    if (hist[BIN] > 0) {                                                                       \
+        hipStream_t st = L.begin(BIN);                                                         \
+        if (write_col & 1)                                                                     \
+            hipLaunchKernelGGL((k_num_dense<BS, SPAN, 1>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
+                               0, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
+                               c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[BIN],       \
+                               hist[BIN], b->nnz, bm_off, bm);                                 \
+        else                                                                                   \
+            hipLaunchKernelGGL((k_num_dense<BS, SPAN, 2>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
+                               0, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
+                               c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[BIN],       \
+                               hist[BIN], b->nnz, bm_off, bm);                                 \
+        NSP_LAUNCH_CHECK();                                                                    \
+        L.end(BIN);                                                                            \
+    }
+    static const int tune_nd6 = getenv("NSPARSE_NUMD6_BS") ? atoi(getenv("NSPARSE_NUMD6_BS")) : 256;
+    NSP_NUM_DENSE(8, 512, 12288)
+    NSP_NUM_DENSE(7, 256, 4096)
+    if (tune_nd6 == 128) { NSP_NUM_DENSE(6, 128, 1536) } else if (tune_nd6 == 512) { NSP_NUM_DENSE(6, 512, 1536) } else { NSP_NUM_DENSE(6, 256, 1536) }
+#undef NSP_NUM_DENSE
+    static const int tune_n2 = getenv("NSPARSE_NUM2_BS") ? atoi(getenv("NSPARSE_NUM2_BS")) : 256;
+    static const int tune_n1 = getenv("NSPARSE_NUM1_BS") ? atoi(getenv("NSPARSE_NUM1_BS")) : 64;
+    NSP_NUM_TB(4, 1024, 8192, 8192)
+    NSP_NUM_TB(3, 512, 4096, 4096)
+    if (tune_n2 == 128) { NSP_NUM_TB(2, 128, 1024, 1024) } else if (tune_n2 == 512) { NSP_NUM_TB(2, 512, 1024, 1024) } else { NSP_NUM_TB(2, 256, 1024, 1024) }
+    if (tune_n1 == 128) { NSP_NUM_TB(1, 128, 256, 256) } else { NSP_NUM_TB(1, 64, 256, 256) }
+#undef NSP_NUM_TB
+    if (hist[0] > 0) {
+        hipStream_t st = L.begin(0);
+        constexpr int BS = 256, LPR = 4;
+        hipLaunchKernelGGL((k_num_small<BS, LPR, 32>), dim3(ceil_div(hist[0], BS / LPR)), dim3(BS), 0,
+                           st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val,
+                           row_perm, off[0], hist[0], write_col);
+        NSP_LAUNCH_CHECK();
+        L.end(0);
+    }
+    // The heavy bin synchronises on the host (its scratch slab is freed here), so it is issued
+    // last: every other bin is already queued on its own stream and overlaps with it.
     constexpr int kTileW = sizeof(real) == 8 ? 12288 : 24576;
     static const int tiled_on = !(getenv("NSPARSE_TILED") && getenv("NSPARSE_TILED")[0] == '0');
     static const int long_len = getenv("NSPARSE_TILED_LONG") ? atoi(getenv("NSPARSE_TILED_LONG")) : 128;
@@ -1693,52 +1828,6 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         dev_free(vslab);
         dev_free(kslab);
     }
-#define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
-    if (hist[BIN] > 0) {                                                                       \
-        hipStream_t st = L.begin(BIN);                                                         \
-        hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, arpt,  \
-                           acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, \
-                           row_prod, off[BIN], hist[BIN], b->nnz, write_col);                                     \
-        NSP_LAUNCH_CHECK();                                                                    \
-        L.end(BIN);                                                                            \
-    }
-#define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
-    if (hist[BIN] > 0) {                                                                       \
-        hipStream_t st = L.begin(BIN);                                                         \
-        if (write_col & 1)                                                                     \
-            hipLaunchKernelGGL((k_num_dense<BS, SPAN, 1>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
-                               0, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
-                               c->d_val, row_perm, row_prod, row_lo, row_span, off[BIN],       \
-                               hist[BIN], b->nnz, bm_off, bm);                                 \
-        else                                                                                   \
-            hipLaunchKernelGGL((k_num_dense<BS, SPAN, 2>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
-                               0, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
-                               c->d_val, row_perm, row_prod, row_lo, row_span, off[BIN],       \
-                               hist[BIN], b->nnz, bm_off, bm);                                 \
-        NSP_LAUNCH_CHECK();                                                                    \
-        L.end(BIN);                                                                            \
-    }
-    static const int tune_nd6 = getenv("NSPARSE_NUMD6_BS") ? atoi(getenv("NSPARSE_NUMD6_BS")) : 256;
-    NSP_NUM_DENSE(8, 512, 12288)
-    NSP_NUM_DENSE(7, 256, 4096)
-    if (tune_nd6 == 128) { NSP_NUM_DENSE(6, 128, 1536) } else if (tune_nd6 == 512) { NSP_NUM_DENSE(6, 512, 1536) } else { NSP_NUM_DENSE(6, 256, 1536) }
-#undef NSP_NUM_DENSE
-    static const int tune_n2 = getenv("NSPARSE_NUM2_BS") ? atoi(getenv("NSPARSE_NUM2_BS")) : 256;
-    static const int tune_n1 = getenv("NSPARSE_NUM1_BS") ? atoi(getenv("NSPARSE_NUM1_BS")) : 64;
-    NSP_NUM_TB(4, 1024, 8192, 8192)
-    NSP_NUM_TB(3, 512, 4096, 4096)
-    if (tune_n2 == 128) { NSP_NUM_TB(2, 128, 1024, 1024) } else if (tune_n2 == 512) { NSP_NUM_TB(2, 512, 1024, 1024) } else { NSP_NUM_TB(2, 256, 1024, 1024) }
-    if (tune_n1 == 128) { NSP_NUM_TB(1, 128, 256, 256) } else { NSP_NUM_TB(1, 64, 256, 256) }
-#undef NSP_NUM_TB
-    if (hist[0] > 0) {
-        hipStream_t st = L.begin(0);
-        constexpr int BS = 256, LPR = 4;
-        hipLaunchKernelGGL((k_num_small<BS, LPR, 32>), dim3(ceil_div(hist[0], BS / LPR)), dim3(BS), 0,
-                           st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val,
-                           row_perm, off[0], hist[0], write_col);
-        NSP_LAUNCH_CHECK();
-        L.end(0);
-    }
     L.join();
     return L;
 }
@@ -1769,6 +1858,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     int *row_perm = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     int *row_lo = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     int *row_span = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
+    int *row_maxb = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     const int K = b->M;
     BInfo *binfo = (BInfo *)dev_alloc(sizeof(BInfo) * (size_t)(K > 0 ? K : 1));
     if (g_dense_enabled < 0) {
@@ -1800,7 +1890,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     int *row_span_num = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
     launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
-                        use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, row_span_num, row_nz, s0);
+                        use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, s0);
     void *bm_scan_tmp = nullptr;
     if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
     const int grid_m = ceil_div(M, 256);
@@ -1828,7 +1918,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
         // used by the symbolic phase alone and the numeric phase hashes
         if (use_bm && h_sym->bm_total > 0 && h_sym->bm_total < (1LL << 30))
             bm = (unsigned int *)dev_alloc(sizeof(unsigned int) * (size_t)h_sym->bm_total);
-        BinLauncher LS = symbolic_phase(a, b, row_prod, row_lo, row_span, row_nz, row_perm, h_sym->hist,
+        BinLauncher LS = symbolic_phase(a, b, row_prod, row_maxb, row_lo, row_span, row_nz, row_perm, h_sym->hist,
                                         h_sym->maxv, d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows,
                                         bm_off, bm, row_span_num);
         sym_used = LS;
@@ -1866,7 +1956,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     S.nnz_c = c->nnz;
 
     // ---- numeric --------------------------------------------------------------------
-    BinLauncher LN = numeric_phase(a, b, c, row_prod, row_lo, row_span, row_perm, h_num->hist,
+    BinLauncher LN = numeric_phase(a, b, c, row_prod, row_maxb, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
                                    (int)h_sym->max_alen, h_sym->b_unsorted == 0);
@@ -1893,6 +1983,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     dev_free(bm_words);
     dev_free(partial);
     dev_free(binfo);
+    dev_free(row_maxb);
     dev_free(row_span);
     dev_free(row_lo);
     dev_free(row_perm);
