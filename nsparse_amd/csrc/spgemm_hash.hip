@@ -93,6 +93,11 @@ constexpr Thr kSymThr = {32, {512, 2048, 8192, 32768}, {4096, 16384, 65536}, 8, 
 constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8, {0, 0}, 0, 0};
 constexpr int kSymLargeBin = 5;
 constexpr int kNumGlobalBin = 5;
+// Setup kernels: rows longer than kLongFactor * W entries are not walked by their W-lane group
+// (a 4700-entry row on 4 lanes is a millisecond of serial dependent gathers): the bulk pass
+// appends them to a short device list and a second, fixed-size launch walks them with 64 lanes.
+constexpr int kLongFactor = 32;
+constexpr int kLongCap = 1 << 16;
 constexpr int kDenseBin0 = 6;
 constexpr int kBitsBin0 = 9;
 constexpr int kSetupMaxGrid = 16384;
@@ -385,38 +390,55 @@ struct __attribute__((aligned(16))) BInfo {
 
 template <int W>
 __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, const int *__restrict__ bcol,
-                                                int K, BInfo *__restrict__ info, BinState *bs)
+                                                int K, BInfo *__restrict__ info, BinState *bs,
+                                                int *__restrict__ long_list, int *long_cnt, int long_len,
+                                                const int *__restrict__ todo)
 {
-    // W lanes per row of B (W from the average row length, so the column loads coalesce)
-    const int r = (blockIdx.x * 256 + threadIdx.x) / W;
+    // W lanes per row of B (W from the average row length, so the column loads coalesce).
+    // todo == nullptr: bulk pass over all rows; rows longer than long_len are deferred to
+    // long_list.  todo != nullptr: pass over the deferred rows todo[0 .. min(*long_cnt, cap)).
+    constexpr int RPB = 256 / W;
     const int lane = threadIdx.x % W;
-    int lo = 0x7fffffff, hi = -1;
-    bool bad = false;
-    int b = 0, e = 0;
-    if (r < K) {
-        b = brpt[r];
-        e = brpt[r + 1];
-        for (int k = b + lane; k < e; k += W) {
-            const int c = bcol[k];
-            if (k > b) bad |= c <= bcol[k - 1];  // strictly ascending?  (neighbour is in cache)
-            lo = c < lo ? c : lo;
-            hi = c > hi ? c : hi;
+    const int nrows = todo ? (*long_cnt < kLongCap ? *long_cnt : kLongCap) : K;
+    for (int base = blockIdx.x * RPB; base < nrows; base += gridDim.x * RPB) {
+        const int q = base + (int)threadIdx.x / W;
+        const int r = q < nrows ? (todo ? todo[q] : q) : -1;
+        int lo = 0x7fffffff, hi = -1, b = 0, e = 0;
+        bool bad = false;
+        if (r >= 0) {
+            b = brpt[r];
+            e = brpt[r + 1];
         }
-    }
+        int ok = 0;
+        if (r >= 0 && !todo && long_list && e - b > long_len && lane == 0) {
+            const int idx = atomicAdd(long_cnt, 1);
+            ok = idx < kLongCap;
+            if (ok) long_list[idx] = r;
+        }
+        const bool defer = __shfl(ok, 0, W) != 0;
+        if (r >= 0 && !defer) {
+            for (int k = b + lane; k < e; k += W) {
+                const int c = bcol[k];
+                if (k > b) bad |= c <= bcol[k - 1];  // strictly ascending?  (neighbour is in cache)
+                lo = c < lo ? c : lo;
+                hi = c > hi ? c : hi;
+            }
+        }
 #pragma unroll
-    for (int o = W / 2; o >= 1; o >>= 1) {
-        const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o);
-        lo = l < lo ? l : lo;
-        hi = h > hi ? h : hi;
-    }
-    if (bad) atomicOr(&bs->b_unsorted, 1);
-    if (r < K && lane == 0) {
-        BInfo o;
-        o.start = b;
-        o.len = e - b;
-        o.lo = lo;
-        o.hi = hi;
-        info[r] = o;
+        for (int o = W / 2; o >= 1; o >>= 1) {
+            const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o);
+            lo = l < lo ? l : lo;
+            hi = h > hi ? h : hi;
+        }
+        if (bad) atomicOr(&bs->b_unsorted, 1);
+        if (r >= 0 && !defer && lane == 0) {
+            BInfo o;
+            o.start = b;
+            o.len = e - b;
+            o.lo = lo;
+            o.hi = hi;
+            info[r] = o;
+        }
     }
 }
 
@@ -431,9 +453,14 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
                                                       Thr thr, long long *__restrict__ partial,
                                                       int *__restrict__ row_span_num,
                                                       int *__restrict__ row_nz,
-                                                      int *__restrict__ row_maxb)
+                                                      int *__restrict__ row_maxb,
+                                                      int *__restrict__ long_list, int *long_cnt,
+                                                      int long_len, const int *__restrict__ todo)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {  // scan tails (instead of two memset launches)
+    // todo == nullptr: bulk pass, rows of A longer than long_len are deferred to long_list;
+    // todo != nullptr: the deferred rows (see kLongFactor)
+    const int nrows = todo ? (*long_cnt < kLongCap ? *long_cnt : kLongCap) : M;
+    if (!todo && blockIdx.x == 0 && threadIdx.x == 0) {  // scan tails (instead of two memset launches)
         bm_words[M] = 0;
         row_nz[M] = 0;
     }
@@ -452,12 +479,39 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
     int t_max = 0, t_alen = 0;
     unsigned long long t_total = 0, t_bm = 0;
     // grid-stride over rows
-    for (int row = blockIdx.x * RPB + threadIdx.x / W; row - (int)(threadIdx.x / W) < M; row += gridDim.x * RPB) {
+    for (int base = blockIdx.x * RPB; base < nrows; base += gridDim.x * RPB) {
+        const int q = base + (int)threadIdx.x / W;
+        int row = q < nrows ? (todo ? todo[q] : q) : M;
         long long n = 0;
         int lo = 0x7fffffff, hi = -1, mb = 0;
+        {
+            int ok = 0;
+            if (row < M && !todo && long_list && arpt[row + 1] - arpt[row] > long_len && lane == 0) {
+                const int idx = atomicAdd(long_cnt, 1);
+                ok = idx < kLongCap;
+                if (ok) long_list[idx] = row;
+            }
+            if (__shfl(ok, 0, W) != 0) row = M;  // deferred: nothing to do for this group now
+        }
         if (row < M) {
             const int e = arpt[row + 1];
-            for (int j = arpt[row] + lane; j < e; j += W) {
+            int j = arpt[row] + lane;
+            for (; j + 3 * W < e; j += 4 * W) {  // four independent gathers in flight
+                int c[4];
+                BInfo bi[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) c[u] = __builtin_nontemporal_load(acol + j + u * W);
+#pragma unroll
+                for (int u = 0; u < 4; u++) bi[u] = binfo[c[u]];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    n += bi[u].len;
+                    mb = bi[u].len > mb ? bi[u].len : mb;
+                    lo = bi[u].lo < lo ? bi[u].lo : lo;
+                    hi = bi[u].hi > hi ? bi[u].hi : hi;
+                }
+            }
+            for (; j < e; j += W) {
                 const int c = __builtin_nontemporal_load(acol + j);
                 const BInfo bi = binfo[c];
                 n += bi.len;
@@ -592,7 +646,7 @@ __global__ __launch_bounds__(64) void k_publish(const BinState *__restrict__ src
 }
 
 // histogram of an existing per-row count (numeric binning, set_min_bin :201-246)
-__global__ __launch_bounds__(256) void k_hist(const int *__restrict__ n, const int *__restrict__ span,
+__global__ __launch_bounds__(1024) void k_hist(const int *__restrict__ n, const int *__restrict__ span,
                                               int M, Thr thr, BinState *bs)
 {
     __shared__ int s_hist[NB];
@@ -600,8 +654,8 @@ __global__ __launch_bounds__(256) void k_hist(const int *__restrict__ n, const i
     if (threadIdx.x < NB) s_hist[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_max = 0;
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    int bin = -1, v = 0;
+    const int i = blockIdx.x * 1024 + threadIdx.x;  // 1024 rows per block: 4x fewer same-address
+    int bin = -1, v = 0;                             // global atomics at the end
     if (i < M) {
         v = n[i];
         bin = bin_of(v, span[i], thr);
@@ -633,7 +687,7 @@ __global__ __launch_bounds__(256) void k_row_len(const int *__restrict__ rpt, in
 
 // rows grouped by bin (set_row_perm :125-154): one LDS pass ranks the rows of a block
 // inside their bin, one global atomic per (block, bin) reserves the range.
-__global__ __launch_bounds__(256) void k_bin_scatter(const int *__restrict__ n,
+__global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
                                                      const int *__restrict__ span, int M, Thr thr,
                                                      BinState *bs, int *__restrict__ perm)
 {
@@ -641,7 +695,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(const int *__restrict__ n,
     __shared__ int s_base[NB];
     if (threadIdx.x < NB) s_cnt[threadIdx.x] = 0;
     __syncthreads();
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
     int b = -1, r = 0;
     if (i < M) b = bin_of(n[i], span[i], thr);
     // rank inside the block: ballot + popcount inside the wave, one LDS atomic per (wave, bin)
@@ -1501,25 +1555,40 @@ static inline int pick_w(long long nnz, int M)
     return w;
 }
 
+
 static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *binfo,
                                 int *row_prod, int *row_lo, int *row_span, int *bm_words,
                                 int bm_span_max, const Thr &thr, BinState *d_bs, long long *partial,
-                                int *row_span_num, int *row_nz, int *row_maxb, hipStream_t st)
+                                int *row_span_num, int *row_nz, int *row_maxb, int *long_list,
+                                int *long_cnt, hipStream_t st)
 {
     const int M = a->M;
     const int w = pick_w(a->nnz, M);
     int grid = ceil_div((long long)M * w, 256);
-    if (grid > kSetupMaxGrid) grid = kSetupMaxGrid;
+    if (grid > kSetupMaxGrid - 256) grid = kSetupMaxGrid - 256;
+    const int *no_todo = nullptr;
+    // nnz_max in (0, threshold] => the host knows no row is long: no deferral, no second launch.
+    // (A wrong nnz_max is harmless: without a list every row is simply walked in place.)
+    if (a->nnz_max > 0 && a->nnz_max <= kLongFactor * w) long_list = nullptr;
 #define NSP_RP(W)                                                                              \
     case W:                                                                                    \
         hipLaunchKernelGGL(k_row_products<W>, dim3(grid), dim3(256), 0, st, a->d_rpt, a->d_col, \
                            binfo, M, row_prod, row_lo, row_span, bm_words, bm_span_max, thr,   \
-                           partial, row_span_num, row_nz, row_maxb);                           \
+                           partial, row_span_num, row_nz, row_maxb, long_list, long_cnt,       \
+                           kLongFactor * W, no_todo);                                          \
         break;
     switch (w) {
         NSP_RP(1) NSP_RP(2) NSP_RP(4) NSP_RP(8) NSP_RP(16) NSP_RP(32) NSP_RP(64)
     }
 #undef NSP_RP
+    if (long_list) {
+        // the deferred long rows, 64 lanes each; their block partials follow the bulk pass's
+        hipLaunchKernelGGL(k_row_products<64>, dim3(256), dim3(256), 0, st, a->d_rpt, a->d_col, binfo, M,
+                           row_prod, row_lo, row_span, bm_words, bm_span_max, thr,
+                           partial + (long long)grid * kPartialStride, row_span_num, row_nz, row_maxb,
+                           (int *)nullptr, long_cnt, 0, (const int *)long_list);
+        grid += 256;
+    }
     hipLaunchKernelGGL(k_reduce_partials, dim3(grid < 32 ? grid : 32), dim3(256), 0, st, partial, grid, d_bs);
     NSP_LAUNCH_CHECK();
 }
@@ -1861,6 +1930,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     int *row_maxb = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     const int K = b->M;
     BInfo *binfo = (BInfo *)dev_alloc(sizeof(BInfo) * (size_t)(K > 0 ? K : 1));
+    int *long_list = (int *)dev_alloc(sizeof(int) * kLongCap);  // reused: B rows first, then A rows
+    int *long_cnt = cx.d_scratch + 240;                         // [0] B pass, [1] A pass
     if (g_dense_enabled < 0) {
         const char *e = getenv("NSPARSE_DENSE");
         g_dense_enabled = !(e && e[0] == '0');
@@ -1869,19 +1940,25 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     if (!g_dense_enabled) sym_thr.dense_ratio = num_thr.dense_ratio = sym_thr.bits_ratio = 0;
     NSP_CHECK(hipStreamSynchronize(0));  // inputs queued on the null stream by the caller
     NSP_CHECK(hipMemsetAsync(d_sym, 0, 2 * sizeof(BinState), s0));
+    NSP_CHECK(hipMemsetAsync(long_cnt, 0, 2 * sizeof(int), s0));
 
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
     {
         const int wb = pick_w(b->nnz, K);
         const int gb = ceil_div((long long)K * wb, 256);
+        int *blist = (b->nnz_max > 0 && b->nnz_max <= kLongFactor * wb) ? nullptr : long_list;
 #define NSP_BI(W)                                                                              \
     case W:                                                                                    \
-        hipLaunchKernelGGL(k_b_info<W>, dim3(gb), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym); \
+        hipLaunchKernelGGL(k_b_info<W>, dim3(gb), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym, \
+                           blist, long_cnt, kLongFactor * W, (const int *)nullptr);            \
         break;
         switch (wb) {
             NSP_BI(1) NSP_BI(2) NSP_BI(4) NSP_BI(8) NSP_BI(16) NSP_BI(32) NSP_BI(64)
         }
 #undef NSP_BI
+        if (blist)
+            hipLaunchKernelGGL(k_b_info<64>, dim3(256), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym,
+                               (int *)nullptr, long_cnt, 0, (const int *)long_list);
     }
     long long *partial = (long long *)dev_alloc(sizeof(long long) * kPartialStride * kSetupMaxGrid);
     // column bitmaps handed from the symbolic to the numeric dense kernels
@@ -1890,12 +1967,12 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     int *row_span_num = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
     launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
-                        use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, s0);
+                        use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, s0);
     void *bm_scan_tmp = nullptr;
     if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
-    const int grid_m = ceil_div(M, 256);
+    const int grid_m = ceil_div(M, 1024);
     if (!numeric_only) {
-        hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_prod, row_span, M, sym_thr, d_sym, row_perm);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_prod, row_span, M, sym_thr, d_sym, row_perm);
         NSP_LAUNCH_CHECK();
     }
     {
@@ -1936,8 +2013,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
     const int *num_span = numeric_only ? row_span : row_span_num;
     if (!numeric_only && bm == nullptr) num_thr.dense_ratio = 0;
-    hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(256), 0, s0, row_nz, num_span, M, num_thr, d_num);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(256), 0, s0, row_nz, num_span, M, num_thr, d_num, row_perm);
+    hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, M, num_thr, d_num);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, M, num_thr, d_num, row_perm);
     NSP_LAUNCH_CHECK();
     {
         const int seq = ++cx.seq;
@@ -1982,6 +2059,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     dev_free(bm_off);
     dev_free(bm_words);
     dev_free(partial);
+    dev_free(long_list);
     dev_free(binfo);
     dev_free(row_maxb);
     dev_free(row_span);
