@@ -1376,6 +1376,15 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
 // ===================================================================================
 //  heavy numeric rows: column-tiled dense windows
 // ===================================================================================
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
+// waits for the acknowledgement of every global store issued before it; the tiled kernel
+// emits a tile with global stores nobody in the workgroup reads back, so waiting for them
+// once per tile (a full HBM round trip) is pure stall.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Rows with more than 5461 non-zeros do not fit an LDS hash table, and on power-law inputs
 // they carry most of the products (R-MAT-18: 59 K such rows, 2.7 G products).  Hashing them in
 // global memory means two random HBM round trips per product.  Instead the row's column window
@@ -1398,15 +1407,33 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                                                   BinState *bs, const int *__restrict__ row_lo,
                                                   const int *__restrict__ row_span, int *__restrict__ slab,
                                                   long long stride_ints, int amax, int write_col,
-                                                  int LONG_LEN)
+                                                  int LONG_LEN, unsigned long long *prof)
 {
+    // prof (NSPARSE_TILED_PROF=1): thread 0 adds 100 MHz ticks per phase -- 0 cursor set-up,
+    // 2 register-fed accumulation, 3 overflow paths, 4 emission, 5 tiles, 6 rows
+    // (kept in registers, one atomic per counter when the workgroup retires)
+    unsigned long long tk = prof ? wall_clock64() : 0;
+    unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&](int phase) {
+        if (prof) {
+            const unsigned long long now = wall_clock64();
+            t_acc[phase] += now - tk;
+            tk = now;
+        }
+    };
     constexpr int NW = BS / 64;
     constexpr int LCAP = 1024;      // long B rows tracked per C row (the rest stay lane-serial)
+    constexpr int EPT = 4;          // lane-serial cursors per thread kept in registers
+    constexpr int KS = 4;           // sweep slots per wavefront kept in registers
+    constexpr int VMAX = 32;        // sweep slots one B row may be dealt out to
+    constexpr int INF = 0x7fffffff;
+    constexpr int R = W / NW;       // columns of a tile emitted by one wavefront
+    constexpr int IT = R / 64;
+    static_assert(W % (NW * 64) == 0, "tile width must split evenly over the wavefronts");
     // LONG_LEN: a B row longer than this is swept by a whole wavefront
     __shared__ __attribute__((aligned(16))) real dense[W];
     __shared__ __attribute__((aligned(16))) unsigned int flag4[W / 4];
-    __shared__ int l_cur[LCAP];
-    __shared__ int l_end[LCAP];
+    __shared__ int4 l_meta[LCAP];   // sweep list: (chunk position, row end, stride, -)
     __shared__ real l_av[LCAP];
     __shared__ int s_row;
     __shared__ int s_nlong;
@@ -1417,6 +1444,10 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
     int *st_next = st_end + amax;
     real *st_av = reinterpret_cast<real *>(st_next + amax);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // The window is clean on entry to every tile: cleared here once, and the emission resets
+    // exactly the slots it finds occupied.
+    for (int i = threadIdx.x; i < W; i += BS) dense[i] = 0;
+    for (int i = threadIdx.x; i < W / 4; i += BS) flag4[i] = 0;
     while (true) {
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -1426,110 +1457,243 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
         __syncthreads();
         const int q = s_row;
         if (q >= count) break;
+        tick(1);  // queue + barriers
         const int rid = row_perm[bin_off + q];
         const int lo = row_lo[rid], span = row_span[rid];
         const int a_beg = arpt[rid], alen = arpt[rid + 1] - a_beg;
-        // cursors: entry e is always handled by thread e % BS, so its state needs no
-        // cross-thread visibility.  Long B rows go to the LDS list instead.
-        for (int e = threadIdx.x; e < alen; e += BS) {
+        // ---- cursor set-up ------------------------------------------------------------
+        // Entry e of the A row is always handled by thread e % BS.  Its cursor into B row
+        // acol[e] keeps the NEXT TWO (column, value) pairs in registers, so that a tile in
+        // which the entry has at most one product is served without waiting for memory: the
+        // refill issued when a pair is consumed is only needed a tile later.  The first EPT
+        // entries of a thread live in registers; the rest (A rows beyond EPT * BS entries) in
+        // the workgroup's global slice with a one-column look-ahead.  B rows longer than
+        // LONG_LEN go to the LDS list and are swept by whole wavefronts.
+        int e_cur[EPT], e_end[EPT], e_c0[EPT], e_c1[EPT];
+        real e_v0[EPT], e_v1[EPT], e_av[EPT];
+        // A long B row is swept in chunks of 64 consecutive entries.  A row that would put more
+        // than one chunk into a tile is dealt out chunk by chunk to V sweep slots (slot v takes
+        // chunks v, v + V, ...), which land on different wavefronts: on power-law inputs the
+        // longest B rows carry most of the products of a C row.
+        const int split = 64 * ((span + W - 1) / W);
+        auto init_entry = [&](int e, int &cur, int &end, real &av) -> bool {
             const int c = acol[a_beg + e];
-            const int cur = brpt[c], end = brpt[c + 1];
-            const real av = aval[a_beg + e];
-            int li = -1;
-            if (end - cur > LONG_LEN) {
-                li = atomicAdd(&s_nlong, 1);
-                if (li < LCAP) {
-                    l_cur[li] = cur;
-                    l_end[li] = end;
-                    l_av[li] = av;
+            cur = brpt[c];
+            end = brpt[c + 1];
+            av = aval[a_beg + e];
+            const int len = end - cur;
+            if (len <= LONG_LEN) return true;
+            int V = (len + split - 1) / split;
+            V = V < 1 ? 1 : (V > VMAX ? VMAX : V);
+            const int li = atomicAdd(&s_nlong, V);
+            const bool fits = li + V <= LCAP;
+            for (int v = 0; v < V && li + v < LCAP; v++) {
+                l_meta[li + v] = fits ? make_int4(cur + 64 * v, end, 64 * V, 0) : make_int4(0, 0, 64, 0);
+                l_av[li + v] = av;
+            }
+            return !fits;  // true: lane-serial
+        };
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            const int e = threadIdx.x + u * BS;
+            e_cur[u] = e_end[u] = 0;
+            e_c0[u] = e_c1[u] = INF;
+            e_v0[u] = e_v1[u] = e_av[u] = 0;
+            if (e < alen && init_entry(e, e_cur[u], e_end[u], e_av[u])) {
+                const int k = e_cur[u], end = e_end[u];
+                if (k < end) {
+                    e_c0[u] = bcol[k];
+                    e_v0[u] = bval[k];
+                }
+                if (k + 1 < end) {
+                    e_c1[u] = bcol[k + 1];
+                    e_v1[u] = bval[k + 1];
                 }
             }
-            const bool serial = li < 0 || li >= LCAP;
+        }
+        for (int e = threadIdx.x + EPT * BS; e < alen; e += BS) {
+            int cur, end;
+            real av;
+            const bool serial = init_entry(e, cur, end, av);
             st_cur[e] = cur;
             st_end[e] = end;
-            st_next[e] = (serial && cur < end) ? bcol[cur] : 0x7fffffff;
+            st_next[e] = (serial && cur < end) ? bcol[cur] : INF;
             st_av[e] = av;
         }
         __syncthreads();
         const int nlong = s_nlong < LCAP ? s_nlong : LCAP;
+        // sweep slots w, w + NW, ...: the first KS of a wavefront keep their current chunk (A)
+        // and the next one (B) in registers, 64 (column, value) pairs each
+        int pa_col[KS], pb_col[KS];
+        real pa_val[KS], pb_val[KS];
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int i = w + s * NW;
+            pa_col[s] = pb_col[s] = INF;
+            pa_val[s] = pb_val[s] = 0;
+            if (i < nlong) {
+                const int4 mt = l_meta[i];
+                const int ka = mt.x + lane, kb = ka + mt.z;
+                if (ka < mt.y) {
+                    pa_col[s] = bcol[ka];
+                    pa_val[s] = bval[ka];
+                }
+                if (kb < mt.y) {
+                    pb_col[s] = bcol[kb];
+                    pb_val[s] = bval[kb];
+                }
+            }
+        }
+        tick(0);
+        if (prof) t_acc[6]++;
         int pos = crpt[rid];
         for (int t0 = 0; t0 < span; t0 += W) {
             const int tw = span - t0 < W ? span - t0 : W;  // columns in this tile
-            const int c0 = lo + t0, c1 = c0 + tw;
-            for (int i = threadIdx.x; i < tw; i += BS) dense[i] = 0;
-            for (int i = threadIdx.x; i < (tw + 3) / 4; i += BS) flag4[i] = 0;
-            __syncthreads();
-            // long B rows: one wavefront per row, 64 consecutive (sorted) entries per step; the
-            // entries inside the tile are a prefix of the 64
-            for (int i = w; i < nlong; i += NW) {
-                int cur = l_cur[i];
-                const int end = l_end[i];
+            const int c0 = lo + t0, tile_end = c0 + tw;
+            auto acc = [&](int col, real x) {
+                const int idx = col - c0;
+                flag[idx] = 1;
+                unsafeAtomicAdd(dense + idx, x);
+            };
+            // ---- register-fed pass ---------------------------------------------------------
+            // Everything inside the tile that is already in registers is accumulated and its
+            // refill issued; a second trip is needed only by cursors that used up their whole
+            // look-ahead (64 in-tile entries of a long row, 2 of a short one), and then all of
+            // them wait for their refills together.
+            // A chunk serves every tile it overlaps (the range test has two sides) and is
+            // replaced only when its last column lies below the end of the tile.
+            bool more;
+            bool fresh[KS];
+#pragma unroll
+            for (int s = 0; s < KS; s++) fresh[s] = true;
+            do {
+                more = false;
+                if (prof) t_acc[10]++;
+#pragma unroll
+                for (int s = 0; s < KS; s++) {
+                    if (!fresh[s]) continue;  // wave-uniform
+                    if ((unsigned)(pa_col[s] - c0) < (unsigned)tw) acc(pa_col[s], l_av[w + s * NW] * pa_val[s]);
+                    fresh[s] = __builtin_amdgcn_readlane(pa_col[s], 63) < tile_end;
+                    if (fresh[s]) {  // chunk A used up: B moves in, the one after B is requested
+                        const int i = w + s * NW;
+                        int4 mt = l_meta[i];
+                        mt.x += mt.z;
+                        if (lane == 0) l_meta[i].x = mt.x;
+                        pa_col[s] = pb_col[s];
+                        pa_val[s] = pb_val[s];
+                        const int k = mt.x + mt.z + lane;
+                        const bool ok = k < mt.y;
+                        pb_col[s] = ok ? bcol[k] : INF;
+                        pb_val[s] = ok ? bval[k] : (real)0;
+                        more = true;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < EPT; u++) {
+                    if (e_c0[u] < tile_end) {
+                        acc(e_c0[u], e_av[u] * e_v0[u]);
+                        const bool two = e_c1[u] < tile_end;
+                        if (two) {
+                            acc(e_c1[u], e_av[u] * e_v1[u]);
+                            e_cur[u] += 2;
+                            const int k = e_cur[u];
+                            const bool ok = k < e_end[u];
+                            e_c0[u] = ok ? bcol[k] : INF;
+                            e_v0[u] = ok ? bval[k] : (real)0;
+                            more = true;
+                        } else {
+                            e_cur[u] += 1;
+                            e_c0[u] = e_c1[u];
+                            e_v0[u] = e_v1[u];
+                        }
+                        const int k1 = e_cur[u] + 1;
+                        const bool ok1 = k1 < e_end[u];
+                        e_c1[u] = ok1 ? bcol[k1] : INF;
+                        e_v1[u] = ok1 ? bval[k1] : (real)0;
+                    }
+                }
+            } while (__any(more));
+            if (prof) {
+                __syncthreads();
+                tick(2);
+            }
+            // ---- overflow paths: state in LDS / global memory --------------------------------
+            // sweep slots beyond the register ones: same chunk walk, one round trip per chunk
+            for (int i = w + KS * NW; i < nlong; i += NW) {
+                int4 mt = l_meta[i];
                 const real av = l_av[i];
                 while (true) {
-                    const int k = cur + lane;
-                    const int col = k < end ? bcol[k] : 0x7fffffff;
-                    const bool in = col < c1;
-                    const int n = __popcll(__ballot(in));
-                    if (in) {
-                        const int idx = col - c0;
-                        flag[idx] = 1;
-                        unsafeAtomicAdd(dense + idx, av * bval[k]);
-                    }
-                    cur += n;
-                    if (n < 64) break;
+                    const int k = mt.x + lane;
+                    const int col = k < mt.y ? bcol[k] : INF;
+                    const real bv = k < mt.y ? bval[k] : (real)0;
+                    if ((unsigned)(col - c0) < (unsigned)tw) acc(col, av * bv);
+                    if (__builtin_amdgcn_readlane(col, 63) >= tile_end) break;
+                    mt.x += mt.z;
                 }
-                if (lane == 0) l_cur[i] = cur;
+                if (lane == 0) l_meta[i].x = mt.x;
             }
-            // everything else: every lane advances the cursors of its own entries
-            for (int e = threadIdx.x; e < alen; e += BS) {
+            // A entries beyond EPT * BS: one product per memory round trip
+            for (int e = threadIdx.x + EPT * BS; e < alen; e += BS) {
                 int col = st_next[e];
-                if (col < c1) {
+                if (col < tile_end) {
                     int cur = st_cur[e];
                     const int end = st_end[e];
                     const real av = st_av[e];
                     do {
-                        const int idx = col - c0;
-                        flag[idx] = 1;
-                        unsafeAtomicAdd(dense + idx, av * bval[cur]);
+                        const real bv = bval[cur];
                         cur++;
-                        col = cur < end ? bcol[cur] : 0x7fffffff;
-                    } while (col < c1);
+                        const int ncol = cur < end ? bcol[cur] : INF;  // issued with bv
+                        acc(col, av * bv);
+                        col = ncol;
+                    } while (col < tile_end);
                     st_cur[e] = cur;
                     st_next[e] = col;
                 }
             }
-            __syncthreads();
-            // ordered emission of the tile: wave w owns [w*R, (w+1)*R)
-            const int R = ((tw + NW * 64 - 1) / (NW * 64)) * 64;
-            const int rb = w * R, re = rb + R < tw ? rb + R : tw;
+            lds_barrier();
+            tick(3);
+            // ---- ordered emission: wavefront w owns columns [w*R, (w+1)*R) of the tile -----
+            // all IT flag reads are issued together; columns past tw are clean, hence empty
+            const int r0 = w * R;
+            unsigned long long msk[IT];
             int cnt = 0;
-            for (int base = rb; base < re; base += 64) {
-                const int idx = base + lane;
-                cnt += __popcll(__ballot(idx < re && flag[idx] != 0));
+#pragma unroll
+            for (int j = 0; j < IT; j++) {
+                msk[j] = __ballot(flag[r0 + j * 64 + lane] != 0);
+                cnt += __popcll(msk[j]);
             }
             if (lane == 0) s_wcnt[w] = cnt;
-            __syncthreads();
+            tick(7);
+            lds_barrier();
+            tick(8);
             int wpos = pos, total = 0;
             for (int u = 0; u < NW; u++) {
                 const int c = s_wcnt[u];
                 if (u < w) wpos += c;
                 total += c;
             }
-            for (int base = rb; base < re; base += 64) {
-                const int idx = base + lane;
-                const bool occ = idx < re && flag[idx] != 0;
-                const unsigned long long m = __ballot(occ);
-                if (occ) {
+#pragma unroll
+            for (int j = 0; j < IT; j++) {
+                const unsigned long long m = msk[j];
+                if ((m >> lane) & 1ull) {
+                    const int idx = r0 + j * 64 + lane;
                     const int p = wpos + __popcll(m & ((1ull << lane) - 1ull));
                     if (write_col & 1) ccol[p] = c0 + idx;
                     cval[p] = dense[idx];
+                    dense[idx] = 0;  // leave the window clean for the next tile
+                    flag[idx] = 0;
                 }
                 wpos += __popcll(m);
             }
             pos += total;
-            __syncthreads();
+            tick(9);
+            lds_barrier();
+            tick(4);
+            if (prof) t_acc[5]++;
         }
     }
+    if (prof && threadIdx.x == 0)
+        for (int i = 0; i < 12; i++) atomicAdd(prof + i, t_acc[i]);
 }
 
 // ===================================================================================
@@ -1846,10 +2010,16 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         const long long stride_ints = 3LL * amax + (long long)amax * (sizeof(real) / sizeof(int));
         const int groups = rows < 1024 ? rows : 1024;
         int *slab = (int *)dev_alloc(sizeof(int) * (size_t)stride_ints * groups);
+        static const int tiled_prof = getenv("NSPARSE_TILED_PROF") ? atoi(getenv("NSPARSE_TILED_PROF")) : 0;
+        unsigned long long *d_prof = nullptr;
+        if (tiled_prof) {
+            d_prof = (unsigned long long *)dev_alloc(16 * sizeof(unsigned long long));
+            NSP_CHECK(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st));
+        }
 #define NSP_TILED(BSX, WX)                                                                     \
     hipLaunchKernelGGL((k_num_tiled<BSX, WX>), dim3(groups), dim3(BSX), 0, st, arpt, acol, aval, brpt, \
                        bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows,   \
-                       d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len)
+                       d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len, d_prof)
         if (tile_sel == 1) { NSP_TILED(1024, kTileW / 2); }
         else if (tile_sel == 2) { NSP_TILED(512, kTileW / 2); }
         else if (tile_sel == 3) { NSP_TILED(512, kTileW / 4); }
@@ -1858,6 +2028,14 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         NSP_LAUNCH_CHECK();
         NSP_CHECK(hipStreamSynchronize(st));
         L.end(kNumGlobalBin);
+        if (d_prof) {
+            unsigned long long h[16];
+            NSP_CHECK(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
+            const double us = 0.01 / groups;  // 100 MHz ticks summed over the workgroups
+            fprintf(stderr, "[tiled] groups %d rows %llu tiles %llu | per-group us: setup %.0f queue %.0f regs %.0f overflow %.0f emit %.0f+%.0f+%.0f+%.0f | trips %llu (long %llu)\n",
+                    groups, h[6], h[5], h[0] * us, h[1] * us, h[2] * us, h[3] * us, h[7] * us, h[8] * us, h[9] * us, h[4] * us, h[10], h[11]);
+            dev_free(d_prof);
+        }
         dev_free(slab);
     } else if (hist[kNumGlobalBin] > 0) {
         hipStream_t st = L.begin(kNumGlobalBin);
