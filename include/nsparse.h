@@ -223,7 +223,7 @@ int nsparse_spgemm_set_sorted(int on);
 /* Statistics of the last spgemm_kernel_hash call. */
 typedef struct {
     long long n_prod;         /* intermediate products                              */
-    int nnz_c;
+    long long nnz_c;          /* 64-bit: reported even when it does not fit sfCSR's int (error -40) */
     int max_prod_row;         /* longest row of intermediate products               */
     int max_nnz_row;          /* longest row of C                                   */
     int sym_bin_size[12];     /* rows per symbolic bin (0 tiny, 1-5 hash, 6-8 dense window, 9-10 bit window) */
@@ -278,7 +278,8 @@ int nsparse_load_csr_bin(sfCSR *mat, const char *path);
  *   kind 0: 3-dof 27-point brick  nx*ny*nz nodes  (cant class;   p0,p1,p2 = nx,ny,nz)
  *   kind 1: scalar 27-point grid  nx*ny*nz        (nlpkkt class; p0,p1,p2 = nx,ny,nz)
  *   kind 2: power-law web graph   p0 rows, ~p1 nnz              (webbase class)
- *   kind 3: R-MAT scale p0, edge factor p1, duplicates merged   (config 5)
+ *   kind 3: R-MAT scale p0, edge factor p1 (or exactly p2 edges when p2 > 0, for fractional
+ *           factors), duplicates merged                           (config 5)
  * Rows [row_begin,row_end) only (row_end <= 0: all rows) so that one rank of a
  * row-sharded run can generate just its block.                                  */
 void nsparse_synth_csr(sfCSR *mat, int kind, long long p0, long long p1, long long p2,

@@ -44,7 +44,7 @@ class sfAMB(C.Structure):
 
 
 class SpgemmStats(C.Structure):
-    _fields_ = [("n_prod", C.c_longlong), ("nnz_c", C.c_int), ("max_prod_row", C.c_int),
+    _fields_ = [("n_prod", C.c_longlong), ("nnz_c", C.c_longlong), ("max_prod_row", C.c_int),
                 ("max_nnz_row", C.c_int), ("sym_bin_size", C.c_int * 12), ("num_bin_size", C.c_int * 12),
                 ("sym_fail_rows", C.c_int), ("ms_setup", C.c_float), ("ms_symbolic", C.c_float),
                 ("ms_numeric", C.c_float), ("ms_total", C.c_float), ("ms_sym_bin", C.c_float * 12),

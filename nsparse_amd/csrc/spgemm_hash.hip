@@ -53,7 +53,6 @@
 namespace nsp {
 namespace spgemm {
 
-constexpr int HASH_SCAL = 107;  // same multiplier as the reference (kernel_spgemm_hash_d.cu:30)
 constexpr int NB = kMaxBins;
 
 // ---- bin ladders ------------------------------------------------------------------
@@ -142,13 +141,18 @@ __host__ __device__ __forceinline__ int bin_of(int n, int span, const Thr &thr)
     return b;
 }
 
-// Slot of a column id.  (key * 107) >> 2: keys that differ by 1 land ~27 slots apart and keys
-// that differ by 4 land 107 slots apart -- both odd strides, so neither the lanes of a V = 1
-// walk (consecutive columns) nor the VW = 4 walk (every lane holds 4 consecutive entries, so
-// one CAS instruction sees columns of stride 4) pile up on a few of the 32 LDS banks.
+// Slot of a column id in a table of mask + 1 = 2^L slots: the TOP L bits of key * 2^32/phi
+// (Fibonacci hashing).  The reference takes the LOW bits of key * 107
+// (kernel_spgemm_hash_d.cu:30,296), which only see the low bits of the key: column ids that
+// are multiples of a large power of two -- a large share of an R-MAT row, whose index bits are
+// 0 with probability 0.76 -- all start probing at the same slot, and a scale-22 row of 25 K
+// columns degenerates into long linear-probe clusters (measured, R-MAT scale 22: symbolic
+// 665 -> 116 ms, whole call 1076 -> 458 ms).  The top bits depend on every bit of the key; consecutive
+// columns land 0.618 * 2^L slots apart, so FEM rows spread evenly as well.  The table
+// contents differ from the reference's, the rows that come out of them do not.
 __device__ __forceinline__ int hash_slot(int key, int mask)
 {
-    return (int)((((unsigned)key * (unsigned)HASH_SCAL) >> 2) & (unsigned)mask);
+    return (int)(((unsigned)key * 0x9E3779B1u) >> __builtin_clz((unsigned)mask));
 }
 
 __device__ __forceinline__ int pow2_ceil(int v) { return v <= 1 ? 1 : (1 << (32 - __clz(v - 1))); }
@@ -182,7 +186,8 @@ __device__ __forceinline__ int ht_find_or_insert(int *tab, int mask, int key, in
 // worst cost one extra CAS.
 __device__ __forceinline__ long long gt_find_or_insert(int *tab, long long mask, int key, int *fresh)
 {
-    long long h = ((long long)key * HASH_SCAL) & mask;
+    long long h = (long long)(((unsigned long long)(unsigned)key * 0x9E3779B97F4A7C15ull) >>
+                              __builtin_clzll((unsigned long long)mask));
     *fresh = 0;
     while (true) {
         const int cur = __hip_atomic_load(tab + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -651,8 +656,12 @@ __global__ __launch_bounds__(1024) void k_hist(const int *__restrict__ n, const 
 {
     __shared__ int s_hist[NB];
     __shared__ int s_max;
+    __shared__ unsigned long long s_sum;  // 64-bit: the int scan of the same numbers may wrap
     if (threadIdx.x < NB) s_hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_max = 0;
+    if (threadIdx.x == 0) {
+        s_max = 0;
+        s_sum = 0;
+    }
     __syncthreads();
     const int i = blockIdx.x * 1024 + threadIdx.x;  // 1024 rows per block: 4x fewer same-address
     int bin = -1, v = 0;                             // global atomics at the end
@@ -668,15 +677,23 @@ __global__ __launch_bounds__(1024) void k_hist(const int *__restrict__ n, const 
         if ((threadIdx.x & 63) == leader) atomicAdd(&s_hist[b], __popcll(same));
         todo &= ~same;
     }
+    unsigned long long sum = (unsigned long long)v;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const int m = __shfl_xor(v, o);
         v = m > v ? m : v;
+        sum += __shfl_xor(sum, o);
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(&s_max, v);
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&s_max, v);
+        atomicAdd(&s_sum, sum);
+    }
     __syncthreads();
     if (threadIdx.x < NB && s_hist[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], s_hist[threadIdx.x]);
-    if (threadIdx.x == 0) atomicMax(&bs->maxv, s_max);
+    if (threadIdx.x == 0) {
+        atomicMax(&bs->maxv, s_max);
+        if (s_sum) atomicAdd((unsigned long long *)&bs->total, s_sum);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_row_len(const int *__restrict__ rpt, int *__restrict__ len, int M)
@@ -2088,6 +2105,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     const int M = a->M;
     nsparse_spgemm_stats &S = g_stats.s;
     memset(&S, 0, sizeof(S));
+    bool too_big = false;
     tm.mark(0, s0);
 
     BinState *d_sym = reinterpret_cast<BinState *>(cx.d_scratch);
@@ -2204,13 +2222,18 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     for (int q = 0; q < NB; q++) S.num_bin_size[q] = h_num->hist[q];
     S.max_nnz_row = h_num->maxv;
     if (!numeric_only) {
+        // upstream keeps nnz(C) and C.rpt in int (nsparse.h:62-75) and wraps silently; refuse
+        too_big = h_num->total > 0x7fffffffLL;
+    }
+    if (!numeric_only && !too_big) {
         c->nnz = h_num->nnz;
         c->d_col = (int *)dev_alloc(sizeof(int) * (size_t)(c->nnz > 0 ? c->nnz : 1));
         c->d_val = (real *)dev_alloc(sizeof(real) * (size_t)(c->nnz > 0 ? c->nnz : 1));
     }
-    S.nnz_c = c->nnz;
+    S.nnz_c = too_big ? h_num->total : c->nnz;
 
     // ---- numeric --------------------------------------------------------------------
+    if (!too_big) {
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_maxb, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
@@ -2229,6 +2252,14 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     S.ms_symbolic = tm.ms(1, 2);
     S.ms_numeric = tm.ms(2, 3);
     S.ms_total = tm.ms(0, 3);
+    } else {
+        NSP_CHECK(hipStreamSynchronize(s0));
+        dev_free(c->d_rpt);
+        c->d_rpt = nullptr;
+        c->d_col = nullptr;
+        c->d_val = nullptr;
+        c->nnz = 0;
+    }
 
     dev_free(scan_tmp);
     dev_free(bm);
@@ -2245,6 +2276,11 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     dev_free(row_perm);
     dev_free(row_nz);
     dev_free(row_prod);
+    if (too_big) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "nnz(C) = %lld does not fit the int row pointers of sfCSR", (long long)S.nnz_c);
+        set_error(-40, msg, __FILE__, __LINE__);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_flop(const int *__restrict__ arpt, const int *__restrict__ acol,

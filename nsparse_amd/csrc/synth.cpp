@@ -150,9 +150,10 @@ void gen_powerlaw(sfCSR *mat, long long n, long long target_nnz, unsigned long l
 
 // R-MAT (a,b,c,d) = (0.57,0.19,0.19,0.05), no vertex permutation, duplicates merged with
 // summed values.
-void gen_rmat(sfCSR *mat, int scale, long long ef, unsigned long long seed, long long rb, long long re)
+void gen_rmat(sfCSR *mat, int scale, long long ef, long long edges, unsigned long long seed, long long rb,
+              long long re)
 {
-    const long long n = 1LL << scale, m = n * ef;
+    const long long n = 1LL << scale, m = edges > 0 ? edges : n * ef;
     if (re <= 0 || re > n) re = n;
     if (rb < 0) rb = 0;
     std::vector<unsigned long long> e;
@@ -202,7 +203,7 @@ extern "C" void nsparse_synth_csr(sfCSR *mat, int kind, long long p0, long long 
         case 0: gen_stencil(mat, 3, p0, p1, p2, seed, row_begin, row_end); break;
         case 1: gen_stencil(mat, 1, p0, p1, p2, seed, row_begin, row_end); break;
         case 2: gen_powerlaw(mat, p0, p1, seed, row_begin, row_end); break;
-        case 3: gen_rmat(mat, (int)p0, p1, seed, row_begin, row_end); break;
+        case 3: gen_rmat(mat, (int)p0, p1, p2, seed, row_begin, row_end); break;
         default:
             fprintf(stderr, "nsparse_synth_csr: unknown kind %d\n", kind);
             memset(mat, 0, sizeof(*mat));

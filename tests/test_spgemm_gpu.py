@@ -241,3 +241,31 @@ def test_full_size_cant_class_properties(lib_d, oracle_d):
     A2 = dict(A, val=A["val"] * 3.0)
     got2, _ = spgemm(lib_d, A2)
     np.testing.assert_allclose(got2["val"], 9.0 * got["val"], rtol=1e-9)
+
+
+def test_nnz_c_beyond_int_is_refused():
+    """nnz(C) >= 2^31 cannot be represented by sfCSR (int rpt / nnz, nsparse.h:62-75); upstream
+    wraps silently.  Here: error -40, no C arrays, the true count in the statistics; and an abort
+    without NSPARSE_NO_ABORT.  A = ones(M x 1), B = ones(1 x N): C is dense M x N."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, ctypes as C, numpy as np; sys.path.insert(0, %r);"
+        "import nsparse_amd as ns; lib = ns.load('d'); M, N = 65536, 32769;"
+        "a = lib.csr_from_numpy(np.arange(M + 1, dtype=np.int32), np.zeros(M, np.int32), np.ones(M), 1);"
+        "b = lib.csr_from_numpy(np.array([0, N], np.int32), np.arange(N, dtype=np.int32), np.ones(N), N);"
+        "lib.csr_memcpy(C.byref(a)); lib.csr_memcpy(C.byref(b)); c = ns.sfCSR();"
+        "lib.spgemm_kernel_hash(C.byref(a), C.byref(b), C.byref(c));"
+        "st = ns.SpgemmStats(); lib.nsparse_get_spgemm_stats(C.byref(st));"
+        "print('RESULT', lib.nsparse_last_error(), st.nnz_c, c.nnz, bool(c.d_col), bool(c.d_rpt))"
+    ) % root
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                       env=dict(os.environ, NSPARSE_NO_ABORT="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")][-1].split()
+    assert line[1:] == ["-40", str(65536 * 32769), "0", "False", "False"], line
+    assert "does not fit" in r.stderr
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
+                       env={k: v for k, v in os.environ.items() if k != "NSPARSE_NO_ABORT"})
+    assert r.returncode != 0 and "does not fit" in r.stderr
