@@ -190,8 +190,8 @@ def main():
     crpt = lib.d2h(c.d_rpt, (c.M + 1,), np.int32)
     nnz_c = c.nnz
     lib.release_csr(c)
-    sym_thr = (C.c_int * 13)()
-    num_thr = (C.c_int * 13)()
+    sym_thr = (C.c_int * 15)()
+    num_thr = (C.c_int * 15)()
     lib.nsparse_get_spgemm_bins(sym_thr, num_thr)
     bytes_bin, prods_bin, row_prod = numeric_bin_bytes(A_loc, A_full, crpt, list(sym_thr), list(num_thr), w)
     dom = int(np.argmax(bin_ms))

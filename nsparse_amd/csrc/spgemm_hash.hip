@@ -47,6 +47,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 
 #include "internal.h"
 
@@ -87,9 +88,13 @@ struct Thr {
     int bits_span[2];    // symbolic only: span <= bits_span[k] -> bin 9 + k (1 bit per column)
     int bits_ratio;      // span <= bits_ratio * n; 0 disables
     int bits_min;        // only rows with n > bits_min (small rows hash faster than they clear)
+    int bits_wide_min;   // rows with n > bits_wide_min (they would fill the two largest hash tables to
+    int bits_wide_span;  // the brim, or overflow them) and span <= bits_wide_span -> bin 10, which
+                         // then covers the window in pieces of bits_span[1] columns; 0 disables
 };
-constexpr Thr kSymThr = {32, {512, 2048, 8192, 32768}, {4096, 16384, 65536}, 8, {262144, 1048576}, 64, 2048};
-constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8, {0, 0}, 0, 0};
+constexpr Thr kSymThr = {32,   {512, 2048, 8192, 32768}, {4096, 16384, 65536}, 8, {262144, 1048576}, 64, 2048,
+                         8192, 16 * 1048576};
+constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8, {0, 0}, 0, 0, 0, 0};
 constexpr int kSymLargeBin = 5;
 constexpr int kNumGlobalBin = 5;
 // Setup kernels: rows longer than kLongFactor * W entries are not walked by their W-lane group
@@ -118,7 +123,7 @@ struct BinState {
     long long bm_total;  // words of column bitmaps (dense window rows)
     long long max_alen;  // longest row of A
     int b_unsorted;      // some row of B does not have strictly ascending columns
-    int pad;
+    int queue_head2;     // second persistent-kernel queue of the heavy numeric bin
 };
 
 struct Stats {
@@ -135,6 +140,9 @@ __host__ __device__ __forceinline__ int bin_of(int n, int span, const Thr &thr)
     if (thr.bits_ratio > 0 && n > thr.bits_min && span > 0 && span <= thr.bits_span[1] &&
         (long long)span <= (long long)thr.bits_ratio * n)
         return kBitsBin0 + (span > thr.bits_span[0]);
+    if (thr.bits_ratio > 0 && thr.bits_wide_min > 0 && n > thr.bits_wide_min && span > 0 &&
+        span <= thr.bits_wide_span)
+        return kBitsBin0 + 1;
     int b = 1;
 #pragma unroll
     for (int q = 0; q < 4; q++) b += (n > thr.hash_t[q]) ? 1 : 0;
@@ -1276,30 +1284,37 @@ __global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, c
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
     const int rid = row_perm[bin_off + slot];
-    const int lo = row_lo[rid];
-    const int words = (row_span[rid] + 31) >> 5;
-    {
-        uint4 *b4 = reinterpret_cast<uint4 *>(bits);
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        for (int i = threadIdx.x; i < (words + 3) / 4; i += BS) b4[i] = z;
-    }
-    if (threadIdx.x == 0) s_nz = 0;
-    __syncthreads();
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
     const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
-    walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
-                             a_end, g, s_ext, (real *)nullptr,
-                             [&](const IVec &k, const RVec &, int n, real) {
-#pragma unroll
-                                 for (int i = 0; i < VW; i++)
-                                     if (i < n) {
-                                         const int idx = k.v[i] - lo;
-                                         atomicOr(bits + (idx >> 5), 1u << (idx & 31));
-                                     }
-                             });
-    __syncthreads();
+    if (threadIdx.x == 0) s_nz = 0;
     int cnt = 0;
-    for (int i = threadIdx.x; i < words; i += BS) cnt += __popc(bits[i]);
+    // A window wider than the bitmap is covered in pieces: every piece walks all products again
+    // and keeps the columns that fall into it (no cursors: the walk is a fraction of what a hash
+    // table filled to the brim costs, and the row need not be sorted).
+    const int row_hi = row_lo[rid] + row_span[rid];
+    for (int lo = row_lo[rid]; lo < row_hi; lo += WORDS_MAX * 32) {
+        const int cols = row_hi - lo < WORDS_MAX * 32 ? row_hi - lo : WORDS_MAX * 32;
+        const int words = (cols + 31) >> 5;
+        {
+            uint4 *b4 = reinterpret_cast<uint4 *>(bits);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (int i = threadIdx.x; i < (words + 3) / 4; i += BS) b4[i] = z;
+        }
+        __syncthreads();
+        walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
+                                 a_end, g, s_ext, (real *)nullptr,
+                                 [&](const IVec &k, const RVec &, int n, real) {
+#pragma unroll
+                                     for (int i = 0; i < VW; i++)
+                                         if (i < n) {
+                                             const unsigned int idx = (unsigned int)(k.v[i] - lo);
+                                             if (idx < (unsigned int)cols) atomicOr(bits + (idx >> 5), 1u << (idx & 31));
+                                         }
+                                 });
+        __syncthreads();
+        for (int i = threadIdx.x; i < words; i += BS) cnt += __popc(bits[i]);
+        __syncthreads();
+    }
     cnt = wave_sum(cnt);
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
     __syncthreads();
@@ -1397,6 +1412,19 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
 // waits for the acknowledgement of every global store issued before it; the tiled kernel
 // emits a tile with global stores nobody in the workgroup reads back, so waiting for them
 // once per tile (a full HBM round trip) is pure stall.
+// Inclusive prefix sum over the 64 lanes in registers (DPP row shifts + row broadcasts); the
+// __shfl_up form goes through the LDS crossbar six times.
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1424,7 +1452,7 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                                                   BinState *bs, const int *__restrict__ row_lo,
                                                   const int *__restrict__ row_span, int *__restrict__ slab,
                                                   long long stride_ints, int amax, int write_col,
-                                                  int LONG_LEN, unsigned long long *prof)
+                                                  int LONG_LEN, unsigned long long *prof, int dens)
 {
     // prof (NSPARSE_TILED_PROF=1): thread 0 adds 100 MHz ticks per phase -- 0 cursor set-up,
     // 2 register-fed accumulation, 3 overflow paths, 4 emission, 5 tiles, 6 rows
@@ -1477,6 +1505,9 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
         tick(1);  // queue + barriers
         const int rid = row_perm[bin_off + q];
         const int lo = row_lo[rid], span = row_span[rid];
+        // dens > 0: rows thinner than one non-zero per `dens` columns, or wider than 32 tiles, are
+        // left to k_num_ranked
+        if (dens > 0 && ((long long)(crpt[rid + 1] - crpt[rid]) * dens < span || span > 32 * W)) continue;
         const int a_beg = arpt[rid], alen = arpt[rid + 1] - a_beg;
         // ---- cursor set-up ------------------------------------------------------------
         // Entry e of the A row is always handled by thread e % BS.  Its cursor into B row
@@ -1711,6 +1742,375 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
     }
     if (prof && threadIdx.x == 0)
         for (int i = 0; i < 12; i++) atomicAdd(prof + i, t_acc[i]);
+}
+
+// ===================================================================================
+//  heavy numeric rows, sparse flavour: bitmap-ranked accumulator
+// ===================================================================================
+// A heavy row whose columns are spread thinly over a wide window (R-MAT scale 22: 18 K non-zeros
+// over 4 M columns) would need hundreds of almost empty dense tiles.  Here LDS holds 8 bytes per
+// NON-ZERO instead of 9 bytes per column: a tile is a bitmap over W columns plus a value array
+// of CAP entries addressed by rank.
+//   pass 1  walk the products of the tile, set the bit of every column           (ds_or)
+//   scan    per-word exclusive prefix of the popcounts; if the tile holds more than CAP
+//           columns it is cut at the word where the prefix crosses CAP
+//   pass 2  walk again, accumulate a*b at  prefix[word] + popcount(bits below)    (ds_add)
+//   emit    values are already in ascending column order and contiguous; the columns are
+//           read off the bitmap
+// Cursors advance only in pass 2, so the cut costs nothing but the re-walk of the columns
+// beyond it.  Same cursor scheme as k_num_tiled: lane-serial entries (4 look-ahead loads per
+// step), long B rows dealt out in 64-entry chunks to wavefront sweep slots.
+template <int BS, int W, int CAP>
+__global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                   const real *__restrict__ aval,
+                                                   const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                   const real *__restrict__ bval,
+                                                   const int *__restrict__ crpt, int *__restrict__ ccol,
+                                                   real *__restrict__ cval,
+                                                   const int *__restrict__ row_perm, int bin_off, int count,
+                                                   BinState *bs, const int *__restrict__ row_lo,
+                                                   const int *__restrict__ row_span, int *__restrict__ slab,
+                                                   long long stride_ints, int amax, int write_col,
+                                                   int LONG_LEN, int dens, int tiled_w,
+                                                   unsigned long long *prof)
+{
+    // prof (NSPARSE_TILED_PROF=1), 100 MHz ticks of thread 0: 0 set-up, 1 pass 1, 2 scan, 3 pass 2,
+    // 4 emission; 5 tiles, 6 rows
+    unsigned long long tk = prof ? wall_clock64() : 0;
+    unsigned long long t_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&](int phase) {
+        if (prof) {
+            const unsigned long long now = wall_clock64();
+            t_acc[phase] += now - tk;
+            tk = now;
+        }
+    };
+    constexpr int NW = BS / 64;
+    constexpr int LCAP = BS, EPT = 4, VMAX = 32, LA = 4;
+    constexpr int INF = 0x7fffffff;
+    constexpr int NWORD = W / 32;
+    static_assert(NWORD == 8 * BS, "eight bitmap words per thread");
+    static_assert(CAP <= 65535, "ranks are kept in 16 bits");
+    __shared__ __attribute__((aligned(16))) unsigned int bits[NWORD];
+    __shared__ __attribute__((aligned(16))) unsigned short pref[NWORD];
+    __shared__ __attribute__((aligned(16))) real vals[CAP];
+    __shared__ int4 l_meta[LCAP];
+    __shared__ real l_av[LCAP];
+    __shared__ int s_row, s_nlong, s_cut, s_ntile, s_total;
+    __shared__ int s_wsum[8 * NW];
+    int *st_cur = slab + (long long)blockIdx.x * stride_ints;
+    int *st_end = st_cur + amax;
+    int *st_next = st_end + amax;
+    real *st_av = reinterpret_cast<real *>(st_next + amax);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < NWORD; i += BS) bits[i] = 0;
+    for (int i = threadIdx.x; i < CAP; i += BS) vals[i] = 0;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_row = atomicAdd(&bs->queue_head2, 1);
+            s_nlong = 0;
+        }
+        __syncthreads();
+        const int q = s_row;
+        if (q >= count) break;
+        const int rid = row_perm[bin_off + q];
+        const int lo = row_lo[rid], span = row_span[rid];
+        int pos = crpt[rid];
+        // dens > 0: only rows thinner than one non-zero per `dens` columns or wider than 32 dense
+        // tiles (the rest belong to k_num_tiled); dens <= 0: every row
+        if (dens > 0 && (long long)(crpt[rid + 1] - pos) * dens >= span && span <= 32 * tiled_w) continue;
+        const int a_beg = arpt[rid], alen = arpt[rid + 1] - a_beg;
+        const int split = 64 * ((span + W - 1) / W + (crpt[rid + 1] - pos) / CAP + 1);
+        auto init_entry = [&](int e, int &cur, int &end, real &av) -> bool {
+            const int c = acol[a_beg + e];
+            cur = brpt[c];
+            end = brpt[c + 1];
+            av = aval[a_beg + e];
+            const int len = end - cur;
+            if (len <= LONG_LEN) return true;
+            int V = (len + split - 1) / split;
+            V = V < 1 ? 1 : (V > VMAX ? VMAX : V);
+            const int li = atomicAdd(&s_nlong, V);
+            const bool fits = li + V <= LCAP;
+            for (int v = 0; v < V && li + v < LCAP; v++) {
+                l_meta[li + v] = fits ? make_int4(cur + 64 * v, end, 64 * V, 0) : make_int4(0, 0, 64, 0);
+                l_av[li + v] = av;
+            }
+            return !fits;  // true: lane-serial
+        };
+        int e_cur[EPT], e_end[EPT], e_nc[EPT];
+        real e_av[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            const int e = threadIdx.x + u * BS;
+            e_cur[u] = e_end[u] = 0;
+            e_nc[u] = INF;
+            e_av[u] = 0;
+            if (e < alen && init_entry(e, e_cur[u], e_end[u], e_av[u]) && e_cur[u] < e_end[u])
+                e_nc[u] = bcol[e_cur[u]];
+        }
+        for (int e = threadIdx.x + EPT * BS; e < alen; e += BS) {
+            int cur, end;
+            real av;
+            const bool serial = init_entry(e, cur, end, av);
+            st_cur[e] = cur;
+            st_end[e] = end;
+            st_next[e] = (serial && cur < end) ? bcol[cur] : INF;
+            st_av[e] = av;
+        }
+        __syncthreads();
+        const int nlong = s_nlong < LCAP ? s_nlong : LCAP;
+        const int row_end = lo + span;
+        int t_lo = lo;
+        tick(0);
+        if (prof) {
+            t_acc[6]++;
+            t_acc[10] += nlong;
+            t_acc[11] += alen;
+            t_acc[12] += s_nlong > LCAP;
+        }
+        while (t_lo < row_end) {
+            // Pass 1 runs to t_max and everything beyond the cut is walked again by the next tile,
+            // so t_max aims at ~7/8 of CAP columns at the density of what is left of the row.
+            int t_max;
+            {
+                const long long rem_nnz = crpt[rid + 1] - pos, rem_span = row_end - t_lo;
+                long long wd_est = rem_nnz > 0 ? (long long)(CAP - CAP / 8) * rem_span / rem_nnz : rem_span;
+                wd_est = (wd_est + 31) & ~31LL;
+                if (wd_est > W) wd_est = W;
+                if (wd_est < 1024) wd_est = 1024;
+                t_max = rem_span <= wd_est ? row_end : t_lo + (int)wd_est;
+            }
+            // One walk of everything inside [t_lo, t_hi).  PASS2 = false: mark columns.
+            // PASS2 = true: accumulate by rank and commit the cursors.
+            auto touch = [&](auto pass2, int col, real x) {
+                const unsigned int idx = (unsigned int)(col - t_lo);
+                if (!decltype(pass2)::value) {
+                    atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+                } else {
+                    const unsigned int below = bits[idx >> 5] & ((1u << (idx & 31)) - 1u);
+                    unsafeAtomicAdd(vals + (int)pref[idx >> 5] + __popc(below), x);
+                }
+            };
+            // lane-serial entries: LA consecutive (column, value) pairs per round trip; the first
+            // batch of all register entries is requested before any of it is used
+            auto load_batch = [&](auto pass2, int k, int end, int c0, int(&c)[LA], real(&v)[LA]) {
+                c[0] = c0;
+#pragma unroll
+                for (int j = 1; j < LA; j++) c[j] = k + j < end ? bcol[k + j] : INF;
+                if (decltype(pass2)::value) {
+#pragma unroll
+                    for (int j = 0; j < LA; j++) v[j] = k + j < end ? bval[k + j] : (real)0;
+                }
+            };
+            // uses the leading pairs that lie inside the tile; returns how many, and the column after them
+            auto consume = [&](auto pass2, int t_hi, const int(&c)[LA], const real(&v)[LA], real av, int &next) -> int {
+                int n = 0;
+                next = INF;
+#pragma unroll
+                for (int j = 0; j < LA; j++) {
+                    if (n == j) {
+                        if (c[j] < t_hi) {
+                            touch(pass2, c[j], decltype(pass2)::value ? av * v[j] : (real)0);
+                            n = j + 1;
+                        } else {
+                            next = c[j];
+                        }
+                    }
+                }
+                return n;
+            };
+            // after a batch that was used up completely: keep going, one round trip per batch
+            auto walk_rest = [&](auto pass2, int t_hi, int &k, int end, int &col, real av) {
+                col = k < end ? bcol[k] : INF;
+                while (col < t_hi) {
+                    int c[LA];
+                    real v[LA];
+                    load_batch(pass2, k, end, col, c, v);
+                    const int n = consume(pass2, t_hi, c, v, av, col);
+                    k += n;
+                    if (n < LA) return;
+                    col = k < end ? bcol[k] : INF;
+                }
+            };
+            auto walk = [&](auto pass2, int t_hi) {
+                constexpr bool P2 = decltype(pass2)::value;
+                // sweep slots: 64-entry chunks, two-sided range test (a chunk may straddle tiles);
+                // the current chunks of SB slots are requested together, and the first such batch
+                // together with the first pair of register entries: one round trip for both
+                constexpr int SB = 4;
+                auto sweep_load = [&](int i0, int4(&mt)[SB], int(&col)[SB], real(&bv)[SB]) {
+#pragma unroll
+                    for (int j = 0; j < SB; j++) {
+                        const int i = i0 + j * NW;
+                        mt[j] = i < nlong ? l_meta[i] : make_int4(0, 0, 64, 0);
+                        const int kk = mt[j].x + lane;
+                        col[j] = kk < mt[j].y ? bcol[kk] : INF;
+                        bv[j] = 0;
+                        if (P2) bv[j] = kk < mt[j].y ? bval[kk] : (real)0;
+                    }
+                };
+                auto sweep_use = [&](int i0, const int4(&mt)[SB], const int(&col)[SB], const real(&bv)[SB]) {
+#pragma unroll
+                    for (int j = 0; j < SB; j++) {
+                        const int i = i0 + j * NW;
+                        if (i >= nlong) continue;
+                        const real av = l_av[i];
+                        int k = mt[j].x, c = col[j];
+                        real x = bv[j];
+                        while (true) {
+                            if (c >= t_lo && c < t_hi) touch(pass2, c, av * x);
+                            if (__builtin_amdgcn_readlane(c, 63) >= t_hi) break;
+                            k += mt[j].z;
+                            const int kk = k + lane;
+                            c = kk < mt[j].y ? bcol[kk] : INF;
+                            if (P2) x = kk < mt[j].y ? bval[kk] : (real)0;
+                        }
+                        if (P2 && lane == 0) l_meta[i].x = k;
+                    }
+                };
+                auto entries_load = [&](int u0, int(&c)[2][LA], real(&v)[2][LA]) {
+#pragma unroll
+                    for (int d = 0; d < 2; d++)
+                        if (e_nc[u0 + d] < t_hi) load_batch(pass2, e_cur[u0 + d], e_end[u0 + d], e_nc[u0 + d], c[d], v[d]);
+                };
+                auto entries_use = [&](int u0, const int(&c)[2][LA], const real(&v)[2][LA]) {
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        const int u = u0 + d;
+                        if (e_nc[u] < t_hi) {
+                            int col;
+                            const int n = consume(pass2, t_hi, c[d], v[d], e_av[u], col);
+                            int k = e_cur[u] + n;
+                            if (n == LA) walk_rest(pass2, t_hi, k, e_end[u], col, e_av[u]);
+                            if (P2) {
+                                e_cur[u] = k;
+                                e_nc[u] = col;
+                            }
+                        }
+                    }
+                };
+                {
+                    int4 mt[SB];
+                    int col[SB];
+                    real bv[SB];
+                    int c[2][LA];
+                    real v[2][LA];
+                    if (w < nlong) sweep_load(w, mt, col, bv);
+                    entries_load(0, c, v);
+                    if (w < nlong) sweep_use(w, mt, col, bv);
+                    entries_use(0, c, v);
+                    static_assert(EPT == 4, "two pairs of register entries");
+                    entries_load(2, c, v);
+                    entries_use(2, c, v);
+                    for (int i0 = w + SB * NW; i0 < nlong; i0 += SB * NW) {
+                        sweep_load(i0, mt, col, bv);
+                        sweep_use(i0, mt, col, bv);
+                    }
+                }
+                for (int e = threadIdx.x + EPT * BS; e < alen; e += BS) {
+                    int col = st_next[e];
+                    if (col < t_hi) {
+                        const int end = st_end[e];
+                        const real av = st_av[e];
+                        int c[LA];
+                        real v[LA];
+                        int k = st_cur[e];
+                        load_batch(pass2, k, end, col, c, v);
+                        const int n = consume(pass2, t_hi, c, v, av, col);
+                        k += n;
+                        if (n == LA) walk_rest(pass2, t_hi, k, end, col, av);
+                        if (P2) {
+                            st_cur[e] = k;
+                            st_next[e] = col;
+                        }
+                    }
+                }
+            };
+            walk(std::false_type{}, t_max);
+            lds_barrier();
+            tick(t_lo == lo ? 7 : 1);
+            // ---- scan: thread t owns words t, t + BS, ..., t + 7 BS ----------------------------
+            // (strided, so that the dense low-column stretch of a power-law row is shared by many
+            // threads when the columns are written out)
+            unsigned int wd[8];
+            int pc[8];  // becomes the exclusive prefix of the word
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                wd[j] = bits[threadIdx.x + j * BS];
+                const int c = __popc(wd[j]);
+                const int incl = wave_incl_scan(c);
+                pc[j] = incl - c;
+                if (lane == 63) s_wsum[j * NW + w] = incl;
+            }
+            if (threadIdx.x == 0) s_cut = t_max;
+            lds_barrier();
+            if (w == 0) {  // 8 * NW partial sums in (segment, wavefront) order -> exclusive offsets
+                static_assert(8 * NW <= 128, "two partial sums per lane");
+                const int i0 = 2 * lane, i1 = 2 * lane + 1;
+                const int a0 = i0 < 8 * NW ? s_wsum[i0] : 0, a1 = i1 < 8 * NW ? s_wsum[i1] : 0;
+                const int incl = wave_incl_scan(a0 + a1);
+                if (i0 < 8 * NW) s_wsum[i0] = incl - a0 - a1;
+                if (i1 < 8 * NW) s_wsum[i1] = incl - a1;
+                if (lane == 63) s_total = incl;
+            }
+            lds_barrier();
+            const int total = s_total;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                pc[j] += s_wsum[j * NW + w];
+                pref[threadIdx.x + j * BS] = (unsigned short)pc[j];
+            }
+            if (total > CAP) {  // cut at the word where the running count would pass CAP
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int p1 = pc[j] + __popc(wd[j]);
+                    if (pc[j] <= CAP && p1 > CAP) {
+                        s_cut = t_lo + 32 * (threadIdx.x + j * BS);
+                        s_ntile = pc[j];
+                    }
+                }
+            } else if (threadIdx.x == 0) {
+                s_ntile = total;
+            }
+            lds_barrier();
+            const int t_hi = s_cut, ntile = s_ntile;
+            tick(2);
+            if (prof && t_hi != t_max) t_acc[9]++;
+            walk(std::true_type{}, t_hi);
+            lds_barrier();
+            tick(t_lo == lo ? 8 : 3);
+            // ---- emission (words and prefixes are read back: not kept live across pass 2) ------
+            if (write_col & 1) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    unsigned int m = bits[threadIdx.x + j * BS];
+                    const int cbase = t_lo + 32 * (threadIdx.x + j * BS);
+                    int p = pos + (int)pref[threadIdx.x + j * BS];
+                    if (cbase < t_hi) {
+                        while (m) {
+                            ccol[p++] = cbase + __builtin_ctz(m);
+                            m &= m - 1;
+                        }
+                    }
+                }
+            }
+            for (int r = threadIdx.x; r < ntile; r += BS) {
+                cval[pos + r] = vals[r];
+                vals[r] = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) bits[threadIdx.x + j * BS] = 0;
+            pos += ntile;
+            t_lo = t_hi;
+            lds_barrier();
+            tick(4);
+            if (prof) t_acc[5]++;
+        }
+    }
+    if (prof && threadIdx.x == 0)
+        for (int i = 0; i < 13; i++) atomicAdd(prof + 16 + i, t_acc[i]);
 }
 
 // ===================================================================================
@@ -2017,9 +2417,13 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     static const int tiled_on = !(getenv("NSPARSE_TILED") && getenv("NSPARSE_TILED")[0] == '0');
     static const int long_len = getenv("NSPARSE_TILED_LONG") ? atoi(getenv("NSPARSE_TILED_LONG")) : 128;
     static const int tile_sel = getenv("NSPARSE_TILED_W") ? atoi(getenv("NSPARSE_TILED_W")) : 0;
-    // tiles per row <= 1024 keeps the fixed per-tile cost bounded; wider matrices hash globally
+    // rows with fewer than one non-zero per ranked_dens columns of their window take the ranked
+    // kernel (0: none, < 0: all)
+    static const int ranked_dens = getenv("NSPARSE_RANKED_DENS") ? atoi(getenv("NSPARSE_RANKED_DENS")) : 12;
+    // dense tiles alone: at most 1024 per row, wider matrices hash globally; with the ranked kernel
+    // taking the wide rows there is no limit
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
-                           (long long)b->N <= (long long)kTileW * 1024;
+                           (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
     if (use_tiled) {
         hipStream_t st = L.begin(kNumGlobalBin);
         const int rows = hist[kNumGlobalBin];
@@ -2030,27 +2434,40 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         static const int tiled_prof = getenv("NSPARSE_TILED_PROF") ? atoi(getenv("NSPARSE_TILED_PROF")) : 0;
         unsigned long long *d_prof = nullptr;
         if (tiled_prof) {
-            d_prof = (unsigned long long *)dev_alloc(16 * sizeof(unsigned long long));
-            NSP_CHECK(hipMemsetAsync(d_prof, 0, 16 * sizeof(unsigned long long), st));
+            d_prof = (unsigned long long *)dev_alloc(32 * sizeof(unsigned long long));
+            NSP_CHECK(hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), st));
         }
 #define NSP_TILED(BSX, WX)                                                                     \
     hipLaunchKernelGGL((k_num_tiled<BSX, WX>), dim3(groups), dim3(BSX), 0, st, arpt, acol, aval, brpt, \
                        bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows,   \
-                       d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len, d_prof)
-        if (tile_sel == 1) { NSP_TILED(1024, kTileW / 2); }
-        else if (tile_sel == 2) { NSP_TILED(512, kTileW / 2); }
-        else if (tile_sel == 3) { NSP_TILED(512, kTileW / 4); }
-        else { NSP_TILED(1024, kTileW); }
+                       d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len, d_prof, ranked_dens)
+        if (ranked_dens >= 0) {
+            if (tile_sel == 1) { NSP_TILED(1024, kTileW / 2); }
+            else if (tile_sel == 2) { NSP_TILED(512, kTileW / 2); }
+            else if (tile_sel == 3) { NSP_TILED(512, kTileW / 4); }
+            else { NSP_TILED(1024, kTileW); }
+        }
 #undef NSP_TILED
         NSP_LAUNCH_CHECK();
+        // thin rows: bitmap-ranked accumulator (same stream: both kernels want the whole LDS of a CU)
+        if (ranked_dens != 0) {
+            constexpr int kRankCap = sizeof(real) == 8 ? 10240 : 20480;
+            hipLaunchKernelGGL((k_num_ranked<1024, 262144, kRankCap>), dim3(groups), dim3(1024), 0, st, arpt, acol,
+                               aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin],
+                               rows, d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len,
+                               ranked_dens, tile_sel == 0 ? kTileW : (tile_sel == 3 ? kTileW / 4 : kTileW / 2), d_prof);
+            NSP_LAUNCH_CHECK();
+        }
         NSP_CHECK(hipStreamSynchronize(st));
         L.end(kNumGlobalBin);
         if (d_prof) {
-            unsigned long long h[16];
+            unsigned long long h[32];
             NSP_CHECK(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
             const double us = 0.01 / groups;  // 100 MHz ticks summed over the workgroups
             fprintf(stderr, "[tiled] groups %d rows %llu tiles %llu | per-group us: setup %.0f queue %.0f regs %.0f overflow %.0f emit %.0f+%.0f+%.0f+%.0f | trips %llu (long %llu)\n",
                     groups, h[6], h[5], h[0] * us, h[1] * us, h[2] * us, h[3] * us, h[7] * us, h[8] * us, h[9] * us, h[4] * us, h[10], h[11]);
+            fprintf(stderr, "[ranked] rows %llu tiles %llu | per-group us: setup %.0f pass1 %.0f (first tile %.0f) scan %.0f pass2 %.0f (first %.0f) emit %.0f | cuts %llu | sum nlong %llu alen %llu list-overflow rows %llu\n",
+                    h[22], h[21], h[16] * us, h[17] * us, h[23] * us, h[18] * us, h[19] * us, h[24] * us, h[20] * us, h[25], h[26], h[27], h[28]);
             dev_free(d_prof);
         }
         dev_free(slab);
@@ -2316,8 +2733,8 @@ int nsparse_spgemm_set_sorted(int on)
 
 void nsparse_get_spgemm_bins(int *sym, int *num)
 {
-    // 13 ints each: tiny, hash_t[4], dense_span[3], dense_ratio, bits_span[2], bits_ratio,
-    // bits_min (ratios are 0 when NSPARSE_DENSE=0)
+    // 15 ints each: tiny, hash_t[4], dense_span[3], dense_ratio, bits_span[2], bits_ratio,
+    // bits_min, bits_wide_min, bits_wide_span (ratios are 0 when NSPARSE_DENSE=0)
     const nsp::spgemm::Thr *t[2] = {&nsp::spgemm::kSymThr, &nsp::spgemm::kNumThr};
     int *out[2] = {sym, num};
     if (nsp::spgemm::g_dense_enabled < 0) {
@@ -2333,6 +2750,8 @@ void nsparse_get_spgemm_bins(int *sym, int *num)
         out[p][10] = t[p]->bits_span[1];
         out[p][11] = nsp::spgemm::g_dense_enabled ? t[p]->bits_ratio : 0;
         out[p][12] = t[p]->bits_min;
+        out[p][13] = t[p]->bits_wide_min;
+        out[p][14] = t[p]->bits_wide_span;
     }
 }
 

@@ -116,13 +116,15 @@ def row_windows(A, B):
 
 
 def bins_of(n, span, ladder):
-    """numpy twin of bin_of() in spgemm_hash.hip; ladder = 9 ints from nsparse_get_spgemm_bins."""
+    """numpy twin of bin_of() in spgemm_hash.hip; ladder = 15 ints from nsparse_get_spgemm_bins."""
     n = np.asarray(n, dtype=np.int64)
     span = np.asarray(span, dtype=np.int64)
     tiny, hash_t, dspan, ratio = ladder[0], ladder[1:5], ladder[5:8], ladder[8]
     b = 1 + sum((n > t).astype(np.int64) for t in hash_t)
     if len(ladder) > 9 and ladder[11] > 0:
         bspan, bratio, bmin = ladder[9:11], ladder[11], ladder[12]
+        if len(ladder) > 13 and ladder[13] > 0:
+            b = np.where((n > ladder[13]) & (span > 0) & (span <= ladder[14]), 10, b)
         bits = (n > bmin) & (span > 0) & (span <= bspan[1]) & (span <= bratio * n)
         b = np.where(bits, 9 + (span > bspan[0]), b)
     if ratio > 0:
@@ -141,8 +143,8 @@ def numeric_bins(row_nz, row_prod, span, sym, num):
 
 
 def ladders(lib):
-    sym = (C.c_int * 13)()
-    num = (C.c_int * 13)()
+    sym = (C.c_int * 15)()
+    num = (C.c_int * 15)()
     lib.nsparse_get_spgemm_bins(sym, num)
     return list(sym), list(num)
 

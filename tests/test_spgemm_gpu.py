@@ -269,3 +269,52 @@ def test_nnz_c_beyond_int_is_refused():
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
                        env={k: v for k, v in os.environ.items() if k != "NSPARSE_NO_ABORT"})
     assert r.returncode != 0 and "does not fit" in r.stderr
+
+
+@pytest.mark.parametrize("prec", ["d", "s"])
+def test_heavy_rows_tiled_and_ranked_kernels_agree(prec, lib_d, lib_s, oracle_d, oracle_s):
+    """Rows beyond the LDS hash tables (nnz > 5461) through each of the two heavy-row kernels alone
+    -- dense column tiles (NSPARSE_RANKED_DENS=0) and the bitmap-ranked accumulator
+    (NSPARSE_RANKED_DENS=-1) -- and through the default mix.  R-MAT scale 14 has rows above the
+    ranked tile capacity (10240 / 20480 values), so tiles are cut."""
+    lib, orc = (lib_d, oracle_d) if prec == "d" else (lib_s, oracle_s)
+    A = synth(lib, 3, 14, 16, 0, seed=0x5EED0022)
+    ref = orc.spgemm(A, A)
+    assert (ref["row_nz"] > 5461).sum() > 100 and ref["row_nz"].max() > 10240
+
+    def check(got):
+        if prec == "d":
+            assert_parity(orc, got, ref)
+            return
+        # fp32: an entry of these rows sums up to ~10^4 products, the oracle in CSR order, the
+        # kernels in atomic order; the reference's 1e-6 is below that rounding noise, so the
+        # values get 2e-5 relative here (all products are positive) and the structure stays exact
+        assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
+        np.testing.assert_allclose(got["val"], ref["val"], rtol=2e-5, atol=0)
+
+    got, st = spgemm(lib, A)
+    assert st.num_bin_size[5] == (ref["row_nz"] > 5461).sum()
+    check(got)
+    for dens in ("0", "-1"):
+        g, s = spgemm_subprocess(A, {"NSPARSE_RANKED_DENS": dens}, prec=prec)
+        assert s["num"][5] == st.num_bin_size[5]
+        check(g)
+
+
+def test_window_wider_than_the_bitmap(lib_d, oracle_d):
+    """3 M columns: the symbolic bit window (2^20 columns of LDS) covers the rows in three pieces
+    (bin 10), the numeric phase takes the ranked kernel (a dense tiling would need 245 tiles)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(77)
+    m, k, n = 48, 3000, 3_000_000
+    a = sp.random(m, k, density=120 / k, format="csr", random_state=rng, dtype=np.float64)
+    b = sp.random(k, n, density=220 / n, format="csr", random_state=rng, dtype=np.float64)
+    a.sort_indices()
+    b.sort_indices()
+    A = dict(M=m, N=k, rpt=a.indptr.astype(np.int32), col=a.indices.astype(np.int32), val=a.data)
+    B = dict(M=k, N=n, rpt=b.indptr.astype(np.int32), col=b.indices.astype(np.int32), val=b.data)
+    ref = oracle_d.spgemm(A, B)
+    assert ref["row_nz"].min() > 8192
+    got, st = spgemm(lib_d, A, B)
+    assert st.sym_bin_size[10] == m and st.sym_fail_rows == 0 and st.num_bin_size[5] == m
+    assert_parity(oracle_d, got, ref)
