@@ -1,0 +1,379 @@
+// spgemm/common.h -- bin ladders, shared device helpers, the product walk.
+// Part of the spgemm_hash.hip translation unit (kernels are launched from its host code).
+#pragma once
+#include <type_traits>
+
+#include "../internal.h"
+
+namespace nsp {
+namespace spgemm {
+
+constexpr int NB = kMaxBins;
+
+// ---- bin ladders ------------------------------------------------------------------
+// Symbolic, n = intermediate products of the row (upper bound of its nnz):
+//   bin 0  n <= 32      sub-wave rows, 4 lanes per row, 64-key table per row
+//   bin 1  n <= 512     one workgroup per row,   64 threads, table <=   512 keys ( 2 KiB)
+//   bin 2  n <= 2048                            128 threads,        <=  2048      ( 8 KiB)
+//   bin 3  n <= 8192                            256 threads,        <=  8192      (32 KiB)
+//   bin 4  n <= 32768                          1024 threads,        <= 32768      (128 KiB)
+//   bin 5  n  > 32768   1024 threads, 32768 keys, row FAILS over to the global table when
+//                       it holds more than 24576 distinct keys
+// Numeric, n = exact nnz of the C row, table = pow2_ceil(1.5 n) (load factor <= 2/3):
+//   bin 0  n <= 16      sub-wave rows, 4 lanes per row, 32 slots per row
+//   bin 1  n <= 170     64 threads,  table <=  256 slots
+//   bin 2  n <= 682     256 threads, table <= 1024
+//   bin 3  n <= 2730    512 threads, table <= 4096
+//   bin 4  n <= 5461    1024 threads, table <= 8192  (96 KiB fp64 + 32 KiB sort keys)
+//   bin 5  n  > 5461    global-memory tables
+// Row -> bin.  Bin 0: tiny rows (sub-wave kernels).  Bins 1..5: hash tables sized by n.
+// Bins 9..10 (symbolic only): BIT WINDOW rows -- same idea with one bit per column, for rows
+// with many products whose window is too wide for byte flags (up to 2^20 columns = 128 KiB).
+// Bins 6..8: DENSE WINDOW rows -- the columns a C row can touch lie in [lo, lo+span) and
+// span is small enough for an LDS array indexed by (col - lo): no probing, no compare-and-swap
+// with return, no sort (see k_sym_dense / k_num_dense).  A row is dense-eligible when
+// span <= dense_span[2] and span <= dense_ratio * n (clearing and scanning the window must not
+// cost more than the products).
+struct Thr {
+    int tiny;            // n <= tiny           -> bin 0
+    int hash_t[4];       // n <= hash_t[k]      -> bin 1 + k, above -> bin 5
+    int dense_span[3];   // span <= dense_span[k] -> bin 6 + k
+    int dense_ratio;     // 0 disables the dense bins
+    int bits_span[2];    // symbolic only: span <= bits_span[k] -> bin 9 + k (1 bit per column)
+    int bits_ratio;      // span <= bits_ratio * n; 0 disables
+    int bits_min;        // only rows with n > bits_min (small rows hash faster than they clear)
+    int bits_wide_min;   // rows with n > bits_wide_min (they would fill the two largest hash tables to
+    int bits_wide_span;  // the brim, or overflow them) and span <= bits_wide_span -> bin 10, which
+                         // then covers the window in pieces of bits_span[1] columns; 0 disables
+};
+constexpr Thr kSymThr = {32,   {512, 2048, 8192, 32768}, {4096, 16384, 65536}, 8, {262144, 1048576}, 64, 2048,
+                         8192, 16 * 1048576};
+constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8, {0, 0}, 0, 0, 0, 0};
+constexpr int kSymLargeBin = 5;
+constexpr int kNumGlobalBin = 5;
+// Setup kernels: rows longer than kLongFactor * W entries are not walked by their W-lane group
+// (a 4700-entry row on 4 lanes is a millisecond of serial dependent gathers): the bulk pass
+// appends them to a short device list and a second, fixed-size launch walks them with 64 lanes.
+constexpr int kLongFactor = 32;
+constexpr int kLongCap = 1 << 16;
+constexpr int kDenseBin0 = 6;
+constexpr int kBitsBin0 = 9;
+constexpr int kSetupMaxGrid = 16384;
+constexpr int kPartialStride = 16;  // long longs per block: hist[NB], max, total, bm, alen
+constexpr int kSymLargeT = 32768;
+constexpr int kSymLargeLimit = 24576;
+static int g_dense_enabled = -1;  // -1: read NSPARSE_DENSE on first use
+static int g_sorted = 1;          // 0: hash rows are written in table order (nsparse_spgemm_set_sorted)
+
+// device-resident counters of one binning pass (lives in Context::d_scratch)
+struct BinState {
+    int hist[NB];
+    int cursor[NB];
+    int maxv;
+    int fail_count;
+    int queue_head;
+    int nnz;
+    long long total;
+    long long bm_total;  // words of column bitmaps (dense window rows)
+    long long max_alen;  // longest row of A
+    int b_unsorted;      // some row of B does not have strictly ascending columns
+    int queue_head2;     // second persistent-kernel queue of the heavy numeric bin
+};
+
+struct Stats {
+    nsparse_spgemm_stats s;
+};
+static Stats g_stats;
+
+__host__ __device__ __forceinline__ int bin_of(int n, int span, const Thr &thr)
+{
+    if (n <= thr.tiny) return 0;
+    if (thr.dense_ratio > 0 && span > 0 && span <= thr.dense_span[2] &&
+        (long long)span <= (long long)thr.dense_ratio * n)
+        return kDenseBin0 + (span > thr.dense_span[0]) + (span > thr.dense_span[1]);
+    if (thr.bits_ratio > 0 && n > thr.bits_min && span > 0 && span <= thr.bits_span[1] &&
+        (long long)span <= (long long)thr.bits_ratio * n)
+        return kBitsBin0 + (span > thr.bits_span[0]);
+    if (thr.bits_ratio > 0 && thr.bits_wide_min > 0 && n > thr.bits_wide_min && span > 0 &&
+        span <= thr.bits_wide_span)
+        return kBitsBin0 + 1;
+    int b = 1;
+#pragma unroll
+    for (int q = 0; q < 4; q++) b += (n > thr.hash_t[q]) ? 1 : 0;
+    return b;
+}
+
+// Slot of a column id in a table of mask + 1 = 2^L slots: the TOP L bits of key * 2^32/phi
+// (Fibonacci hashing).  The reference takes the LOW bits of key * 107
+// (kernel_spgemm_hash_d.cu:30,296), which only see the low bits of the key: column ids that
+// are multiples of a large power of two -- a large share of an R-MAT row, whose index bits are
+// 0 with probability 0.76 -- all start probing at the same slot, and a scale-22 row of 25 K
+// columns degenerates into long linear-probe clusters (measured, R-MAT scale 22: symbolic
+// 665 -> 116 ms, whole call 1076 -> 458 ms).  The top bits depend on every bit of the key; consecutive
+// columns land 0.618 * 2^L slots apart, so FEM rows spread evenly as well.  The table
+// contents differ from the reference's, the rows that come out of them do not.
+__device__ __forceinline__ int hash_slot(int key, int mask)
+{
+    return (int)(((unsigned)key * 0x9E3779B1u) >> __builtin_clz((unsigned)mask));
+}
+
+__device__ __forceinline__ int pow2_ceil(int v) { return v <= 1 ? 1 : (1 << (32 - __clz(v - 1))); }
+
+__device__ __forceinline__ int lds_load(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Insert `key` into an open-addressing table of (mask+1) ints (empty = -1), linear
+// probing.  Returns the slot; *fresh = 1 when this call created the entry.
+// One LDS compare-and-swap per probe and nothing else: CAS(slot, -1, key) returns -1 (we
+// inserted), key (already there, nothing written) or another key (next slot).  The
+// read-then-CAS form of the reference costs three times the instructions on CDNA (nested
+// exec-mask regions) and the kernels are issue-bound, not LDS-bound.
+__device__ __forceinline__ int ht_find_or_insert(int *tab, int mask, int key, int *fresh)
+{
+    int h = hash_slot(key, mask);
+    while (true) {
+        const int old = atomicCAS(tab + h, -1, key);
+        if (old == -1 || old == key) {
+            *fresh = old == -1;
+            return h;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+// Same on a table in global memory.  Only the value returned by the CAS decides, so a
+// stale L1 line (another CU cannot touch this slice, but atomics execute in L2) can at
+// worst cost one extra CAS.
+__device__ __forceinline__ long long gt_find_or_insert(int *tab, long long mask, int key, int *fresh)
+{
+    long long h = (long long)(((unsigned long long)(unsigned)key * 0x9E3779B97F4A7C15ull) >>
+                              __builtin_clzll((unsigned long long)mask));
+    *fresh = 0;
+    while (true) {
+        const int cur = __hip_atomic_load(tab + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return h;
+        if (cur == -1) {
+            const int old = atomicCAS(tab + h, -1, key);
+            if (old == -1) { *fresh = 1; return h; }
+            if (old == key) return h;
+        }
+        h = (h + 1) & mask;
+    }
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Every lane takes VW consecutive entries of a B row per step: one 16-byte column load and
+// VW/2 16-byte value loads instead of VW scalar pairs, and the walk's bookkeeping (the kernels
+// are instruction-issue-bound: rocprofv3 shows VALU 73 % / SALU 83 % busy, LDS 15 %) is paid
+// once per VW products.
+constexpr int VW = 4;
+struct __attribute__((aligned(4))) IVec {
+    int v[VW];
+};
+struct __attribute__((aligned(sizeof(real) < 8 ? 4 : 8))) RVec {
+    real v[VW];
+};
+
+// Lanes per B row for a C row with `np` products spread over `alen` entries of A, for a
+// workgroup of BS threads.  With g lanes per group the row takes
+//     ceil(alen / (BS/g)) * ceil(avg_len / (g*VW))   group steps,
+// so g trades padding of the B rows (small g pads less) against imbalance between groups
+// (large g, few groups).  The largest g with the fewest steps wins.
+__device__ __forceinline__ int group_width(int np, int alen, int BS, int maxb = 0)
+{
+    if (alen <= 0) return 64;
+    const int avg = (np + alen - 1) / alen;
+    int best_g = 64, best_t = 0x7fffffff;
+#pragma unroll
+    for (int g = 64; g >= 1; g >>= 1) {
+        const int ng = BS / g;
+        int t = ((alen + ng - 1) / ng) * ((avg + g * VW - 1) / (g * VW));
+        // the group that owns the longest B row of this C row (maxb entries) cannot finish
+        // earlier than that row alone takes: on power-law inputs (hub rows of hundreds of entries
+        // among rows of three) this term, not the average, decides
+        const int tl = (maxb + g * VW - 1) / (g * VW);
+        t = t > tl ? t : tl;
+        if (t < best_t) { best_t = t; best_g = g; }
+    }
+    return best_g;
+}
+
+// Workgroup b runs on XCD b % 8 (observed dispatch order, not a contract: only speed depends
+// on it).  Rows of a bin are listed in roughly ascending order and neighbouring rows of A touch
+// the same rows of B, so XCD x is given the x-th contiguous eighth of the bin: its private 4 MiB
+// L2 then holds one window of B instead of all of it (measured before: 1.35 GB fetched per
+// numeric launch for 0.1 GB of B).  Launch with 8 * ceil(n / 8) workgroups.
+__device__ __forceinline__ int xcd_row_slot(int n)
+{
+    const int nb8 = (n + 7) >> 3;
+    const int slot = (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3);
+    return slot < n ? slot : -1;
+}
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Walk every intermediate product of one C row with the threads of a workgroup and hand
+// (column, aval * bval) to `consume`.
+//
+// The naive loop (per A entry: load A.col -> load B.rpt[c], B.rpt[c+1] -> load B.col/B.val)
+// is a chain of three dependent global loads per A entry, 2-3 k cycles of latency for one or
+// two wave-steps of work.  Here each lane of a group loads ONE A entry and its B row extent
+// and parks them in LDS (`s_ext`, `s_av`: one slot per thread), so a batch of g entries costs
+// the two dependent latencies once.  The group then runs a flat state machine over
+// (entry, chunk-of-g) steps in which the loads of step s+1 are issued before step s is
+// hashed, so every B chunk is in flight for a whole hashing step.
+// VW entries of a B row starting at i0; returns how many of them belong to the row (< ke).
+// The load is always the full 16-byte vector: elements past ke belong to the next row of B
+// (valid memory, masked out by the returned count); only the last VW-1 entries of the whole
+// array (i0 + VW > bnnz) take the element-wise path.
+template <bool WITH_VAL>
+__device__ __forceinline__ int fetch_chunk(const int *__restrict__ bcol, const real *__restrict__ bval,
+                                           int i0, int ke, int bnnz, IVec &k, RVec &v)
+{
+    int n = ke - i0;
+    n = n < 0 ? 0 : (n > VW ? VW : n);
+    if (n > 0) {
+        if (i0 + VW <= bnnz) {
+            // unsigned index: zero-extension is free, so the loads use base + 32-bit offset
+            k = *reinterpret_cast<const IVec *>(bcol + (unsigned)i0);
+            if (WITH_VAL) v = *reinterpret_cast<const RVec *>(bval + (unsigned)i0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < VW; i++) {
+                const int ii = i < n ? i0 + i : i0;
+                k.v[i] = bcol[ii];
+                if (WITH_VAL) v.v[i] = bval[ii];
+            }
+        }
+    }
+    return n;
+}
+
+template <int BS, bool WITH_VAL, typename F>
+__device__ __forceinline__ void walk_products(const int *__restrict__ acol, const real *__restrict__ aval,
+                                              const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                              const real *__restrict__ bval, int bnnz, int a_beg,
+                                              int a_end, int g, int2 *s_ext, real *s_av, F &&consume)
+{
+    const int ngroups = BS / g;
+    const int gid = threadIdx.x / g, gl = threadIdx.x % g;
+    const int first = a_beg + gid;
+    const int cnt = first < a_end ? (a_end - first + ngroups - 1) / ngroups : 0;
+    int2 *ext = s_ext + gid * g;
+    real *avs = s_av + gid * g;
+    const int lane_off = gl * VW;
+    const int stride = g * VW;
+    for (int b0 = 0; b0 < cnt; b0 += g) {
+        const int m = b0 + gl;
+        int2 e = make_int2(0, 0);
+        real av = 0;
+        if (m < cnt) {
+            const int j = first + m * ngroups;
+            const int c = __builtin_nontemporal_load(acol + j);
+            if (WITH_VAL) av = __builtin_nontemporal_load(aval + j);
+            struct __attribute__((aligned(4))) I2 {
+                int b, e;
+            };
+            const I2 r = *reinterpret_cast<const I2 *>(brpt + c);  // one 8-byte gather
+            e.x = r.b;
+            e.y = r.e;
+        }
+        ext[gl] = e;
+        if (WITH_VAL) avs[gl] = av;
+        wave_lds_sync();  // a group never spans wavefronts: in-order LDS is enough
+        const int nb = cnt - b0 < g ? cnt - b0 : g;
+        int t = 0;
+        int2 cur = ext[0];
+        real cav = WITH_VAL ? avs[0] : (real)0;
+        int base = cur.x;
+        IVec pk;
+        RVec pv;
+        int pn = fetch_chunk<WITH_VAL>(bcol, bval, base + lane_off, cur.y, bnnz, pk, pv);
+        while (t < nb) {
+            const IVec ck = pk;
+            const RVec cv = pv;
+            const int cn = pn;
+            const real sc = cav;
+            base += stride;
+            if (base >= cur.y) {
+                t++;
+                if (t < nb) {
+                    cur = ext[t];
+                    if (WITH_VAL) cav = avs[t];
+                    base = cur.x;
+                }
+            }
+            pn = t < nb ? fetch_chunk<WITH_VAL>(bcol, bval, base + lane_off, cur.y, bnnz, pk, pv) : 0;
+            if (cn > 0) consume(ck, cv, cn, sc);
+        }
+        wave_lds_sync();
+    }
+}
+
+// VW find-or-insert operations of one lane, the first probes issued back to back
+__device__ __forceinline__ void ht_insert_vec(int *tab, int mask, const IVec &k, int n, int (&h)[VW], int &fresh)
+{
+    int old[VW];
+#pragma unroll
+    for (int i = 0; i < VW; i++) h[i] = hash_slot(k.v[i], mask);
+#pragma unroll
+    for (int i = 0; i < VW; i++) old[i] = i < n ? atomicCAS(tab + h[i], -1, k.v[i]) : k.v[i];
+#pragma unroll
+    for (int i = 0; i < VW; i++) {
+        while (old[i] != -1 && old[i] != k.v[i]) {
+            h[i] = (h[i] + 1) & mask;
+            old[i] = atomicCAS(tab + h[i], -1, k.v[i]);
+        }
+        fresh += old[i] == -1;
+    }
+}
+
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
+// waits for the acknowledgement of every global store issued before it; the tiled kernel
+// emits a tile with global stores nobody in the workgroup reads back, so waiting for them
+// once per tile (a full HBM round trip) is pure stall.
+// Inclusive prefix sum over the 64 lanes in registers (DPP row shifts + row broadcasts); the
+// __shfl_up form goes through the LDS crossbar six times.
+__device__ __forceinline__ int wave_incl_scan(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Rows with more than 5461 non-zeros do not fit an LDS hash table, and on power-law inputs
+// they carry most of the products (R-MAT-18: 59 K such rows, 2.7 G products).  Hashing them in
+// global memory means two random HBM round trips per product.  Instead the row's column window
+// is cut into tiles of W columns that DO fit LDS as a dense array.  Rows of B are sorted, so
+// the part of B row k that falls into a tile is contiguous: every A entry keeps a cursor
+// (position, end, next column, a value) in a per-workgroup global scratch slice, and for each
+// tile every lane advances the cursors of its entries while the column stays inside the tile,
+// accumulating into LDS.  The tile is then emitted in ascending order (byte flags + ballot /
+// popcount), so the row leaves sorted without a sort.  One pass over the products, no global
+// atomics.  Persistent workgroups pull rows from a queue.  Needs sorted rows of B (checked by
+// the caller through the B-info pass: unsorted B falls back to the global hash table).
+
+}  // namespace spgemm
+}  // namespace nsp

@@ -1,0 +1,379 @@
+// spgemm/heavy_ranked.h -- heavy numeric rows, bitmap-ranked accumulator.
+// Part of the spgemm_hash.hip translation unit (kernels are launched from its host code).
+#pragma once
+#include "common.h"
+
+namespace nsp {
+namespace spgemm {
+
+// ===================================================================================
+//  heavy numeric rows, sparse flavour: bitmap-ranked accumulator
+// ===================================================================================
+// A heavy row whose columns are spread thinly over a wide window (R-MAT scale 22: 18 K non-zeros
+// over 4 M columns) would need hundreds of almost empty dense tiles.  Here LDS holds 8 bytes per
+// NON-ZERO instead of 9 bytes per column: a tile is a bitmap over W columns plus a value array
+// of CAP entries addressed by rank.
+//   pass 1  walk the products of the tile, set the bit of every column           (ds_or)
+//   scan    per-word exclusive prefix of the popcounts; if the tile holds more than CAP
+//           columns it is cut at the word where the prefix crosses CAP
+//   pass 2  walk again, accumulate a*b at  prefix[word] + popcount(bits below)    (ds_add)
+//   emit    values are already in ascending column order and contiguous; the columns are
+//           read off the bitmap
+// Cursors advance only in pass 2, so the cut costs nothing but the re-walk of the columns
+// beyond it.  Same cursor scheme as k_num_tiled: lane-serial entries (4 look-ahead loads per
+// step), long B rows dealt out in 64-entry chunks to wavefront sweep slots.
+template <int BS, int W, int CAP>
+__global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                   const real *__restrict__ aval,
+                                                   const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                   const real *__restrict__ bval,
+                                                   const int *__restrict__ crpt, int *__restrict__ ccol,
+                                                   real *__restrict__ cval,
+                                                   const int *__restrict__ row_perm, int bin_off, int count,
+                                                   BinState *bs, const int *__restrict__ row_lo,
+                                                   const int *__restrict__ row_span, int *__restrict__ slab,
+                                                   long long stride_ints, int amax, int write_col,
+                                                   int LONG_LEN, int dens, int tiled_w,
+                                                   unsigned long long *prof)
+{
+    // prof (NSPARSE_TILED_PROF=1), 100 MHz ticks of thread 0: 0 set-up, 1 pass 1, 2 scan, 3 pass 2,
+    // 4 emission; 5 tiles, 6 rows
+    unsigned long long tk = prof ? wall_clock64() : 0;
+    unsigned long long t_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    auto tick = [&](int phase) {
+        if (prof) {
+            const unsigned long long now = wall_clock64();
+            t_acc[phase] += now - tk;
+            tk = now;
+        }
+    };
+    constexpr int NW = BS / 64;
+    constexpr int LCAP = BS, EPT = 4, VMAX = 32, LA = 4;
+    constexpr int INF = 0x7fffffff;
+    constexpr int NWORD = W / 32;
+    static_assert(NWORD == 8 * BS, "eight bitmap words per thread");
+    static_assert(CAP <= 65535, "ranks are kept in 16 bits");
+    __shared__ __attribute__((aligned(16))) unsigned int bits[NWORD];
+    __shared__ __attribute__((aligned(16))) unsigned short pref[NWORD];
+    __shared__ __attribute__((aligned(16))) real vals[CAP];
+    __shared__ int4 l_meta[LCAP];
+    __shared__ real l_av[LCAP];
+    __shared__ int s_row, s_nlong, s_cut, s_ntile, s_total;
+    __shared__ int s_wsum[8 * NW];
+    int *st_cur = slab + (long long)blockIdx.x * stride_ints;
+    int *st_end = st_cur + amax;
+    int *st_next = st_end + amax;
+    real *st_av = reinterpret_cast<real *>(st_next + amax);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < NWORD; i += BS) bits[i] = 0;
+    for (int i = threadIdx.x; i < CAP; i += BS) vals[i] = 0;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_row = atomicAdd(&bs->queue_head2, 1);
+            s_nlong = 0;
+        }
+        __syncthreads();
+        const int q = s_row;
+        if (q >= count) break;
+        const int rid = row_perm[bin_off + q];
+        const int lo = row_lo[rid], span = row_span[rid];
+        int pos = crpt[rid];
+        // dens > 0: only rows thinner than one non-zero per `dens` columns or wider than 32 dense
+        // tiles (the rest belong to k_num_tiled); dens <= 0: every row
+        if (dens > 0 && (long long)(crpt[rid + 1] - pos) * dens >= span && span <= 32 * tiled_w) continue;
+        const int a_beg = arpt[rid], alen = arpt[rid + 1] - a_beg;
+        const int split = 64 * ((span + W - 1) / W + (crpt[rid + 1] - pos) / CAP + 1);
+        auto init_entry = [&](int e, int &cur, int &end, real &av) -> bool {
+            const int c = acol[a_beg + e];
+            cur = brpt[c];
+            end = brpt[c + 1];
+            av = aval[a_beg + e];
+            const int len = end - cur;
+            if (len <= LONG_LEN) return true;
+            int V = (len + split - 1) / split;
+            V = V < 1 ? 1 : (V > VMAX ? VMAX : V);
+            const int li = atomicAdd(&s_nlong, V);
+            const bool fits = li + V <= LCAP;
+            for (int v = 0; v < V && li + v < LCAP; v++) {
+                l_meta[li + v] = fits ? make_int4(cur + 64 * v, end, 64 * V, 0) : make_int4(0, 0, 64, 0);
+                l_av[li + v] = av;
+            }
+            return !fits;  // true: lane-serial
+        };
+        int e_cur[EPT], e_end[EPT], e_nc[EPT];
+        real e_av[EPT];
+#pragma unroll
+        for (int u = 0; u < EPT; u++) {
+            const int e = threadIdx.x + u * BS;
+            e_cur[u] = e_end[u] = 0;
+            e_nc[u] = INF;
+            e_av[u] = 0;
+            if (e < alen && init_entry(e, e_cur[u], e_end[u], e_av[u]) && e_cur[u] < e_end[u])
+                e_nc[u] = bcol[e_cur[u]];
+        }
+        for (int e = threadIdx.x + EPT * BS; e < alen; e += BS) {
+            int cur, end;
+            real av;
+            const bool serial = init_entry(e, cur, end, av);
+            st_cur[e] = cur;
+            st_end[e] = end;
+            st_next[e] = (serial && cur < end) ? bcol[cur] : INF;
+            st_av[e] = av;
+        }
+        __syncthreads();
+        const int nlong = s_nlong < LCAP ? s_nlong : LCAP;
+        const int row_end = lo + span;
+        int t_lo = lo;
+        tick(0);
+        if (prof) {
+            t_acc[6]++;
+            t_acc[10] += nlong;
+            t_acc[11] += alen;
+            t_acc[12] += s_nlong > LCAP;
+        }
+        while (t_lo < row_end) {
+            // Pass 1 runs to t_max and everything beyond the cut is walked again by the next tile,
+            // so t_max aims at ~7/8 of CAP columns at the density of what is left of the row.
+            int t_max;
+            {
+                const long long rem_nnz = crpt[rid + 1] - pos, rem_span = row_end - t_lo;
+                long long wd_est = rem_nnz > 0 ? (long long)(CAP - CAP / 8) * rem_span / rem_nnz : rem_span;
+                wd_est = (wd_est + 31) & ~31LL;
+                if (wd_est > W) wd_est = W;
+                if (wd_est < 1024) wd_est = 1024;
+                t_max = rem_span <= wd_est ? row_end : t_lo + (int)wd_est;
+            }
+            // One walk of everything inside [t_lo, t_hi).  PASS2 = false: mark columns.
+            // PASS2 = true: accumulate by rank and commit the cursors.
+            auto touch = [&](auto pass2, int col, real x) {
+                const unsigned int idx = (unsigned int)(col - t_lo);
+                if (!decltype(pass2)::value) {
+                    atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+                } else {
+                    const unsigned int below = bits[idx >> 5] & ((1u << (idx & 31)) - 1u);
+                    unsafeAtomicAdd(vals + (int)pref[idx >> 5] + __popc(below), x);
+                }
+            };
+            // lane-serial entries: LA consecutive (column, value) pairs per round trip; the first
+            // batch of all register entries is requested before any of it is used
+            auto load_batch = [&](auto pass2, int k, int end, int c0, int(&c)[LA], real(&v)[LA]) {
+                c[0] = c0;
+#pragma unroll
+                for (int j = 1; j < LA; j++) c[j] = k + j < end ? bcol[k + j] : INF;
+                if (decltype(pass2)::value) {
+#pragma unroll
+                    for (int j = 0; j < LA; j++) v[j] = k + j < end ? bval[k + j] : (real)0;
+                }
+            };
+            // uses the leading pairs that lie inside the tile; returns how many, and the column after them
+            auto consume = [&](auto pass2, int t_hi, const int(&c)[LA], const real(&v)[LA], real av, int &next) -> int {
+                int n = 0;
+                next = INF;
+#pragma unroll
+                for (int j = 0; j < LA; j++) {
+                    if (n == j) {
+                        if (c[j] < t_hi) {
+                            touch(pass2, c[j], decltype(pass2)::value ? av * v[j] : (real)0);
+                            n = j + 1;
+                        } else {
+                            next = c[j];
+                        }
+                    }
+                }
+                return n;
+            };
+            // after a batch that was used up completely: keep going, one round trip per batch
+            auto walk_rest = [&](auto pass2, int t_hi, int &k, int end, int &col, real av) {
+                col = k < end ? bcol[k] : INF;
+                while (col < t_hi) {
+                    int c[LA];
+                    real v[LA];
+                    load_batch(pass2, k, end, col, c, v);
+                    const int n = consume(pass2, t_hi, c, v, av, col);
+                    k += n;
+                    if (n < LA) return;
+                    col = k < end ? bcol[k] : INF;
+                }
+            };
+            auto walk = [&](auto pass2, int t_hi) {
+                constexpr bool P2 = decltype(pass2)::value;
+                // sweep slots: 64-entry chunks, two-sided range test (a chunk may straddle tiles);
+                // the current chunks of SB slots are requested together, and the first such batch
+                // together with the first pair of register entries: one round trip for both
+                constexpr int SB = 4;
+                auto sweep_load = [&](int i0, int4(&mt)[SB], int(&col)[SB], real(&bv)[SB]) {
+#pragma unroll
+                    for (int j = 0; j < SB; j++) {
+                        const int i = i0 + j * NW;
+                        mt[j] = i < nlong ? l_meta[i] : make_int4(0, 0, 64, 0);
+                        const int kk = mt[j].x + lane;
+                        col[j] = kk < mt[j].y ? bcol[kk] : INF;
+                        bv[j] = 0;
+                        if (P2) bv[j] = kk < mt[j].y ? bval[kk] : (real)0;
+                    }
+                };
+                auto sweep_use = [&](int i0, const int4(&mt)[SB], const int(&col)[SB], const real(&bv)[SB]) {
+#pragma unroll
+                    for (int j = 0; j < SB; j++) {
+                        const int i = i0 + j * NW;
+                        if (i >= nlong) continue;
+                        const real av = l_av[i];
+                        int k = mt[j].x, c = col[j];
+                        real x = bv[j];
+                        while (true) {
+                            if (c >= t_lo && c < t_hi) touch(pass2, c, av * x);
+                            if (__builtin_amdgcn_readlane(c, 63) >= t_hi) break;
+                            k += mt[j].z;
+                            const int kk = k + lane;
+                            c = kk < mt[j].y ? bcol[kk] : INF;
+                            if (P2) x = kk < mt[j].y ? bval[kk] : (real)0;
+                        }
+                        if (P2 && lane == 0) l_meta[i].x = k;
+                    }
+                };
+                auto entries_load = [&](int u0, int(&c)[2][LA], real(&v)[2][LA]) {
+#pragma unroll
+                    for (int d = 0; d < 2; d++)
+                        if (e_nc[u0 + d] < t_hi) load_batch(pass2, e_cur[u0 + d], e_end[u0 + d], e_nc[u0 + d], c[d], v[d]);
+                };
+                auto entries_use = [&](int u0, const int(&c)[2][LA], const real(&v)[2][LA]) {
+#pragma unroll
+                    for (int d = 0; d < 2; d++) {
+                        const int u = u0 + d;
+                        if (e_nc[u] < t_hi) {
+                            int col;
+                            const int n = consume(pass2, t_hi, c[d], v[d], e_av[u], col);
+                            int k = e_cur[u] + n;
+                            if (n == LA) walk_rest(pass2, t_hi, k, e_end[u], col, e_av[u]);
+                            if (P2) {
+                                e_cur[u] = k;
+                                e_nc[u] = col;
+                            }
+                        }
+                    }
+                };
+                {
+                    int4 mt[SB];
+                    int col[SB];
+                    real bv[SB];
+                    int c[2][LA];
+                    real v[2][LA];
+                    if (w < nlong) sweep_load(w, mt, col, bv);
+                    entries_load(0, c, v);
+                    if (w < nlong) sweep_use(w, mt, col, bv);
+                    entries_use(0, c, v);
+                    static_assert(EPT == 4, "two pairs of register entries");
+                    entries_load(2, c, v);
+                    entries_use(2, c, v);
+                    for (int i0 = w + SB * NW; i0 < nlong; i0 += SB * NW) {
+                        sweep_load(i0, mt, col, bv);
+                        sweep_use(i0, mt, col, bv);
+                    }
+                }
+                for (int e = threadIdx.x + EPT * BS; e < alen; e += BS) {
+                    int col = st_next[e];
+                    if (col < t_hi) {
+                        const int end = st_end[e];
+                        const real av = st_av[e];
+                        int c[LA];
+                        real v[LA];
+                        int k = st_cur[e];
+                        load_batch(pass2, k, end, col, c, v);
+                        const int n = consume(pass2, t_hi, c, v, av, col);
+                        k += n;
+                        if (n == LA) walk_rest(pass2, t_hi, k, end, col, av);
+                        if (P2) {
+                            st_cur[e] = k;
+                            st_next[e] = col;
+                        }
+                    }
+                }
+            };
+            walk(std::false_type{}, t_max);
+            lds_barrier();
+            tick(t_lo == lo ? 7 : 1);
+            // ---- scan: thread t owns words t, t + BS, ..., t + 7 BS ----------------------------
+            // (strided, so that the dense low-column stretch of a power-law row is shared by many
+            // threads when the columns are written out)
+            unsigned int wd[8];
+            int pc[8];  // becomes the exclusive prefix of the word
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                wd[j] = bits[threadIdx.x + j * BS];
+                const int c = __popc(wd[j]);
+                const int incl = wave_incl_scan(c);
+                pc[j] = incl - c;
+                if (lane == 63) s_wsum[j * NW + w] = incl;
+            }
+            if (threadIdx.x == 0) s_cut = t_max;
+            lds_barrier();
+            if (w == 0) {  // 8 * NW partial sums in (segment, wavefront) order -> exclusive offsets
+                static_assert(8 * NW <= 128, "two partial sums per lane");
+                const int i0 = 2 * lane, i1 = 2 * lane + 1;
+                const int a0 = i0 < 8 * NW ? s_wsum[i0] : 0, a1 = i1 < 8 * NW ? s_wsum[i1] : 0;
+                const int incl = wave_incl_scan(a0 + a1);
+                if (i0 < 8 * NW) s_wsum[i0] = incl - a0 - a1;
+                if (i1 < 8 * NW) s_wsum[i1] = incl - a1;
+                if (lane == 63) s_total = incl;
+            }
+            lds_barrier();
+            const int total = s_total;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                pc[j] += s_wsum[j * NW + w];
+                pref[threadIdx.x + j * BS] = (unsigned short)pc[j];
+            }
+            if (total > CAP) {  // cut at the word where the running count would pass CAP
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const int p1 = pc[j] + __popc(wd[j]);
+                    if (pc[j] <= CAP && p1 > CAP) {
+                        s_cut = t_lo + 32 * (threadIdx.x + j * BS);
+                        s_ntile = pc[j];
+                    }
+                }
+            } else if (threadIdx.x == 0) {
+                s_ntile = total;
+            }
+            lds_barrier();
+            const int t_hi = s_cut, ntile = s_ntile;
+            tick(2);
+            if (prof && t_hi != t_max) t_acc[9]++;
+            walk(std::true_type{}, t_hi);
+            lds_barrier();
+            tick(t_lo == lo ? 8 : 3);
+            // ---- emission (words and prefixes are read back: not kept live across pass 2) ------
+            if (write_col & 1) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    unsigned int m = bits[threadIdx.x + j * BS];
+                    const int cbase = t_lo + 32 * (threadIdx.x + j * BS);
+                    int p = pos + (int)pref[threadIdx.x + j * BS];
+                    if (cbase < t_hi) {
+                        while (m) {
+                            ccol[p++] = cbase + __builtin_ctz(m);
+                            m &= m - 1;
+                        }
+                    }
+                }
+            }
+            for (int r = threadIdx.x; r < ntile; r += BS) {
+                cval[pos + r] = vals[r];
+                vals[r] = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) bits[threadIdx.x + j * BS] = 0;
+            pos += ntile;
+            t_lo = t_hi;
+            lds_barrier();
+            tick(4);
+            if (prof) t_acc[5]++;
+        }
+    }
+    if (prof && threadIdx.x == 0)
+        for (int i = 0; i < 13; i++) atomicAdd(prof + 16 + i, t_acc[i]);
+}
+
+}  // namespace spgemm
+}  // namespace nsp

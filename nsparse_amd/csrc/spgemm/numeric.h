@@ -1,0 +1,281 @@
+// spgemm/numeric.h -- numeric hash kernels (bins 0-4) and the global-table fallback.
+// Part of the spgemm_hash.hip translation unit (kernels are launched from its host code).
+#pragma once
+#include "common.h"
+
+namespace nsp {
+namespace spgemm {
+
+// ===================================================================================
+//  numeric phase
+// ===================================================================================
+
+// bin 0: LPR lanes per row, TROW slots per row, rank sort (calculate_value_col_bin_pwarp
+// :631-723).  The LPR lanes of a row live in one wavefront, so wave-level ordering of LDS
+// operations is all the synchronisation needed between accumulate and read-out.
+template <int BS, int LPR, int TROW>
+__global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
+                                                  const int *__restrict__ acol,
+                                                  const real *__restrict__ aval,
+                                                  const int *__restrict__ brpt,
+                                                  const int *__restrict__ bcol,
+                                                  const real *__restrict__ bval,
+                                                  const int *__restrict__ crpt,
+                                                  int *__restrict__ ccol, real *__restrict__ cval,
+                                                  const int *__restrict__ row_perm, int bin_off,
+                                                  int bin_size, int write_col)
+{
+    constexpr int RPB = BS / LPR;
+    __shared__ int keys[RPB * TROW];
+    __shared__ real vals[RPB * TROW];
+    for (int i = threadIdx.x; i < RPB * TROW; i += BS) {
+        keys[i] = -1;
+        vals[i] = 0;
+    }
+    __syncthreads();
+    const int lrow = threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int q = blockIdx.x * RPB + lrow;
+    const bool active = q < bin_size;
+    int rid = 0;
+    int *kt = keys + lrow * TROW;
+    real *vt = vals + lrow * TROW;
+    if (active) {
+        rid = row_perm[bin_off + q];
+        const int e = arpt[rid + 1];
+        for (int j = arpt[rid] + sub; j < e; j += LPR) {
+            const int c = __builtin_nontemporal_load(acol + j);
+            const real av = __builtin_nontemporal_load(aval + j);
+            const int ke = brpt[c + 1];
+            for (int k = brpt[c]; k < ke; k++) {
+                int fresh;
+                const int h = ht_find_or_insert(kt, TROW - 1, bcol[k], &fresh);
+                unsafeAtomicAdd(vt + h, av * bval[k]);
+            }
+        }
+    }
+    __syncthreads();  // uniform: every thread reaches it
+    if (active) {
+        const int off = crpt[rid];
+        for (int s = sub; s < TROW; s += LPR) {
+            const int key = kt[s];
+            if (key == -1) continue;
+            int rank = 0;
+            for (int u = 0; u < TROW; u++) {
+                const int o = kt[u];
+                rank += (o != -1 && o < key) ? 1 : 0;
+            }
+            if (write_col & 1) ccol[off + rank] = key;
+            cval[off + rank] = vt[s];
+        }
+    }
+}
+
+// In-LDS bitonic sort of P (power of two) ints, ascending.  Stages whose partner distance
+// is < 128 keep every compare-exchange pair inside one wavefront's 128-element segment and
+// run back to back with wave-level ordering only; only the wider stages need a workgroup
+// barrier.
+template <int BS>
+__device__ __forceinline__ void bitonic_sort_lds(int *s, int P)
+{
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    constexpr int NW = BS / 64;
+    // compare-exchange of pair number t at partner distance j inside merge size k
+    auto cex = [&](int t, int j, int k) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int p = i | j;
+        const int a = s[i], b = s[p];
+        const bool up = (i & k) == 0;
+        if ((a > b) == up) { s[i] = b; s[p] = a; }
+    };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    // phase 1: every merge size up to 128 stays inside a 128-element segment
+    const int kmax1 = P < 128 ? P : 128;
+    for (int seg = wid; seg * 128 < P; seg += NW) {
+        const int t = seg * 64 + lane;
+        for (int k = 2; k <= kmax1; k <<= 1)
+            for (int j = k >> 1; j >= 1; j >>= 1) {
+                if (t < P / 2) cex(t, j, k);
+                wave_sync();
+            }
+    }
+    __syncthreads();
+    // phase 2: wide stages with workgroup barriers, then the sub-segment tail of each merge
+    for (int k = 256; k <= P; k <<= 1) {
+        for (int j = k >> 1; j >= 128; j >>= 1) {
+            for (int t = threadIdx.x; t < P / 2; t += BS) cex(t, j, k);
+            __syncthreads();
+        }
+        for (int seg = wid; seg * 128 < P; seg += NW) {
+            const int t = seg * 64 + lane;
+            for (int j = 64; j >= 1; j >>= 1) {
+                cex(t, j, k);
+                wave_sync();
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// bins 1..4: one workgroup per row (calculate_value_col_bin_each_tb :829-927).
+template <int BS, int TMAX, int PMAX>
+__global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
+                                               const int *__restrict__ acol,
+                                               const real *__restrict__ aval,
+                                               const int *__restrict__ brpt,
+                                               const int *__restrict__ bcol,
+                                               const real *__restrict__ bval,
+                                               const int *__restrict__ crpt,
+                                               int *__restrict__ ccol, real *__restrict__ cval,
+                                               const int *__restrict__ row_perm,
+                                               const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb, int bin_off,
+                                               int bin_size, int bnnz, int write_col)
+{
+    __shared__ __attribute__((aligned(16))) real vals[TMAX];
+    __shared__ __attribute__((aligned(16))) int keys[TMAX];
+    __shared__ __attribute__((aligned(16))) int srt[PMAX];
+    __shared__ int2 s_ext[BS];
+    __shared__ real s_av[BS];
+    __shared__ int s_cnt;
+    const int slot = xcd_row_slot(bin_size);
+    if (slot < 0) return;
+    const int rid = row_perm[bin_off + slot];
+    const int off = crpt[rid];
+    const int n = crpt[rid + 1] - off;
+    int T = pow2_ceil(n + (n >> 1));
+    if (T < 64) T = 64;
+    if (T > TMAX) T = TMAX;
+    const int mask = T - 1;
+    for (int i = threadIdx.x; i < T; i += BS) {
+        keys[i] = -1;
+        vals[i] = 0;
+    }
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
+    walk_products<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av,
+                            [&](const IVec &k, const RVec &v, int n, real sc) {
+                                int h[VW], fresh = 0;
+                                ht_insert_vec(keys, mask, k, n, h, fresh);
+#pragma unroll
+                                for (int i = 0; i < VW; i++)
+                                    if (i < n) unsafeAtomicAdd(vals + h[i], sc * v.v[i]);
+                            });
+    __syncthreads();
+
+    // compaction: ballot + popcount inside the wave, one LDS atomic per 64 slots
+    const int lane = threadIdx.x & 63;
+    for (int base = (threadIdx.x >> 6) * 64; base < T; base += BS) {
+        const int key = keys[base + lane];
+        const bool occ = key != -1;
+        const unsigned long long m = __ballot(occ);
+        if (m) {
+            int start = 0;
+            if (lane == 0) start = atomicAdd(&s_cnt, __popcll(m));
+            start = __shfl(start, 0);
+            if (occ) srt[start + __popcll(m & ((1ull << lane) - 1ull))] = key;
+        }
+    }
+    const int P = pow2_ceil(n);
+    for (int i = n + threadIdx.x; i < P; i += BS) srt[i] = 0x7fffffff;
+    __syncthreads();
+    // write_col bit 1: unsorted output requested (cuda-cpp template<bool sort>,
+    // HashSpGEMM_volta.hpp:585-604): columns leave in compaction order
+    if (P > 1 && !(write_col & 2)) bitonic_sort_lds<BS>(srt, P);
+
+    for (int i = threadIdx.x; i < n; i += BS) {
+        const int key = srt[i];
+        int h = hash_slot(key, mask);
+        while (keys[h] != key) h = (h + 1) & mask;
+        if (write_col & 1) ccol[off + i] = key;
+        cval[off + i] = vals[h];
+    }
+}
+
+// bin 5: persistent workgroups, private (keys, values) slices of global slabs; the row is
+// written UNSORTED into (tcol, tval) at its C offset and sorted afterwards by one rocprim
+// segmented radix sort (calculate_value_col_bin_each_gl :929-1027).
+template <int BS>
+__global__ __launch_bounds__(BS) void k_num_global(const int *__restrict__ arpt,
+                                                   const int *__restrict__ acol,
+                                                   const real *__restrict__ aval,
+                                                   const int *__restrict__ brpt,
+                                                   const int *__restrict__ bcol,
+                                                   const real *__restrict__ bval,
+                                                   const int *__restrict__ crpt,
+                                                   int *__restrict__ tcol, real *__restrict__ tval,
+                                                   const int *__restrict__ row_perm, int bin_off,
+                                                   int count, BinState *bs,
+                                                   int *__restrict__ kslab, real *__restrict__ vslab,
+                                                   long long slice, int *__restrict__ seg_beg,
+                                                   int *__restrict__ seg_end)
+{
+    __shared__ int s_row;
+    __shared__ int s_cnt;
+    int *keys = kslab + (long long)blockIdx.x * slice;
+    real *vals = vslab + (long long)blockIdx.x * slice;
+    const int lane = threadIdx.x & 63;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_row = atomicAdd(&bs->queue_head, 1);
+            s_cnt = 0;
+        }
+        __syncthreads();
+        const int q = s_row;
+        if (q >= count) break;
+        const int rid = row_perm[bin_off + q];
+        const int off = crpt[rid];
+        const int n = crpt[rid + 1] - off;
+        if (threadIdx.x == 0) {
+            seg_beg[q] = off;
+            seg_end[q] = off + n;
+        }
+        long long T = 64;
+        while (T < 2LL * n) T <<= 1;
+        if (T > slice) T = slice;
+        const long long mask = T - 1;
+        for (long long i = threadIdx.x; i < T; i += BS) {
+            keys[i] = -1;
+            vals[i] = 0;
+        }
+        __syncthreads();
+        const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+        for (int j = a_beg + (threadIdx.x >> 6); j < a_end; j += BS / 64) {
+            const int c = acol[j];
+            const real av = aval[j];
+            const int ke = brpt[c + 1];
+            for (int k = brpt[c] + lane; k < ke; k += 64) {
+                int fresh;
+                const long long h = gt_find_or_insert(keys, mask, bcol[k], &fresh);
+                unsafeAtomicAdd(vals + h, av * bval[k]);
+            }
+        }
+        __syncthreads();
+        for (long long base = (threadIdx.x >> 6) * 64; base < T; base += BS) {
+            const int key = __hip_atomic_load(keys + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool occ = key != -1;
+            const unsigned long long m = __ballot(occ);
+            if (m) {
+                int start = 0;
+                if (lane == 0) start = atomicAdd(&s_cnt, __popcll(m));
+                start = __shfl(start, 0);
+                if (occ) {
+                    const int pos = off + start + __popcll(m & ((1ull << lane) - 1ull));
+                    tcol[pos] = key;
+                    tval[pos] = __hip_atomic_load(vals + base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace spgemm
+}  // namespace nsp

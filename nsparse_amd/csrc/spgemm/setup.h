@@ -1,0 +1,372 @@
+// spgemm/setup.h -- products per row, column windows, histogram, bin-grouped row permutation.
+// Part of the spgemm_hash.hip translation unit (kernels are launched from its host code).
+#pragma once
+#include "common.h"
+
+namespace nsp {
+namespace spgemm {
+
+// ===================================================================================
+//  setup: products per row, histogram, bin-grouped row permutation
+// ===================================================================================
+
+// W lanes cooperate on one row of A (W = pow2 <= 64 chosen from the average row length so
+// that the A.col loads of a wave coalesce).  Restates set_intprod_num (:70-86) fused with
+// set_bin (:88-112) and with the flop sum of get_spgemm_flop.
+// One 16-byte record per row of B: where it starts, how long it is, and its smallest / largest
+// column id (rows need not be sorted).  Every later stage reaches a B row through ONE gather of
+// this record instead of two B.rpt loads (+ two window loads): the column window of a C row is
+// the union of the windows of the B rows it touches.
+struct __attribute__((aligned(16))) BInfo {
+    int start, len, lo, hi;
+};
+
+template <int W>
+__global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                int K, BInfo *__restrict__ info, BinState *bs,
+                                                int *__restrict__ long_list, int *long_cnt, int long_len,
+                                                const int *__restrict__ todo)
+{
+    // W lanes per row of B (W from the average row length, so the column loads coalesce).
+    // todo == nullptr: bulk pass over all rows; rows longer than long_len are deferred to
+    // long_list.  todo != nullptr: pass over the deferred rows todo[0 .. min(*long_cnt, cap)).
+    constexpr int RPB = 256 / W;
+    const int lane = threadIdx.x % W;
+    const int nrows = todo ? (*long_cnt < kLongCap ? *long_cnt : kLongCap) : K;
+    for (int base = blockIdx.x * RPB; base < nrows; base += gridDim.x * RPB) {
+        const int q = base + (int)threadIdx.x / W;
+        const int r = q < nrows ? (todo ? todo[q] : q) : -1;
+        int lo = 0x7fffffff, hi = -1, b = 0, e = 0;
+        bool bad = false;
+        if (r >= 0) {
+            b = brpt[r];
+            e = brpt[r + 1];
+        }
+        int ok = 0;
+        if (r >= 0 && !todo && long_list && e - b > long_len && lane == 0) {
+            const int idx = atomicAdd(long_cnt, 1);
+            ok = idx < kLongCap;
+            if (ok) long_list[idx] = r;
+        }
+        const bool defer = __shfl(ok, 0, W) != 0;
+        if (r >= 0 && !defer) {
+            for (int k = b + lane; k < e; k += W) {
+                const int c = bcol[k];
+                if (k > b) bad |= c <= bcol[k - 1];  // strictly ascending?  (neighbour is in cache)
+                lo = c < lo ? c : lo;
+                hi = c > hi ? c : hi;
+            }
+        }
+#pragma unroll
+        for (int o = W / 2; o >= 1; o >>= 1) {
+            const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o);
+            lo = l < lo ? l : lo;
+            hi = h > hi ? h : hi;
+        }
+        if (bad) atomicOr(&bs->b_unsorted, 1);
+        if (r >= 0 && !defer && lane == 0) {
+            BInfo o;
+            o.start = b;
+            o.len = e - b;
+            o.lo = lo;
+            o.hi = hi;
+            info[r] = o;
+        }
+    }
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ arpt,
+                                                      const int *__restrict__ acol,
+                                                      const BInfo *__restrict__ binfo, int M,
+                                                      int *__restrict__ row_prod,
+                                                      int *__restrict__ row_lo,
+                                                      int *__restrict__ row_span,
+                                                      int *__restrict__ bm_words, int bm_span_max,
+                                                      Thr thr, long long *__restrict__ partial,
+                                                      int *__restrict__ row_span_num,
+                                                      int *__restrict__ row_nz,
+                                                      int *__restrict__ row_maxb,
+                                                      int *__restrict__ long_list, int *long_cnt,
+                                                      int long_len, const int *__restrict__ todo)
+{
+    // todo == nullptr: bulk pass, rows of A longer than long_len are deferred to long_list;
+    // todo != nullptr: the deferred rows (see kLongFactor)
+    const int nrows = todo ? (*long_cnt < kLongCap ? *long_cnt : kLongCap) : M;
+    if (!todo && blockIdx.x == 0 && threadIdx.x == 0) {  // scan tails (instead of two memset launches)
+        bm_words[M] = 0;
+        row_nz[M] = 0;
+    }
+    __shared__ int s_hist[NB];
+    __shared__ int s_max;
+    __shared__ unsigned long long s_total;
+    __shared__ unsigned long long s_bm;
+    __shared__ int s_alen;
+    if (threadIdx.x < NB) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_max = 0; s_total = 0; s_bm = 0; s_alen = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x % W;
+    constexpr int RPB = 256 / W;
+    // per-thread statistics, folded once per wave at the end: one LDS atomic per row would
+    // serialise when (almost) every row falls into the same bin (1 M-row power-law inputs)
+    int t_max = 0, t_alen = 0;
+    unsigned long long t_total = 0, t_bm = 0;
+    // grid-stride over rows
+    for (int base = blockIdx.x * RPB; base < nrows; base += gridDim.x * RPB) {
+        const int q = base + (int)threadIdx.x / W;
+        int row = q < nrows ? (todo ? todo[q] : q) : M;
+        long long n = 0;
+        int lo = 0x7fffffff, hi = -1, mb = 0;
+        {
+            int ok = 0;
+            if (row < M && !todo && long_list && arpt[row + 1] - arpt[row] > long_len && lane == 0) {
+                const int idx = atomicAdd(long_cnt, 1);
+                ok = idx < kLongCap;
+                if (ok) long_list[idx] = row;
+            }
+            if (__shfl(ok, 0, W) != 0) row = M;  // deferred: nothing to do for this group now
+        }
+        if (row < M) {
+            const int e = arpt[row + 1];
+            int j = arpt[row] + lane;
+            for (; j + 3 * W < e; j += 4 * W) {  // four independent gathers in flight
+                int c[4];
+                BInfo bi[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) c[u] = __builtin_nontemporal_load(acol + j + u * W);
+#pragma unroll
+                for (int u = 0; u < 4; u++) bi[u] = binfo[c[u]];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    n += bi[u].len;
+                    mb = bi[u].len > mb ? bi[u].len : mb;
+                    lo = bi[u].lo < lo ? bi[u].lo : lo;
+                    hi = bi[u].hi > hi ? bi[u].hi : hi;
+                }
+            }
+            for (; j < e; j += W) {
+                const int c = __builtin_nontemporal_load(acol + j);
+                const BInfo bi = binfo[c];
+                n += bi.len;
+                mb = bi.len > mb ? bi.len : mb;
+                lo = bi.lo < lo ? bi.lo : lo;
+                hi = bi.hi > hi ? bi.hi : hi;
+            }
+        }
+#pragma unroll
+        for (int o = W / 2; o >= 1; o >>= 1) {
+            n += __shfl_xor(n, o);
+            const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o), m2 = __shfl_xor(mb, o);
+            lo = l < lo ? l : lo;
+            hi = h > hi ? h : hi;
+            mb = m2 > mb ? m2 : mb;
+        }
+        int bin = -1;
+        if (row < M && lane == 0) {
+            const int ni = n > 0x7fffffffLL ? 0x7fffffff : (int)n;  // saturate (hub rows)
+            const long long sp = hi >= lo ? (long long)hi - lo + 1 : 0;
+            const int span = sp > 0x7fffffffLL ? 0x7fffffff : (int)sp;
+            row_prod[row] = ni;
+            row_lo[row] = hi >= lo ? lo : 0;
+            row_span[row] = span;
+            row_maxb[row] = mb;
+            // words of the column bitmap the symbolic dense kernel hands to the numeric one
+            const int bw = (span > 0 && span <= bm_span_max) ? (span + 31) >> 5 : 0;
+            bm_words[row] = bw;
+            row_span_num[row] = 0;  // set by k_sym_dense when it hands a bitmap over
+            bin = bin_of(ni, span, thr);
+            const int al = arpt[row + 1] - arpt[row];
+            if (W >= 16) {  // at most 4 rows per wave: direct LDS atomics are cheapest
+                atomicAdd(&s_hist[bin], 1);
+                atomicMax(&s_max, ni);
+                atomicMax(&s_alen, al);
+                atomicAdd(&s_total, (unsigned long long)n);
+                if (bw) atomicAdd(&s_bm, (unsigned long long)bw);
+            } else {
+                t_max = ni > t_max ? ni : t_max;
+                t_alen = al > t_alen ? al : t_alen;
+                t_total += (unsigned long long)n;
+                t_bm += (unsigned long long)bw;
+            }
+        }
+        if (W < 16) {
+            // histogram: one LDS atomic per (wave, bin present in the wave)
+            unsigned long long todo = __ballot(bin >= 0);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int b = __shfl(bin, leader);
+                const unsigned long long same = __ballot(bin == b);
+                if ((threadIdx.x & 63) == leader) atomicAdd(&s_hist[b], __popcll(same));
+                todo &= ~same;
+            }
+        }
+    }
+    if (W < 16) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int m1 = __shfl_xor(t_max, o), m2 = __shfl_xor(t_alen, o);
+            t_max = m1 > t_max ? m1 : t_max;
+            t_alen = m2 > t_alen ? m2 : t_alen;
+            t_total += __shfl_xor(t_total, o);
+            t_bm += __shfl_xor(t_bm, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&s_max, t_max);
+            atomicMax(&s_alen, t_alen);
+            atomicAdd(&s_total, t_total);
+            atomicAdd(&s_bm, t_bm);
+        }
+    }
+    __syncthreads();
+    // Per-block partials with plain stores; k_reduce_partials folds them.  (Same-address
+    // device-scope atomics from thousands of workgroups serialise at ~20 ns each on the
+    // 8-XCD part: 0.38 ms for 15 K blocks, 0.14 ms for 2 K -- measured.)
+    long long *out = partial + (long long)blockIdx.x * kPartialStride;
+    if (threadIdx.x < NB) out[threadIdx.x] = s_hist[threadIdx.x];
+    if (threadIdx.x == 0) {
+        out[NB] = s_max;
+        out[NB + 1] = (long long)s_total;
+        out[NB + 2] = (long long)s_bm;
+        out[NB + 3] = s_alen;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reduce_partials(const long long *__restrict__ partial, int nblocks,
+                                                         BinState *bs)
+{
+    __shared__ unsigned long long s_acc[kPartialStride];
+    __shared__ int s_max;
+    __shared__ int s_alen;
+    if (threadIdx.x < kPartialStride) s_acc[threadIdx.x] = 0;
+    if (threadIdx.x == 0) { s_max = 0; s_alen = 0; }
+    __syncthreads();
+    // a few dozen workgroups, each folds a slice of the partials and issues one global atomic
+    // per field: thread t handles field (t % 16) of partials t/16, t/16 + 16, ... of its slice
+    const int per = (nblocks + gridDim.x - 1) / gridDim.x;
+    const int b0 = blockIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
+    const int f = threadIdx.x & 15;
+    if (f < NB + 4) {
+        long long acc = 0;
+        for (int b = b0 + (threadIdx.x >> 4); b < b1; b += 16) {
+            const long long v = partial[(long long)b * kPartialStride + f];
+            acc = (f == NB || f == NB + 3) ? (v > acc ? v : acc) : acc + v;
+        }
+        if (f == NB) atomicMax(&s_max, (int)acc);
+        else if (f == NB + 3) atomicMax(&s_alen, (int)acc);
+        else if (acc) atomicAdd(&s_acc[f], (unsigned long long)acc);
+    }
+    __syncthreads();
+    if (threadIdx.x < NB && s_acc[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], (int)s_acc[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        if (s_max) atomicMax(&bs->maxv, s_max);
+        if (s_acc[NB + 1]) atomicAdd((unsigned long long *)&bs->total, s_acc[NB + 1]);
+        if (s_acc[NB + 2]) atomicAdd((unsigned long long *)&bs->bm_total, s_acc[NB + 2]);
+        if (s_alen) atomicMax((unsigned long long *)&bs->max_alen, (unsigned long long)s_alen);
+    }
+}
+
+// Copy a counter block to mapped host memory and raise a sequence flag: the host polls the
+// flag instead of paying hipMemcpyAsync + hipStreamSynchronize (~40 us per round trip here).
+__global__ __launch_bounds__(64) void k_publish(const BinState *__restrict__ src, int *dst, int words,
+                                                const int *__restrict__ nnz_src, int *flag, int seq)
+{
+    const int *s = reinterpret_cast<const int *>(src);
+    for (int i = threadIdx.x; i < words; i += 64) dst[i] = s[i];
+    if (nnz_src && threadIdx.x == 0) reinterpret_cast<BinState *>(dst)->nnz = *nnz_src;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// histogram of an existing per-row count (numeric binning, set_min_bin :201-246)
+__global__ __launch_bounds__(1024) void k_hist(const int *__restrict__ n, const int *__restrict__ span,
+                                              int M, Thr thr, BinState *bs)
+{
+    __shared__ int s_hist[NB];
+    __shared__ int s_max;
+    __shared__ unsigned long long s_sum;  // 64-bit: the int scan of the same numbers may wrap
+    if (threadIdx.x < NB) s_hist[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        s_max = 0;
+        s_sum = 0;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + threadIdx.x;  // 1024 rows per block: 4x fewer same-address
+    int bin = -1, v = 0;                             // global atomics at the end
+    if (i < M) {
+        v = n[i];
+        bin = bin_of(v, span[i], thr);
+    }
+    unsigned long long todo = __ballot(bin >= 0);
+    while (todo) {  // one LDS atomic per (wave, bin present in the wave)
+        const int leader = __ffsll((long long)todo) - 1;
+        const int b = __shfl(bin, leader);
+        const unsigned long long same = __ballot(bin == b);
+        if ((threadIdx.x & 63) == leader) atomicAdd(&s_hist[b], __popcll(same));
+        todo &= ~same;
+    }
+    unsigned long long sum = (unsigned long long)v;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int m = __shfl_xor(v, o);
+        v = m > v ? m : v;
+        sum += __shfl_xor(sum, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(&s_max, v);
+        atomicAdd(&s_sum, sum);
+    }
+    __syncthreads();
+    if (threadIdx.x < NB && s_hist[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], s_hist[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        atomicMax(&bs->maxv, s_max);
+        if (s_sum) atomicAdd((unsigned long long *)&bs->total, s_sum);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_row_len(const int *__restrict__ rpt, int *__restrict__ len, int M)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < M) len[i] = rpt[i + 1] - rpt[i];
+}
+
+// rows grouped by bin (set_row_perm :125-154): one LDS pass ranks the rows of a block
+// inside their bin, one global atomic per (block, bin) reserves the range.
+__global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
+                                                     const int *__restrict__ span, int M, Thr thr,
+                                                     BinState *bs, int *__restrict__ perm)
+{
+    __shared__ int s_cnt[NB];
+    __shared__ int s_base[NB];
+    if (threadIdx.x < NB) s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int b = -1, r = 0;
+    if (i < M) b = bin_of(n[i], span[i], thr);
+    // rank inside the block: ballot + popcount inside the wave, one LDS atomic per (wave, bin)
+    unsigned long long todo = __ballot(b >= 0);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int bb = __shfl(b, leader);
+        const unsigned long long same = __ballot(b == bb);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&s_cnt[bb], __popcll(same));
+        base = __shfl(base, leader);
+        if (b == bb) r = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if (b < 0) b = 0;
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        int off = 0;
+        for (int q = 0; q < (int)threadIdx.x; q++) off += bs->hist[q];
+        const int c = s_cnt[threadIdx.x];
+        s_base[threadIdx.x] = off + (c ? atomicAdd(&bs->cursor[threadIdx.x], c) : 0);
+    }
+    __syncthreads();
+    if (i < M) perm[s_base[b] + r] = i;
+}
+
+}  // namespace spgemm
+}  // namespace nsp

@@ -1,0 +1,177 @@
+// spgemm/symbolic.h -- symbolic hash kernels (bins 0-5).
+// Part of the spgemm_hash.hip translation unit (kernels are launched from its host code).
+#pragma once
+#include "common.h"
+
+namespace nsp {
+namespace spgemm {
+
+// ===================================================================================
+//  symbolic phase
+// ===================================================================================
+
+// bin 0: LPR lanes per row, TROW keys per row (set_row_nz_bin_pwarp :266-327).
+template <int BS, int LPR, int TROW>
+__global__ __launch_bounds__(BS) void k_sym_small(const int *__restrict__ arpt,
+                                                  const int *__restrict__ acol,
+                                                  const int *__restrict__ brpt,
+                                                  const int *__restrict__ bcol,
+                                                  const int *__restrict__ row_perm,
+                                                  int *__restrict__ row_nz, int bin_off, int bin_size)
+{
+    constexpr int RPB = BS / LPR;
+    __shared__ int tab[RPB * TROW];
+    for (int i = threadIdx.x; i < RPB * TROW; i += BS) tab[i] = -1;
+    __syncthreads();
+    const int lrow = threadIdx.x / LPR;
+    const int sub = threadIdx.x % LPR;
+    const int q = blockIdx.x * RPB + lrow;
+    int cnt = 0;
+    int rid = 0;
+    if (q < bin_size) {
+        rid = row_perm[bin_off + q];
+        int *t = tab + lrow * TROW;
+        const int e = arpt[rid + 1];
+        for (int j = arpt[rid] + sub; j < e; j += LPR) {
+            const int c = __builtin_nontemporal_load(acol + j);
+            const int ke = brpt[c + 1];
+            for (int k = brpt[c]; k < ke; k++) {
+                int fresh;
+                ht_find_or_insert(t, TROW - 1, bcol[k], &fresh);
+                cnt += fresh;
+            }
+        }
+    }
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) cnt += __shfl_xor(cnt, o);
+    if (q < bin_size && sub == 0) row_nz[rid] = cnt;
+}
+
+// bins 1..5: one workgroup per row (set_row_nz_bin_each_tb :399-472; LARGE = the try-in-LDS
+// kernel with a fail list, set_row_nz_bin_each_tb_large :474-554).
+template <int BS, int TMAX, bool LARGE>
+__global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
+                                               const int *__restrict__ acol,
+                                               const int *__restrict__ brpt,
+                                               const int *__restrict__ bcol,
+                                               const int *__restrict__ row_perm,
+                                               const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb,
+                                               int *__restrict__ row_nz, int bin_off, int bin_size,
+                                               int bnnz, BinState *bs, int *__restrict__ fail_list)
+{
+    __shared__ __attribute__((aligned(16))) int tab[TMAX];
+    __shared__ int2 s_ext[LARGE ? 1 : BS];
+    __shared__ int s_nz;
+    const int slot = xcd_row_slot(bin_size);
+    if (slot < 0) return;
+    const int rid = row_perm[bin_off + slot];
+    const int np = row_prod[rid];
+    int T = LARGE ? TMAX : pow2_ceil(np);
+    if (T < 64) T = 64;
+    if (T > TMAX) T = TMAX;
+    const int mask = T - 1;
+    {
+        int4 *t4 = reinterpret_cast<int4 *>(tab);
+        const int4 m1 = make_int4(-1, -1, -1, -1);
+        for (int i = threadIdx.x; i < T / 4; i += BS) t4[i] = m1;
+    }
+    if (threadIdx.x == 0) s_nz = 0;
+    __syncthreads();
+
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int g = group_width(np, a_end - a_beg, BS, row_maxb[rid]);
+    int cnt = 0;
+    if (!LARGE) {
+        walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz,
+                                 a_beg, a_end, g, s_ext, (real *)nullptr,
+                                 [&](const IVec &k, const RVec &, int n, real) {
+                                     int h[VW];
+                                     ht_insert_vec(tab, mask, k, n, h, cnt);
+                                 });
+    } else {
+        // try-in-LDS: plain walk with early exit once the table holds kSymLargeLimit keys
+        const int ngroups = BS / g;
+        const int gid = threadIdx.x / g, gl = threadIdx.x % g;
+        bool full = false;
+        for (int j = a_beg + gid; j < a_end && !full; j += ngroups) {
+            const int c = __builtin_nontemporal_load(acol + j);
+            const int ke = brpt[c + 1];
+            for (int k = brpt[c] + gl; k < ke; k += g) {
+                if (lds_load(&s_nz) >= kSymLargeLimit) { full = true; break; }
+                int fresh;
+                ht_find_or_insert(tab, mask, bcol[k], &fresh);
+                if (fresh) atomicAdd(&s_nz, 1);
+            }
+        }
+    }
+    if (!LARGE) {
+        cnt = wave_sum(cnt);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int nz = s_nz;
+        if (LARGE && nz >= kSymLargeLimit) {
+            fail_list[atomicAdd(&bs->fail_count, 1)] = rid;
+        } else {
+            row_nz[rid] = nz;
+        }
+    }
+}
+
+// overflow rows: persistent workgroups, private slice of a global slab
+// (set_row_nz_bin_each_gl :556-622, bounded-memory variant HashSpGEMM_volta.hpp:341-412).
+template <int BS>
+__global__ __launch_bounds__(BS) void k_sym_global(const int *__restrict__ arpt,
+                                                   const int *__restrict__ acol,
+                                                   const int *__restrict__ brpt,
+                                                   const int *__restrict__ bcol,
+                                                   const int *__restrict__ fail_list, int count,
+                                                   const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb,
+                                                   int *__restrict__ row_nz, int ncols,
+                                                   BinState *bs, int *__restrict__ slab,
+                                                   long long slice)
+{
+    __shared__ int s_row;
+    __shared__ int s_nz;
+    int *tab = slab + (long long)blockIdx.x * slice;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            s_row = atomicAdd(&bs->queue_head, 1);
+            s_nz = 0;
+        }
+        __syncthreads();
+        const int q = s_row;
+        if (q >= count) break;
+        const int rid = fail_list[q];
+        long long bound = row_prod[rid];
+        if (bound > ncols) bound = ncols;  // a row of C has at most ncols distinct columns
+        long long T = 64;
+        while (T < 2 * bound) T <<= 1;
+        if (T > slice) T = slice;
+        const long long mask = T - 1;
+        for (long long i = threadIdx.x; i < T; i += BS) tab[i] = -1;
+        __syncthreads();
+        const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+        int cnt = 0;
+        for (int j = a_beg + (threadIdx.x >> 6); j < a_end; j += BS / 64) {
+            const int c = acol[j];
+            const int ke = brpt[c + 1];
+            for (int k = brpt[c] + (threadIdx.x & 63); k < ke; k += 64) {
+                int fresh;
+                gt_find_or_insert(tab, mask, bcol[k], &fresh);
+                cnt += fresh;
+            }
+        }
+        cnt = wave_sum(cnt);
+        if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
+        __syncthreads();
+        if (threadIdx.x == 0) row_nz[rid] = s_nz;
+    }
+}
+
+}  // namespace spgemm
+}  // namespace nsp

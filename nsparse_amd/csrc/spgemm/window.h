@@ -1,0 +1,229 @@
+// spgemm/window.h -- dense-window and bit-window rows (bins 6-10).
+// Part of the spgemm_hash.hip translation unit (kernels are launched from its host code).
+#pragma once
+#include "common.h"
+
+namespace nsp {
+namespace spgemm {
+
+// ===================================================================================
+//  dense-window rows (bins 6..8)
+// ===================================================================================
+// The columns a C row can contain lie in [lo, lo + span) (union of the column windows of the
+// B rows it touches, computed in k_row_products).  When span fits LDS the row needs no hash
+// table: symbolic = one byte flag per column, set with a plain LDS store (idempotent, no
+// atomic, no return value to wait for), count = popcount of the flags; numeric = one real per
+// column accumulated with a no-return LDS atomic add, emitted in ascending order by scanning
+// the flags with ballot/popcount -- no compaction pass and no sort.  The reference has no such
+// path (48 KB of shared memory per block on its target); on CDNA4's 160 KiB it covers every row
+// of a banded / FEM matrix.  Wide-window rows (graphs) stay on the hash bins.
+
+template <int BS, int SPAN_MAX>
+__global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                  const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                  const int *__restrict__ row_perm,
+                                                  const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb,
+                                                  const int *__restrict__ row_lo,
+                                                  const int *__restrict__ row_span,
+                                                  int *__restrict__ row_nz, int bin_off, int bin_size,
+                                                  int bnnz, const int *__restrict__ bm_off,
+                                                  unsigned int *__restrict__ bm,
+                                                  int *__restrict__ row_span_num)
+{
+    __shared__ __attribute__((aligned(16))) unsigned int flag4[SPAN_MAX / 4 + 8];
+    __shared__ int2 s_ext[BS];
+    __shared__ int s_nz;
+    const int slot = xcd_row_slot(bin_size);
+    if (slot < 0) return;
+    const int rid = row_perm[bin_off + slot];
+    const int lo = row_lo[rid];
+    const int span = row_span[rid];
+    const int words = (span + 3) >> 2;
+    {
+        uint4 *f4 = reinterpret_cast<uint4 *>(flag4);
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        for (int i = threadIdx.x; i < (words + 3) / 4 + 2; i += BS) f4[i] = z;  // + bitmap tail
+    }
+    if (threadIdx.x == 0) s_nz = 0;
+    __syncthreads();
+    unsigned char *flag = reinterpret_cast<unsigned char *>(flag4);
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
+    walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
+                             a_end, g, s_ext, (real *)nullptr,
+                             [&](const IVec &k, const RVec &, int n, real) {
+#pragma unroll
+                                 for (int i = 0; i < VW; i++)
+                                     if (i < n) flag[k.v[i] - lo] = 1;
+                             });
+    __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < words; i += BS) cnt += __popc(flag4[i] & 0x01010101u);
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
+    // Hand the structure to the numeric phase: 1 bit per column of the window, 32 flag bytes
+    // -> one word.  The numeric dense kernel then needs no flags of its own (one LDS atomic
+    // per product instead of an atomic and a store) and no sort.
+    if (bm != nullptr) {
+        const int bw = bm_off[rid + 1] - bm_off[rid];
+        unsigned int *dst = bm + bm_off[rid];
+        for (int wi = threadIdx.x; wi < bw; wi += BS) {
+            unsigned int bits = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const unsigned int x = flag4[wi * 8 + q] & 0x01010101u;
+                bits |= ((x * 0x01020408u) >> 24) << (4 * q);
+            }
+            dst[wi] = bits;
+        }
+        if (threadIdx.x == 0) row_span_num[rid] = bw > 0 ? span : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) row_nz[rid] = s_nz;
+}
+
+// Symbolic for rows with many products and a wide window: one BIT per column of the window in
+// LDS (128 KiB cover 2^20 columns), set with a no-return LDS atomic OR.  Replaces the 32768-key
+// hash table (1 workgroup per CU, CAS with return per product) and the try-in-LDS / global
+// table detour for every row of a matrix with up to a million columns.
+template <int BS, int WORDS_MAX>
+__global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                 const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                 const int *__restrict__ row_perm,
+                                                 const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb,
+                                                 const int *__restrict__ row_lo,
+                                                 const int *__restrict__ row_span,
+                                                 int *__restrict__ row_nz, int bin_off, int bin_size,
+                                                 int bnnz)
+{
+    __shared__ __attribute__((aligned(16))) unsigned int bits[WORDS_MAX];
+    __shared__ int2 s_ext[BS];
+    __shared__ int s_nz;
+    const int slot = xcd_row_slot(bin_size);
+    if (slot < 0) return;
+    const int rid = row_perm[bin_off + slot];
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
+    if (threadIdx.x == 0) s_nz = 0;
+    int cnt = 0;
+    // A window wider than the bitmap is covered in pieces: every piece walks all products again
+    // and keeps the columns that fall into it (no cursors: the walk is a fraction of what a hash
+    // table filled to the brim costs, and the row need not be sorted).
+    const int row_hi = row_lo[rid] + row_span[rid];
+    for (int lo = row_lo[rid]; lo < row_hi; lo += WORDS_MAX * 32) {
+        const int cols = row_hi - lo < WORDS_MAX * 32 ? row_hi - lo : WORDS_MAX * 32;
+        const int words = (cols + 31) >> 5;
+        {
+            uint4 *b4 = reinterpret_cast<uint4 *>(bits);
+            const uint4 z = make_uint4(0, 0, 0, 0);
+            for (int i = threadIdx.x; i < (words + 3) / 4; i += BS) b4[i] = z;
+        }
+        __syncthreads();
+        walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
+                                 a_end, g, s_ext, (real *)nullptr,
+                                 [&](const IVec &k, const RVec &, int n, real) {
+#pragma unroll
+                                     for (int i = 0; i < VW; i++)
+                                         if (i < n) {
+                                             const unsigned int idx = (unsigned int)(k.v[i] - lo);
+                                             if (idx < (unsigned int)cols) atomicOr(bits + (idx >> 5), 1u << (idx & 31));
+                                         }
+                                 });
+        __syncthreads();
+        for (int i = threadIdx.x; i < words; i += BS) cnt += __popc(bits[i]);
+        __syncthreads();
+    }
+    cnt = wave_sum(cnt);
+    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
+    __syncthreads();
+    if (threadIdx.x == 0) row_nz[rid] = s_nz;
+}
+
+template <int BS, int SPAN_MAX, int MODE>
+__global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                  const real *__restrict__ aval,
+                                                  const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                  const real *__restrict__ bval,
+                                                  const int *__restrict__ crpt, int *__restrict__ ccol,
+                                                  real *__restrict__ cval,
+                                                  const int *__restrict__ row_perm,
+                                                  const int *__restrict__ row_prod,
+                                                  const int *__restrict__ row_maxb,
+                                                  const int *__restrict__ row_lo,
+                                                  const int *__restrict__ row_span, int bin_off,
+                                                  int bin_size, int bnnz,
+                                                  const int *__restrict__ bm_off,
+                                                  const unsigned int *__restrict__ bm)
+{
+    // MODE 1: full call -- the column structure of the row comes from the bitmap written by
+    //         k_sym_dense; columns and values are emitted in ascending order.
+    // MODE 2: numeric-only re-run -- C.col exists; values are gathered at its columns.
+    constexpr int NW = BS / 64;
+    __shared__ __attribute__((aligned(16))) real dense[SPAN_MAX + 4];
+    __shared__ int2 s_ext[BS];
+    __shared__ real s_av[BS];
+    __shared__ int s_wcnt[NW];
+    const int slot = xcd_row_slot(bin_size);
+    if (slot < 0) return;
+    const int rid = row_perm[bin_off + slot];
+    const int off = crpt[rid];
+    const int lo = row_lo[rid];
+    const int span = row_span[rid];
+    // The VW entries a lane holds have consecutive columns inside a run, so one atomic
+    // instruction sees columns of stride VW across the lanes: the value of column idx lives at
+    // (idx & 3) * Q + (idx >> 2), which turns that stride into consecutive 8-byte slots.
+    const int Q = (span + 3) >> 2;
+    for (int i = threadIdx.x; i < 4 * Q; i += BS) dense[i] = 0;
+    __syncthreads();
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
+    walk_products<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av,
+                            [&](const IVec &k, const RVec &v, int n, real sc) {
+#pragma unroll
+                                for (int i = 0; i < VW; i++)
+                                    if (i < n) {
+                                        const int idx = k.v[i] - lo;
+                                        unsafeAtomicAdd(dense + __mul24(idx & 3, Q) + (idx >> 2), sc * v.v[i]);
+                                    }
+                            });
+    __syncthreads();
+    if (MODE == 2) {
+        const int n = crpt[rid + 1] - off;
+        for (int p = threadIdx.x; p < n; p += BS) {
+            const int idx = ccol[off + p] - lo;
+            cval[off + p] = dense[__mul24(idx & 3, Q) + (idx >> 2)];
+        }
+        return;
+    }
+    // ordered emission: wave w owns the column range [w*R, (w+1)*R)
+    const unsigned int *bits = bm + bm_off[rid];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int R = ((span + NW * 64 - 1) / (NW * 64)) * 64;
+    const int rb = w * R, re = rb + R < span ? rb + R : span;
+    int cnt = 0;
+    for (int base = rb; base < re; base += 64) {
+        const int idx = base + lane;
+        const bool occ = idx < re && ((bits[idx >> 5] >> (idx & 31)) & 1u);
+        cnt += __popcll(__ballot(occ));
+    }
+    if (lane == 0) s_wcnt[w] = cnt;
+    __syncthreads();
+    int pos = off;
+    for (int u = 0; u < w; u++) pos += s_wcnt[u];
+    for (int base = rb; base < re; base += 64) {
+        const int idx = base + lane;
+        const bool occ = idx < re && ((bits[idx >> 5] >> (idx & 31)) & 1u);
+        const unsigned long long m = __ballot(occ);
+        if (occ) {
+            const int p = pos + __popcll(m & ((1ull << lane) - 1ull));
+            ccol[p] = lo + idx;
+            cval[p] = dense[__mul24(idx & 3, Q) + (idx >> 2)];
+        }
+        pos += __popcll(m);
+    }
+}
+
+}  // namespace spgemm
+}  // namespace nsp

@@ -116,7 +116,7 @@ def row_windows(A, B):
 
 
 def bins_of(n, span, ladder):
-    """numpy twin of bin_of() in spgemm_hash.hip; ladder = 15 ints from nsparse_get_spgemm_bins."""
+    """numpy twin of bin_of() in csrc/spgemm/common.h; ladder = 15 ints from nsparse_get_spgemm_bins."""
     n = np.asarray(n, dtype=np.int64)
     span = np.asarray(span, dtype=np.int64)
     tiny, hash_t, dspan, ratio = ladder[0], ladder[1:5], ladder[5:8], ladder[8]
