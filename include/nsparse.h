@@ -274,6 +274,14 @@ void nsparse_spmv_amb_async(real *d_y, sfAMB *mat, real *d_x, sfPlan *plan, void
 int nsparse_save_csr_bin(const sfCSR *mat, const char *path);
 int nsparse_load_csr_bin(sfCSR *mat, const char *path);
 
+/* The plan sf_csr2amb wrote back (reference convert_amb.cu:906), kept beside the matrix so that
+ * the next run skips the search (up to 100 format builds + 500 timed SpMVs with
+ * NSPARSE_AMB_TUNE=timed).  A one-line text file; load returns 0 and sets isPlan = TRUE, or
+ * non-zero (missing, other precision build, other chunk size) and leaves *plan alone.  The sample
+ * driver amb_{s,d} uses `<file>.plan` when NSPARSE_BIN_CACHE=1 and no plan is given.          */
+int nsparse_save_plan(const sfPlan *plan, const char *path);
+int nsparse_load_plan(sfPlan *plan, const char *path);
+
 /* Synthetic stand-ins for the SuiteSparse inputs named in BASELINE.md (there is
  * no network on the GPU box).  Each fills the HOST side of *mat with malloc'd
  * arrays (free with release_cpu_csr); columns ascend inside every row.

@@ -89,6 +89,8 @@ SIGNATURES = {
     "nsparse_spmv_amb_async": (None, [C.c_void_p, _P(sfAMB), C.c_void_p, _P(sfPlan), C.c_void_p]),
     "nsparse_save_csr_bin": (C.c_int, [_P(sfCSR), C.c_char_p]),
     "nsparse_load_csr_bin": (C.c_int, [_P(sfCSR), C.c_char_p]),
+    "nsparse_save_plan": (C.c_int, [_P(sfPlan), C.c_char_p]),
+    "nsparse_load_plan": (C.c_int, [_P(sfPlan), C.c_char_p]),
     "nsparse_synth_csr": (None, [_P(sfCSR), C.c_int, C.c_longlong, C.c_longlong, C.c_longlong,
                                  C.c_ulonglong, C.c_longlong, C.c_longlong]),
 }

@@ -261,6 +261,42 @@ int nsparse_load_csr_bin(sfCSR *mat, const char *path)
 
 /* ------------------------------------------------------------------ plan --- */
 
+int nsparse_save_plan(const sfPlan *plan, const char *path)
+{
+    FILE *fp = fopen(path, "w");
+    if (!fp) return -1;
+    const int n = fprintf(fp, "NSPPLAN1 real %d chunk %d seg_size %zu block_size %d thread_block %zu thread_grid %zu "
+                              "sigma %d seg_num %zu\n",
+                          (int)sizeof(real), nsparse_set_amb_chunk(0), plan->seg_size, plan->block_size,
+                          plan->thread_block, plan->thread_grid, plan->SIGMA, plan->seg_num);
+    fclose(fp);
+    return n > 0 ? 0 : -2;
+}
+
+int nsparse_load_plan(sfPlan *plan, const char *path)
+{
+    FILE *fp = fopen(path, "r");
+    if (!fp) return -1;
+    int rb = 0, chunk = 0, bs = 0, sigma = 0;
+    size_t seg = 0, tb = 0, tg = 0, sn = 0;
+    const int got = fscanf(fp, "NSPPLAN1 real %d chunk %d seg_size %zu block_size %d thread_block %zu thread_grid %zu "
+                               "sigma %d seg_num %zu",
+                           &rb, &chunk, &seg, &bs, &tb, &tg, &sigma, &sn);
+    fclose(fp);
+    if (got != 8) return -2;
+    if (rb != (int)sizeof(real) || chunk != nsparse_set_amb_chunk(0)) return -3;  // tuned for another build
+    if (seg < 1 || seg > (size_t)USHORT_MAX || bs < 1 || bs > MAX_BLOCK_SIZE) return -4;
+    plan->isPlan = TRUE;
+    plan->seg_size = seg;
+    plan->block_size = bs;
+    plan->thread_block = tb;
+    plan->thread_grid = tg;
+    plan->SIGMA = sigma;
+    plan->seg_num = sn;
+    return 0;
+}
+
+
 void init_plan(sfPlan *plan) { plan->isPlan = FALSE; }
 
 void set_plan(sfPlan *plan, size_t seg_size, int block_size)

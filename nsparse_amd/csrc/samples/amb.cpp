@@ -29,6 +29,13 @@ int main(int argc, char **argv)
 #endif
     if (argc >= 4) set_plan(&plan, (size_t)atoi(argv[2]), atoi(argv[3]));
     else init_plan(&plan);
+    // NSPARSE_BIN_CACHE=1: the plan found for this matrix is kept beside it
+    const char *bc = getenv("NSPARSE_BIN_CACHE");
+    const bool keep_plan = bc && bc[0] == '1' && argc < 4;
+    char plan_path[4096];
+    snprintf(plan_path, sizeof plan_path, "%s.plan", argv[1]);
+    const bool had_plan = keep_plan && nsparse_load_plan(&plan, plan_path) == 0;
+    if (had_plan) fprintf(stderr, "plan: %s\n", plan_path);
 
     csr_memcpy(&mat);
     real *d_x, *d_y;
@@ -42,6 +49,7 @@ int main(int argc, char **argv)
     gettimeofday(&t0, NULL);
     sf_csr2amb(&amb, &mat, d_x, &plan);
     gettimeofday(&t1, NULL);
+    if (keep_plan && !had_plan) (void)nsparse_save_plan(&plan, plan_path);
     printf("Format Conversion Cost (CSR=>AMB, %d-%d): %f[msec]\n", (int)amb.seg_size, amb.block_size,
            (float)(t1.tv_sec - t0.tv_sec) * 1000 + (float)(t1.tv_usec - t0.tv_usec) / 1000);
 

@@ -233,3 +233,29 @@ def test_binary_matrix_cache(tmp_path, lib_d, lib_s):
     r2 = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, env=env)
     want = f"{A['M']} {A['nnz']} {A['nnz_max']}"  # C stdio and Python print interleave freely
     assert r2.returncode == 0 and want in r1.stdout.splitlines() and want in r2.stdout.splitlines()
+
+
+def test_plan_file_round_trip(tmp_path, lib_d, lib_s):
+    """nsparse_save_plan / nsparse_load_plan: every field back, isPlan TRUE; a plan written by the
+    other precision build or for the other chunk size is refused and leaves the plan alone."""
+    p = ns.sfPlan()
+    lib_d.set_plan(C.byref(p), 4096, 7)
+    p.thread_block, p.thread_grid, p.SIGMA, p.seg_num = 256, 1234, 32767, 16
+    path = str(tmp_path / "m.mtx.plan").encode()
+    assert lib_d.nsparse_save_plan(C.byref(p), path) == 0
+    q = ns.sfPlan()
+    lib_d.init_plan(C.byref(q))
+    assert lib_d.nsparse_load_plan(C.byref(q), path) == 0
+    assert (q.isPlan, q.seg_size, q.block_size, q.thread_block, q.thread_grid, q.SIGMA, q.seg_num) == \
+        (1, 4096, 7, 256, 1234, 32767, 16)
+    r = ns.sfPlan()
+    lib_s.init_plan(C.byref(r))
+    assert lib_s.nsparse_load_plan(C.byref(r), path) == -3 and r.isPlan == 0
+    old = lib_d.nsparse_set_amb_chunk(32)
+    try:
+        assert lib_d.nsparse_load_plan(C.byref(r), path) == -3
+    finally:
+        lib_d.nsparse_set_amb_chunk(64)
+    assert old == 32 and lib_d.nsparse_load_plan(C.byref(r), b"/nonexistent.plan") == -1
+    open(path, "w").write("garbage\n")
+    assert lib_d.nsparse_load_plan(C.byref(r), path) == -2

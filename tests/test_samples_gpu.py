@@ -42,3 +42,20 @@ def test_amb_cli(prec, plan):
         assert (m.group(1), m.group(2)) == plan
     assert re.search(r"SpMV using AMB format: .*test\.mtx, [\d.]+\[GFLOPS\], [\d.]+\[ms\]", out)
     assert "Calculation Result is Correct" in out
+
+
+def test_amb_cli_keeps_the_plan_beside_the_matrix(tmp_path):
+    """NSPARSE_BIN_CACHE=1: the first run writes <file>.plan (and <file>.csr.bin), the second run
+    converts with that plan instead of searching; same layout, same verdict."""
+    import shutil
+    mtx = str(tmp_path / "test.mtx")
+    shutil.copy(MTX, mtx)
+    exe = os.path.join(ns.capi.LIB_DIR, "amb_d")
+    env = dict(os.environ, NSPARSE_BIN_CACHE="1")
+    runs = [subprocess.run([exe, mtx], capture_output=True, text=True, timeout=300, env=env) for _ in range(2)]
+    assert all(r.returncode == 0 for r in runs), runs[-1].stderr[-2000:]
+    assert os.path.exists(mtx + ".plan") and os.path.exists(mtx + ".csr.bin")
+    assert "plan:" not in runs[0].stderr and "plan: " + mtx + ".plan" in runs[1].stderr
+    conv = [re.search(r"CSR=>AMB, (\d+)-(\d+)\)", r.stdout).groups() for r in runs]
+    assert conv[0] == conv[1]
+    assert all("Calculation Result is Correct" in r.stdout for r in runs)
