@@ -21,21 +21,105 @@ struct __attribute__((aligned(16))) BInfo {
     int start, len, lo, hi;
 };
 
+// Rows of B that A can reach: [0x7fffffff - range[0], range[1]), both kept as maxima so that
+// zero means "nothing seen".  When A is a row block of a larger problem (1-D row partition, B
+// replicated) only that stretch of B needs its records.  Two steps without same-address atomics
+// (they serialise across the 8 XCDs at ~20 ns each): per-workgroup partials, then one workgroup
+// folds them.
+__global__ __launch_bounds__(256) void k_col_range(const int *__restrict__ acol, int nnz,
+                                                   unsigned int *__restrict__ part)
+{
+    __shared__ unsigned int s_a[4], s_b[4];
+    unsigned int a = 0, b = 0;
+    auto see = [&](int col) {
+        const unsigned int c = (unsigned int)col;
+        a = a > 0x7fffffffu - c ? a : 0x7fffffffu - c;
+        b = b > c + 1 ? b : c + 1;
+    };
+    const int n4 = nnz >> 2;
+    const int4 *c4 = reinterpret_cast<const int4 *>(acol);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const int4 v = c4[i];
+        see(v.x);
+        see(v.y);
+        see(v.z);
+        see(v.w);
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < (nnz & 3)) see(acol[4 * n4 + threadIdx.x]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned int x = __shfl_xor(a, o), y = __shfl_xor(b, o);
+        a = x > a ? x : a;
+        b = y > b ? y : b;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_a[threadIdx.x >> 6] = a;
+        s_b[threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int u = 1; u < 4; u++) {
+            a = s_a[u] > a ? s_a[u] : a;
+            b = s_b[u] > b ? s_b[u] : b;
+        }
+        part[2 * blockIdx.x] = a;
+        part[2 * blockIdx.x + 1] = b;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_col_range_fold(const unsigned int *__restrict__ part, int nparts,
+                                                        unsigned int *__restrict__ range)
+{
+    __shared__ unsigned int s_a[4], s_b[4];
+    unsigned int a = 0, b = 0;
+    for (int i = threadIdx.x; i < nparts; i += 256) {
+        a = part[2 * i] > a ? part[2 * i] : a;
+        b = part[2 * i + 1] > b ? part[2 * i + 1] : b;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        const unsigned int x = __shfl_xor(a, o), y = __shfl_xor(b, o);
+        a = x > a ? x : a;
+        b = y > b ? y : b;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_a[threadIdx.x >> 6] = a;
+        s_b[threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int u = 1; u < 4; u++) {
+            a = s_a[u] > a ? s_a[u] : a;
+            b = s_b[u] > b ? s_b[u] : b;
+        }
+        range[0] = a;
+        range[1] = b;
+    }
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                 int K, BInfo *__restrict__ info, BinState *bs,
                                                 int *__restrict__ long_list, int *long_cnt, int long_len,
-                                                const int *__restrict__ todo)
+                                                const int *__restrict__ todo,
+                                                const unsigned int *__restrict__ range)
 {
     // W lanes per row of B (W from the average row length, so the column loads coalesce).
-    // todo == nullptr: bulk pass over all rows; rows longer than long_len are deferred to
-    // long_list.  todo != nullptr: pass over the deferred rows todo[0 .. min(*long_cnt, cap)).
+    // todo == nullptr: bulk pass over all rows (over the rows k_col_range found when range is
+    // given); rows longer than long_len are deferred to long_list.  todo != nullptr: pass over
+    // the deferred rows todo[0 .. min(*long_cnt, cap)).
     constexpr int RPB = 256 / W;
     const int lane = threadIdx.x % W;
-    const int nrows = todo ? (*long_cnt < kLongCap ? *long_cnt : kLongCap) : K;
+    int r0 = 0, r1 = K;
+    if (range) {
+        r0 = (int)(0x7fffffffu - range[0]);
+        r1 = (int)range[1] < K ? (int)range[1] : K;
+        if (r1 <= r0) return;
+    }
+    const int nrows = todo ? (*long_cnt < kLongCap ? *long_cnt : kLongCap) : r1 - r0;
     for (int base = blockIdx.x * RPB; base < nrows; base += gridDim.x * RPB) {
         const int q = base + (int)threadIdx.x / W;
-        const int r = q < nrows ? (todo ? todo[q] : q) : -1;
+        const int r = q < nrows ? (todo ? todo[q] : r0 + q) : -1;
         int lo = 0x7fffffff, hi = -1, b = 0, e = 0;
         bool bad = false;
         if (r >= 0) {

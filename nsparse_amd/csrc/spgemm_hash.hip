@@ -509,17 +509,32 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     if (!g_dense_enabled) sym_thr.dense_ratio = num_thr.dense_ratio = sym_thr.bits_ratio = 0;
     NSP_CHECK(hipStreamSynchronize(0));  // inputs queued on the null stream by the caller
     NSP_CHECK(hipMemsetAsync(d_sym, 0, 2 * sizeof(BinState), s0));
-    NSP_CHECK(hipMemsetAsync(long_cnt, 0, 2 * sizeof(int), s0));
+    NSP_CHECK(hipMemsetAsync(long_cnt, 0, 4 * sizeof(int), s0));  // + the two words of k_col_range
 
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
     {
         const int wb = pick_w(b->nnz, K);
-        const int gb = ceil_div((long long)K * wb, 256);
+        int gb = ceil_div((long long)K * wb, 256);
         int *blist = (b->nnz_max > 0 && b->nnz_max <= kLongFactor * wb) ? nullptr : long_list;
+        // A with fewer rows than B: a row block of a partitioned product (B replicated).  Then only
+        // the rows of B its columns reach get a record -- for a banded matrix the block's own
+        // stretch, so the set-up cost does not grow with the number of ranks.
+        unsigned int *range = nullptr, *range_part = nullptr;
+        if (M < K && a->nnz > 0) {
+            range = reinterpret_cast<unsigned int *>(long_cnt + 2);
+            const int nparts = 1024;
+            range_part = (unsigned int *)dev_alloc(sizeof(unsigned int) * 2 * nparts);
+            hipLaunchKernelGGL(k_col_range, dim3(nparts), dim3(256), 0, s0, a->d_col, a->nnz, range_part);
+            hipLaunchKernelGGL(k_col_range_fold, dim3(1), dim3(256), 0, s0, range_part, nparts, range);
+            // the stretch is not known here: a grid for all of B would mostly be workgroups that
+            // find nothing to do (25 us of them at 8 ranks), so a bounded grid strides over it
+            const int gcap = ceil_div((long long)M * wb, 256) + 1024;
+            gb = gb < gcap ? gb : gcap;
+        }
 #define NSP_BI(W)                                                                              \
     case W:                                                                                    \
         hipLaunchKernelGGL(k_b_info<W>, dim3(gb), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym, \
-                           blist, long_cnt, kLongFactor * W, (const int *)nullptr);            \
+                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range);     \
         break;
         switch (wb) {
             NSP_BI(1) NSP_BI(2) NSP_BI(4) NSP_BI(8) NSP_BI(16) NSP_BI(32) NSP_BI(64)
@@ -527,7 +542,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
 #undef NSP_BI
         if (blist)
             hipLaunchKernelGGL(k_b_info<64>, dim3(256), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym,
-                               (int *)nullptr, long_cnt, 0, (const int *)long_list);
+                               (int *)nullptr, long_cnt, 0, (const int *)long_list, (const unsigned int *)nullptr);
+        if (range_part) dev_free(range_part);  // stream-ordered reuse, see scan_exclusive
     }
     long long *partial = (long long *)dev_alloc(sizeof(long long) * kPartialStride * kSetupMaxGrid);
     // column bitmaps handed from the symbolic to the numeric dense kernels

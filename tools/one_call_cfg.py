@@ -12,6 +12,8 @@ lib.csr_memcpy(C.byref(a)); lib.csr_memcpy(C.byref(b)); c = ns.sfCSR()
 serial = os.environ.get("NSPARSE_SERIAL") == "1"
 if serial:
     lib.nsparse_set_profiling(1)
+if os.environ.get("NSPARSE_UNSORTED") == "1":
+    lib.nsparse_spgemm_set_sorted(0)
 for i in range(int(os.environ.get("NSPARSE_CALLS", "4"))):
     lib.spgemm_kernel_hash(C.byref(a), C.byref(b), C.byref(c)); lib.release_csr(c)
 st = ns.SpgemmStats(); lib.nsparse_get_spgemm_stats(C.byref(st))
