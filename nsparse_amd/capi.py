@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_DIR = os.path.join(_HERE, "lib")
+LIB_DIR = os.environ.get("NSPARSE_LIB_DIR") or os.path.join(_HERE, "lib")  # override: A/B builds
 
 c_int_p = C.POINTER(C.c_int)
 c_uint_p = C.POINTER(C.c_uint)

@@ -261,11 +261,21 @@ __device__ __forceinline__ int fetch_chunk(const int *__restrict__ bcol, const r
     return n;
 }
 
+// B rows parked by the group walk for a pass by the whole workgroup (walk_products_mixed)
+template <bool WITH_VAL>
+struct DeferList {
+    static constexpr int CAP = 32;  // small on purpose: LDS per workgroup decides the occupancy of
+    int n;                          // the one-wavefront-per-row kernels
+    int2 ext[CAP];
+    real av[WITH_VAL ? CAP : 1];
+};
+
 template <int BS, bool WITH_VAL, typename F>
 __device__ __forceinline__ void walk_products(const int *__restrict__ acol, const real *__restrict__ aval,
                                               const int *__restrict__ brpt, const int *__restrict__ bcol,
                                               const real *__restrict__ bval, int bnnz, int a_beg,
-                                              int a_end, int g, int2 *s_ext, real *s_av, F &&consume)
+                                              int a_end, int g, int2 *s_ext, real *s_av, F &&consume,
+                                              DeferList<WITH_VAL> *dl = nullptr, int defer_len = 0x7fffffff)
 {
     const int ngroups = BS / g;
     const int gid = threadIdx.x / g, gl = threadIdx.x % g;
@@ -289,6 +299,14 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
             const I2 r = *reinterpret_cast<const I2 *>(brpt + c);  // one 8-byte gather
             e.x = r.b;
             e.y = r.e;
+            if (dl && e.y - e.x > defer_len) {  // far longer than the rows g was chosen for
+                const int i = atomicAdd(&dl->n, 1);
+                if (i < DeferList<WITH_VAL>::CAP) {
+                    dl->ext[i] = e;
+                    if (WITH_VAL) dl->av[i] = av;
+                    e = make_int2(0, 0);
+                }
+            }
         }
         ext[gl] = e;
         if (WITH_VAL) avs[gl] = av;
@@ -319,6 +337,41 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
             if (cn > 0) consume(ck, cv, cn, sc);
         }
         wave_lds_sync();
+    }
+}
+
+// Rows of power-law matrices mix hundreds of B rows of two or three entries with one or two of
+// hundreds: whatever single group width is chosen, either the short rows pad 64 lanes or the long
+// row is walked 4 entries at a time by a narrow group (webbase class: 59 such rows held the whole
+// symbolic phase for 0.26 ms).  Here the width is chosen for the rows without the longest one,
+// B rows more than 8 steps long are parked in LDS, and after the group walk the whole workgroup
+// strides over each parked row.  Must be called by every thread of the workgroup; dl->n zeroed and
+// visible (barrier) beforehand.
+template <int BS, bool WITH_VAL, typename F>
+__device__ __forceinline__ void walk_products_mixed(const int *__restrict__ acol, const real *__restrict__ aval,
+                                                    const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                    const real *__restrict__ bval, int bnnz, int a_beg,
+                                                    int a_end, int np, int maxb, int2 *s_ext, real *s_av,
+                                                    DeferList<WITH_VAL> *dl, F &&consume)
+{
+    const int alen = a_end - a_beg;
+    // longest row > 8 x the average (workgroup-uniform): width for the others, the long ones parked
+    const bool mixed = alen > 1 && (long long)maxb * alen > 8LL * np;
+    const int g = group_width(mixed ? np - maxb : np, mixed ? alen - 1 : alen, BS, mixed ? 0 : maxb);  // once
+    walk_products<BS, WITH_VAL>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av, consume,
+                                mixed ? dl : nullptr, 8 * g * VW);
+    if (!mixed) return;
+    __syncthreads();
+    const int nd = dl->n < DeferList<WITH_VAL>::CAP ? dl->n : DeferList<WITH_VAL>::CAP;
+    for (int d = 0; d < nd; d++) {
+        const int2 e = dl->ext[d];
+        const real av = WITH_VAL ? dl->av[d] : (real)0;
+        for (int base = e.x + (int)threadIdx.x * VW; base < e.y; base += BS * VW) {
+            IVec k;
+            RVec v;
+            const int n = fetch_chunk<WITH_VAL>(bcol, bval, base, e.y, bnnz, k, v);
+            if (n > 0) consume(k, v, n, av);
+        }
     }
 }
 

@@ -43,14 +43,41 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
     if (active) {
         rid = row_perm[bin_off + q];
         const int e = arpt[rid + 1];
-        for (int j = arpt[rid] + sub; j < e; j += LPR) {
-            const int c = __builtin_nontemporal_load(acol + j);
-            const real av = __builtin_nontemporal_load(aval + j);
-            const int ke = brpt[c + 1];
-            for (int k = brpt[c]; k < ke; k++) {
-                int fresh;
-                const int h = ht_find_or_insert(kt, TROW - 1, bcol[k], &fresh);
-                unsafeAtomicAdd(vt + h, av * bval[k]);
+        auto add = [&](int key, real x) {
+            int fresh;
+            const int h = ht_find_or_insert(kt, TROW - 1, key, &fresh);
+            unsafeAtomicAdd(vt + h, x);
+        };
+        // EB of the lane's A entries at a time, their loads requested level by level (see
+        // k_sym_small): ~3 memory round trips per row instead of 3 per entry
+        constexpr int EB = 4;
+        for (int j0 = arpt[rid] + sub; j0 < e; j0 += LPR * EB) {
+            int c[EB], kb[EB], ke[EB], k0[EB], k1[EB];
+            real av[EB], v0[EB], v1[EB];
+#pragma unroll
+            for (int u = 0; u < EB; u++) {
+                const int j = j0 + u * LPR;
+                c[u] = j < e ? __builtin_nontemporal_load(acol + j) : -1;
+                av[u] = j < e ? __builtin_nontemporal_load(aval + j) : (real)0;
+            }
+#pragma unroll
+            for (int u = 0; u < EB; u++) {
+                kb[u] = c[u] >= 0 ? brpt[c[u]] : 0;
+                ke[u] = c[u] >= 0 ? brpt[c[u] + 1] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < EB; u++) {
+                const bool h0 = kb[u] < ke[u], h1 = kb[u] + 1 < ke[u];
+                k0[u] = h0 ? bcol[kb[u]] : -1;
+                v0[u] = h0 ? bval[kb[u]] : (real)0;
+                k1[u] = h1 ? bcol[kb[u] + 1] : -1;
+                v1[u] = h1 ? bval[kb[u] + 1] : (real)0;
+            }
+#pragma unroll
+            for (int u = 0; u < EB; u++) {
+                if (k0[u] >= 0) add(k0[u], av[u] * v0[u]);
+                if (k1[u] >= 0) add(k1[u], av[u] * v1[u]);
+                for (int k = kb[u] + 2; k < ke[u]; k++) add(bcol[k], av[u] * bval[k]);
             }
         }
     }
@@ -141,6 +168,7 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     __shared__ __attribute__((aligned(16))) int srt[PMAX];
     __shared__ int2 s_ext[BS];
     __shared__ real s_av[BS];
+    __shared__ DeferList<true> s_defer;
     __shared__ int s_cnt;
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
@@ -155,19 +183,22 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
         keys[i] = -1;
         vals[i] = 0;
     }
-    if (threadIdx.x == 0) s_cnt = 0;
+    if (threadIdx.x == 0) {
+        s_cnt = 0;
+        s_defer.n = 0;
+    }
     __syncthreads();
 
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
-    walk_products<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av,
-                            [&](const IVec &k, const RVec &v, int n, real sc) {
-                                int h[VW], fresh = 0;
-                                ht_insert_vec(keys, mask, k, n, h, fresh);
+    walk_products_mixed<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, row_prod[rid], row_maxb[rid],
+                                  s_ext, s_av, &s_defer,
+                                  [&](const IVec &k, const RVec &v, int n, real sc) {
+                                      int h[VW], fresh = 0;
+                                      ht_insert_vec(keys, mask, k, n, h, fresh);
 #pragma unroll
-                                for (int i = 0; i < VW; i++)
-                                    if (i < n) unsafeAtomicAdd(vals + h[i], sc * v.v[i]);
-                            });
+                                      for (int i = 0; i < VW; i++)
+                                          if (i < n) unsafeAtomicAdd(vals + h[i], sc * v.v[i]);
+                                  });
     __syncthreads();
 
     // compaction: ballot + popcount inside the wave, one LDS atomic per 64 slots

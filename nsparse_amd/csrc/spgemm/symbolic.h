@@ -32,13 +32,44 @@ __global__ __launch_bounds__(BS) void k_sym_small(const int *__restrict__ arpt,
         rid = row_perm[bin_off + q];
         int *t = tab + lrow * TROW;
         const int e = arpt[rid + 1];
-        for (int j = arpt[rid] + sub; j < e; j += LPR) {
-            const int c = __builtin_nontemporal_load(acol + j);
-            const int ke = brpt[c + 1];
-            for (int k = brpt[c]; k < ke; k++) {
+        // A lane takes EB of its A entries at a time and asks for everything they need level by
+        // level -- the EB columns, then the EB row extents, then the first two entries of each
+        // B row -- so a row costs ~3 memory round trips instead of 3 per entry (these rows are a
+        // dependent-load chain with nothing else to hide it: power-law inputs put a million of
+        // them into this bin).
+        constexpr int EB = 4;
+        for (int j0 = arpt[rid] + sub; j0 < e; j0 += LPR * EB) {
+            int c[EB], kb[EB], ke[EB], k0[EB], k1[EB];
+#pragma unroll
+            for (int u = 0; u < EB; u++) {
+                const int j = j0 + u * LPR;
+                c[u] = j < e ? __builtin_nontemporal_load(acol + j) : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < EB; u++) {
+                kb[u] = c[u] >= 0 ? brpt[c[u]] : 0;
+                ke[u] = c[u] >= 0 ? brpt[c[u] + 1] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < EB; u++) {
+                k0[u] = kb[u] < ke[u] ? bcol[kb[u]] : -1;
+                k1[u] = kb[u] + 1 < ke[u] ? bcol[kb[u] + 1] : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < EB; u++) {
                 int fresh;
-                ht_find_or_insert(t, TROW - 1, bcol[k], &fresh);
-                cnt += fresh;
+                if (k0[u] >= 0) {
+                    ht_find_or_insert(t, TROW - 1, k0[u], &fresh);
+                    cnt += fresh;
+                }
+                if (k1[u] >= 0) {
+                    ht_find_or_insert(t, TROW - 1, k1[u], &fresh);
+                    cnt += fresh;
+                }
+                for (int k = kb[u] + 2; k < ke[u]; k++) {
+                    ht_find_or_insert(t, TROW - 1, bcol[k], &fresh);
+                    cnt += fresh;
+                }
             }
         }
     }
@@ -62,6 +93,7 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
 {
     __shared__ __attribute__((aligned(16))) int tab[TMAX];
     __shared__ int2 s_ext[LARGE ? 1 : BS];
+    __shared__ DeferList<false> s_defer;
     __shared__ int s_nz;
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
@@ -76,19 +108,22 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
         const int4 m1 = make_int4(-1, -1, -1, -1);
         for (int i = threadIdx.x; i < T / 4; i += BS) t4[i] = m1;
     }
-    if (threadIdx.x == 0) s_nz = 0;
+    if (threadIdx.x == 0) {
+        s_nz = 0;
+        s_defer.n = 0;
+    }
     __syncthreads();
 
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
     const int g = group_width(np, a_end - a_beg, BS, row_maxb[rid]);
     int cnt = 0;
     if (!LARGE) {
-        walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz,
-                                 a_beg, a_end, g, s_ext, (real *)nullptr,
-                                 [&](const IVec &k, const RVec &, int n, real) {
-                                     int h[VW];
-                                     ht_insert_vec(tab, mask, k, n, h, cnt);
-                                 });
+        walk_products_mixed<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz,
+                                       a_beg, a_end, np, row_maxb[rid], s_ext, (real *)nullptr, &s_defer,
+                                       [&](const IVec &k, const RVec &, int n, real) {
+                                           int h[VW];
+                                           ht_insert_vec(tab, mask, k, n, h, cnt);
+                                       });
     } else {
         // try-in-LDS: plain walk with early exit once the table holds kSymLargeLimit keys
         const int ngroups = BS / g;

@@ -151,6 +151,9 @@ struct BinLauncher {
     bool used[NB] = {};
     bool serial;     // profiling mode: one stream, bins back to back
     int main_bin;    // the bin with the most rows runs on the main stream itself (no fork/join)
+    void *deferred[4] = {};  // scratch of kernels still in flight: returned to the cache by collect()
+    int ndeferred = 0;
+    void free_later(void *p) { deferred[ndeferred++] = p; }
     BinLauncher(Context &c, int phase, const int *hist = nullptr)
         : cx(&c), ev(c.ev_bin + phase * 2 * NB), serial(c.profiling), main_bin(-1)
     {
@@ -186,6 +189,8 @@ struct BinLauncher {
     }
     void collect(float *out)  // call after the device is idle
     {
+        for (int i = 0; i < ndeferred; i++) dev_free(deferred[i]);
+        ndeferred = 0;
         for (int b = 0; b < NB; b++) {
             out[b] = 0;
             if (used[b]) {
@@ -321,6 +326,68 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     const int *arpt = a->d_rpt, *acol = a->d_col, *brpt = b->d_rpt, *bcol = b->d_col;
     const real *aval = a->d_val, *bval = b->d_val;
     L.fork();
+    // The heavy bin goes first: its few persistent workgroups want a whole CU each (LDS) and run
+    // longest, so they should not queue behind a million small rows.  Nothing here waits on the
+    // host; the cursor slab returns to the cache when the call has drained (collect()).
+    constexpr int kTileW = sizeof(real) == 8 ? 12288 : 24576;
+    static const int tiled_on = !(getenv("NSPARSE_TILED") && getenv("NSPARSE_TILED")[0] == '0');
+    static const int long_len = getenv("NSPARSE_TILED_LONG") ? atoi(getenv("NSPARSE_TILED_LONG")) : 128;
+    static const int tile_sel = getenv("NSPARSE_TILED_W") ? atoi(getenv("NSPARSE_TILED_W")) : 0;
+    // rows with fewer than one non-zero per ranked_dens columns of their window take the ranked
+    // kernel (0: none, < 0: all)
+    static const int ranked_dens = getenv("NSPARSE_RANKED_DENS") ? atoi(getenv("NSPARSE_RANKED_DENS")) : 12;
+    // dense tiles alone: at most 1024 per row, wider matrices hash globally; with the ranked kernel
+    // taking the wide rows there is no limit
+    const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
+                           (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
+    if (use_tiled) {
+        hipStream_t st = L.begin(kNumGlobalBin);
+        const int rows = hist[kNumGlobalBin];
+        const int amax = (max_alen + 1) & ~1;  // even: the value slice stays 8-byte aligned
+        const long long stride_ints = 3LL * amax + (long long)amax * (sizeof(real) / sizeof(int));
+        const int groups = rows < 1024 ? rows : 1024;
+        int *slab = (int *)dev_alloc(sizeof(int) * (size_t)stride_ints * groups);
+        static const int tiled_prof = getenv("NSPARSE_TILED_PROF") ? atoi(getenv("NSPARSE_TILED_PROF")) : 0;
+        unsigned long long *d_prof = nullptr;
+        if (tiled_prof) {
+            d_prof = (unsigned long long *)dev_alloc(32 * sizeof(unsigned long long));
+            NSP_CHECK(hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), st));
+        }
+#define NSP_TILED(BSX, WX)                                                                     \
+    hipLaunchKernelGGL((k_num_tiled<BSX, WX>), dim3(groups), dim3(BSX), 0, st, arpt, acol, aval, brpt, \
+                       bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows,   \
+                       d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len, d_prof, ranked_dens)
+        if (ranked_dens >= 0) {
+            if (tile_sel == 1) { NSP_TILED(1024, kTileW / 2); }
+            else if (tile_sel == 2) { NSP_TILED(512, kTileW / 2); }
+            else if (tile_sel == 3) { NSP_TILED(512, kTileW / 4); }
+            else { NSP_TILED(1024, kTileW); }
+        }
+#undef NSP_TILED
+        NSP_LAUNCH_CHECK();
+        // thin rows: bitmap-ranked accumulator (same stream: both kernels want the whole LDS of a CU)
+        if (ranked_dens != 0) {
+            constexpr int kRankCap = sizeof(real) == 8 ? 10240 : 20480;
+            hipLaunchKernelGGL((k_num_ranked<1024, 262144, kRankCap>), dim3(groups), dim3(1024), 0, st, arpt, acol,
+                               aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin],
+                               rows, d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len,
+                               ranked_dens, tile_sel == 0 ? kTileW : (tile_sel == 3 ? kTileW / 4 : kTileW / 2), d_prof);
+            NSP_LAUNCH_CHECK();
+        }
+        L.end(kNumGlobalBin);
+        if (d_prof) {
+            NSP_CHECK(hipStreamSynchronize(st));
+            unsigned long long h[32];
+            NSP_CHECK(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
+            const double us = 0.01 / groups;  // 100 MHz ticks summed over the workgroups
+            fprintf(stderr, "[tiled] groups %d rows %llu tiles %llu | per-group us: setup %.0f queue %.0f regs %.0f overflow %.0f emit %.0f+%.0f+%.0f+%.0f | trips %llu (long %llu)\n",
+                    groups, h[6], h[5], h[0] * us, h[1] * us, h[2] * us, h[3] * us, h[7] * us, h[8] * us, h[9] * us, h[4] * us, h[10], h[11]);
+            fprintf(stderr, "[ranked] rows %llu tiles %llu | per-group us: setup %.0f pass1 %.0f (first tile %.0f) scan %.0f pass2 %.0f (first %.0f) emit %.0f | cuts %llu | sum nlong %llu alen %llu list-overflow rows %llu\n",
+                    h[22], h[21], h[16] * us, h[17] * us, h[23] * us, h[18] * us, h[19] * us, h[24] * us, h[20] * us, h[25], h[26], h[27], h[28]);
+            dev_free(d_prof);
+        }
+        L.free_later(slab);
+    }
 #define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
     if (hist[BIN] > 0) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
@@ -367,67 +434,9 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         NSP_LAUNCH_CHECK();
         L.end(0);
     }
-    // The heavy bin synchronises on the host (its scratch slab is freed here), so it is issued
-    // last: every other bin is already queued on its own stream and overlaps with it.
-    constexpr int kTileW = sizeof(real) == 8 ? 12288 : 24576;
-    static const int tiled_on = !(getenv("NSPARSE_TILED") && getenv("NSPARSE_TILED")[0] == '0');
-    static const int long_len = getenv("NSPARSE_TILED_LONG") ? atoi(getenv("NSPARSE_TILED_LONG")) : 128;
-    static const int tile_sel = getenv("NSPARSE_TILED_W") ? atoi(getenv("NSPARSE_TILED_W")) : 0;
-    // rows with fewer than one non-zero per ranked_dens columns of their window take the ranked
-    // kernel (0: none, < 0: all)
-    static const int ranked_dens = getenv("NSPARSE_RANKED_DENS") ? atoi(getenv("NSPARSE_RANKED_DENS")) : 12;
-    // dense tiles alone: at most 1024 per row, wider matrices hash globally; with the ranked kernel
-    // taking the wide rows there is no limit
-    const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
-                           (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
-    if (use_tiled) {
-        hipStream_t st = L.begin(kNumGlobalBin);
-        const int rows = hist[kNumGlobalBin];
-        const int amax = (max_alen + 1) & ~1;  // even: the value slice stays 8-byte aligned
-        const long long stride_ints = 3LL * amax + (long long)amax * (sizeof(real) / sizeof(int));
-        const int groups = rows < 1024 ? rows : 1024;
-        int *slab = (int *)dev_alloc(sizeof(int) * (size_t)stride_ints * groups);
-        static const int tiled_prof = getenv("NSPARSE_TILED_PROF") ? atoi(getenv("NSPARSE_TILED_PROF")) : 0;
-        unsigned long long *d_prof = nullptr;
-        if (tiled_prof) {
-            d_prof = (unsigned long long *)dev_alloc(32 * sizeof(unsigned long long));
-            NSP_CHECK(hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), st));
-        }
-#define NSP_TILED(BSX, WX)                                                                     \
-    hipLaunchKernelGGL((k_num_tiled<BSX, WX>), dim3(groups), dim3(BSX), 0, st, arpt, acol, aval, brpt, \
-                       bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows,   \
-                       d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len, d_prof, ranked_dens)
-        if (ranked_dens >= 0) {
-            if (tile_sel == 1) { NSP_TILED(1024, kTileW / 2); }
-            else if (tile_sel == 2) { NSP_TILED(512, kTileW / 2); }
-            else if (tile_sel == 3) { NSP_TILED(512, kTileW / 4); }
-            else { NSP_TILED(1024, kTileW); }
-        }
-#undef NSP_TILED
-        NSP_LAUNCH_CHECK();
-        // thin rows: bitmap-ranked accumulator (same stream: both kernels want the whole LDS of a CU)
-        if (ranked_dens != 0) {
-            constexpr int kRankCap = sizeof(real) == 8 ? 10240 : 20480;
-            hipLaunchKernelGGL((k_num_ranked<1024, 262144, kRankCap>), dim3(groups), dim3(1024), 0, st, arpt, acol,
-                               aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin],
-                               rows, d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len,
-                               ranked_dens, tile_sel == 0 ? kTileW : (tile_sel == 3 ? kTileW / 4 : kTileW / 2), d_prof);
-            NSP_LAUNCH_CHECK();
-        }
-        NSP_CHECK(hipStreamSynchronize(st));
-        L.end(kNumGlobalBin);
-        if (d_prof) {
-            unsigned long long h[32];
-            NSP_CHECK(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
-            const double us = 0.01 / groups;  // 100 MHz ticks summed over the workgroups
-            fprintf(stderr, "[tiled] groups %d rows %llu tiles %llu | per-group us: setup %.0f queue %.0f regs %.0f overflow %.0f emit %.0f+%.0f+%.0f+%.0f | trips %llu (long %llu)\n",
-                    groups, h[6], h[5], h[0] * us, h[1] * us, h[2] * us, h[3] * us, h[7] * us, h[8] * us, h[9] * us, h[4] * us, h[10], h[11]);
-            fprintf(stderr, "[ranked] rows %llu tiles %llu | per-group us: setup %.0f pass1 %.0f (first tile %.0f) scan %.0f pass2 %.0f (first %.0f) emit %.0f | cuts %llu | sum nlong %llu alen %llu list-overflow rows %llu\n",
-                    h[22], h[21], h[16] * us, h[17] * us, h[23] * us, h[18] * us, h[19] * us, h[24] * us, h[20] * us, h[25], h[26], h[27], h[28]);
-            dev_free(d_prof);
-        }
-        dev_free(slab);
-    } else if (hist[kNumGlobalBin] > 0) {
+    // rows beyond the LDS tables without the tile kernels (unsorted B, or switched off): global
+    // table + segmented sort; synchronises on the host (scratch freed here), hence last
+    if (!use_tiled && hist[kNumGlobalBin] > 0) {
         hipStream_t st = L.begin(kNumGlobalBin);
         const int rows = hist[kNumGlobalBin];
         long long slice = 64;
