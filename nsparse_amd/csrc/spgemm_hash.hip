@@ -231,7 +231,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     int *fail_list = nullptr;
     L.fork();
 #define NSP_SYM_TB(BIN, BS, TMAX)                                                              \
-    if (hist[BIN] > 0) {                                                                       \
+    if (hist[BIN] > 0 && now(BIN)) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_tb<BS, TMAX, false>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, \
                            st, arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[BIN],   \
@@ -241,7 +241,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         L.end(BIN);                                                                            \
     }
 #define NSP_SYM_DENSE(BIN, BS, SPAN)                                                            \
-    if (hist[BIN] > 0) {                                                                       \
+    if (hist[BIN] > 0 && now(BIN)) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_dense<BS, SPAN>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
                            arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_lo, row_span, row_nz, \
@@ -250,7 +250,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         L.end(BIN);                                                                            \
     }
 #define NSP_SYM_BITS(BIN, BS, WORDS)                                                           \
-    if (hist[BIN] > 0) {                                                                       \
+    if (hist[BIN] > 0 && now(BIN)) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_bits<BS, WORDS>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
                            arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_lo, row_span, row_nz, \
@@ -258,22 +258,24 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
+    // Host launch cost is on the critical path (~14 us per bin: stream wait, two event records,
+    // the launch): the bin with the most rows -- the one on the main stream -- goes out first, the
+    // others follow biggest rows first.
+    for (int pass = 0; pass < 2; pass++) {
+    auto now = [&](int bin) { return (pass == 0) == (bin == L.main_bin); };
     NSP_SYM_BITS(10, 1024, 32768)
     NSP_SYM_BITS(9, 512, 8192)
-#undef NSP_SYM_BITS
     static const int tune_d6 = getenv("NSPARSE_SYMD6_BS") ? atoi(getenv("NSPARSE_SYMD6_BS")) : 128;
     NSP_SYM_DENSE(8, 1024, 65536)
     NSP_SYM_DENSE(7, 512, 16384)
     if (tune_d6 == 128) { NSP_SYM_DENSE(6, 128, 4096) } else if (tune_d6 == 512) { NSP_SYM_DENSE(6, 512, 4096) } else { NSP_SYM_DENSE(6, 256, 4096) }
-#undef NSP_SYM_DENSE
     static const int tune_s3 = getenv("NSPARSE_SYM3_BS") ? atoi(getenv("NSPARSE_SYM3_BS")) : 512;
     static const int tune_s2 = getenv("NSPARSE_SYM2_BS") ? atoi(getenv("NSPARSE_SYM2_BS")) : 128;
     NSP_SYM_TB(4, 1024, 32768)
     if (tune_s3 == 512) { NSP_SYM_TB(3, 512, 8192) } else if (tune_s3 == 1024) { NSP_SYM_TB(3, 1024, 8192) } else { NSP_SYM_TB(3, 256, 8192) }
     if (tune_s2 == 256) { NSP_SYM_TB(2, 256, 2048) } else { NSP_SYM_TB(2, 128, 2048) }
     NSP_SYM_TB(1, 64, 512)
-#undef NSP_SYM_TB
-    if (hist[0] > 0) {
+    if (hist[0] > 0 && now(0)) {
         hipStream_t st = L.begin(0);
         constexpr int BS = 256, LPR = 4;
         hipLaunchKernelGGL((k_sym_small<BS, LPR, 64>), dim3(ceil_div(hist[0], BS / LPR)), dim3(BS), 0,
@@ -281,6 +283,10 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         NSP_LAUNCH_CHECK();
         L.end(0);
     }
+    }  // pass
+#undef NSP_SYM_BITS
+#undef NSP_SYM_DENSE
+#undef NSP_SYM_TB
     // the overflow bin needs a host round trip (fail count), so it is issued last: by then
     // every other bin is already queued on its own stream.
     if (hist[5] > 0) {
@@ -340,7 +346,11 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // taking the wide rows there is no limit
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
                            (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
-    if (use_tiled) {
+    // launch order: the bin with the most rows (main stream) first, then the heavy bin, then the
+    // rest biggest rows first (see symbolic_phase)
+    for (int pass = 0; pass < 2; pass++) {
+    auto now = [&](int bin) { return (pass == 0) == (bin == L.main_bin); };
+    if (use_tiled && now(kNumGlobalBin)) {
         hipStream_t st = L.begin(kNumGlobalBin);
         const int rows = hist[kNumGlobalBin];
         const int amax = (max_alen + 1) & ~1;  // even: the value slice stays 8-byte aligned
@@ -389,7 +399,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         L.free_later(slab);
     }
 #define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
-    if (hist[BIN] > 0) {                                                                       \
+    if (hist[BIN] > 0 && now(BIN)) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, arpt,  \
                            acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, \
@@ -398,7 +408,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         L.end(BIN);                                                                            \
     }
 #define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
-    if (hist[BIN] > 0) {                                                                       \
+    if (hist[BIN] > 0 && now(BIN)) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
         if (write_col & 1)                                                                     \
             hipLaunchKernelGGL((k_num_dense<BS, SPAN, 1>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
@@ -417,15 +427,13 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     NSP_NUM_DENSE(8, 512, 12288)
     NSP_NUM_DENSE(7, 256, 4096)
     if (tune_nd6 == 128) { NSP_NUM_DENSE(6, 128, 1536) } else if (tune_nd6 == 512) { NSP_NUM_DENSE(6, 512, 1536) } else { NSP_NUM_DENSE(6, 256, 1536) }
-#undef NSP_NUM_DENSE
     static const int tune_n2 = getenv("NSPARSE_NUM2_BS") ? atoi(getenv("NSPARSE_NUM2_BS")) : 256;
     static const int tune_n1 = getenv("NSPARSE_NUM1_BS") ? atoi(getenv("NSPARSE_NUM1_BS")) : 64;
     NSP_NUM_TB(4, 1024, 8192, 8192)
     NSP_NUM_TB(3, 512, 4096, 4096)
     if (tune_n2 == 128) { NSP_NUM_TB(2, 128, 1024, 1024) } else if (tune_n2 == 512) { NSP_NUM_TB(2, 512, 1024, 1024) } else { NSP_NUM_TB(2, 256, 1024, 1024) }
     if (tune_n1 == 128) { NSP_NUM_TB(1, 128, 256, 256) } else { NSP_NUM_TB(1, 64, 256, 256) }
-#undef NSP_NUM_TB
-    if (hist[0] > 0) {
+    if (hist[0] > 0 && now(0)) {
         hipStream_t st = L.begin(0);
         constexpr int BS = 256, LPR = 4;
         hipLaunchKernelGGL((k_num_small<BS, LPR, 32>), dim3(ceil_div(hist[0], BS / LPR)), dim3(BS), 0,
@@ -434,6 +442,9 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         NSP_LAUNCH_CHECK();
         L.end(0);
     }
+    }  // pass
+#undef NSP_NUM_DENSE
+#undef NSP_NUM_TB
     // rows beyond the LDS tables without the tile kernels (unsorted B, or switched off): global
     // table + segmented sort; synchronises on the host (scratch freed here), hence last
     if (!use_tiled && hist[kNumGlobalBin] > 0) {
