@@ -78,6 +78,7 @@ struct BinState {
     long long max_alen;  // longest row of A
     int b_unsorted;      // some row of B does not have strictly ascending columns
     int queue_head2;     // second persistent-kernel queue of the heavy numeric bin
+    int max_span[NB];    // widest column window among the rows of each bin (sizes the LDS of the window kernels)
 };
 
 struct Stats {
@@ -85,11 +86,16 @@ struct Stats {
 };
 static Stats g_stats;
 
-__host__ __device__ __forceinline__ int bin_of(int n, int span, const Thr &thr)
+// `work` = products of the row.  Symbolic: the same number as n.  Numeric: n is the nnz of the C
+// row, and a window is also worth its clearing and scanning when the row has many products for
+// few non-zeros (FEM: 6561 products, 375 non-zeros, a window of 5 K columns once the mesh
+// cross-section is 20 x 20 nodes): dense when span <= dense_ratio * n or span <= dense_ratio/4 * work.
+__host__ __device__ __forceinline__ int bin_of(int n, int span, const Thr &thr, int work)
 {
     if (n <= thr.tiny) return 0;
     if (thr.dense_ratio > 0 && span > 0 && span <= thr.dense_span[2] &&
-        (long long)span <= (long long)thr.dense_ratio * n)
+        ((long long)span <= (long long)thr.dense_ratio * n ||
+         (long long)span * 4 <= (long long)thr.dense_ratio * work))
         return kDenseBin0 + (span > thr.dense_span[0]) + (span > thr.dense_span[1]);
     if (thr.bits_ratio > 0 && n > thr.bits_min && span > 0 && span <= thr.bits_span[1] &&
         (long long)span <= (long long)thr.bits_ratio * n)

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             const int bw = (span > 0 && span <= bm_span_max) ? (span + 31) >> 5 : 0;
             bm_words[row] = bw;
             row_span_num[row] = 0;  // set by k_sym_dense when it hands a bitmap over
-            bin = bin_of(ni, span, thr);
+            bin = bin_of(ni, span, thr, ni);
             const int al = arpt[row + 1] - arpt[row];
             if (W >= 16) {  // at most 4 rows per wave: direct LDS atomics are cheapest
                 atomicAdd(&s_hist[bin], 1);
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) void k_publish(const BinState *__restrict__ src
 
 // histogram of an existing per-row count (numeric binning, set_min_bin :201-246)
 __global__ __launch_bounds__(1024) void k_hist(const int *__restrict__ n, const int *__restrict__ span,
-                                              int M, Thr thr, BinState *bs)
+                                              const int *__restrict__ work, int M, Thr thr, BinState *bs)
 {
     __shared__ int s_hist[NB];
     __shared__ int s_max;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(1024) void k_hist(const int *__restrict__ n, const 
     int bin = -1, v = 0;                             // global atomics at the end
     if (i < M) {
         v = n[i];
-        bin = bin_of(v, span[i], thr);
+        bin = bin_of(v, span[i], thr, work ? work[i] : v);
     }
     unsigned long long todo = __ballot(bin >= 0);
     while (todo) {  // one LDS atomic per (wave, bin present in the wave)
@@ -417,16 +417,25 @@ __global__ __launch_bounds__(256) void k_row_len(const int *__restrict__ rpt, in
 // rows grouped by bin (set_row_perm :125-154): one LDS pass ranks the rows of a block
 // inside their bin, one global atomic per (block, bin) reserves the range.
 __global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
-                                                     const int *__restrict__ span, int M, Thr thr,
+                                                     const int *__restrict__ span,
+                                                     const int *__restrict__ work, int M, Thr thr,
                                                      BinState *bs, int *__restrict__ perm)
 {
     __shared__ int s_cnt[NB];
     __shared__ int s_base[NB];
-    if (threadIdx.x < NB) s_cnt[threadIdx.x] = 0;
+    __shared__ int s_span[NB];
+    if (threadIdx.x < NB) {
+        s_cnt[threadIdx.x] = 0;
+        s_span[threadIdx.x] = 0;
+    }
     __syncthreads();
     const int i = blockIdx.x * 1024 + threadIdx.x;
     int b = -1, r = 0;
-    if (i < M) b = bin_of(n[i], span[i], thr);
+    if (i < M) {
+        const int ni = n[i];
+        b = bin_of(ni, span[i], thr, work ? work[i] : ni);
+        if (b >= kDenseBin0) atomicMax(&s_span[b], span[i]);  // window bins only
+    }
     // rank inside the block: ballot + popcount inside the wave, one LDS atomic per (wave, bin)
     unsigned long long todo = __ballot(b >= 0);
     const int lane = threadIdx.x & 63;
@@ -447,6 +456,7 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
         for (int q = 0; q < (int)threadIdx.x; q++) off += bs->hist[q];
         const int c = s_cnt[threadIdx.x];
         s_base[threadIdx.x] = off + (c ? atomicAdd(&bs->cursor[threadIdx.x], c) : 0);
+        if (s_span[threadIdx.x]) atomicMax(&bs->max_span[threadIdx.x], s_span[threadIdx.x]);
     }
     __syncthreads();
     if (i < M) perm[s_base[b] + r] = i;

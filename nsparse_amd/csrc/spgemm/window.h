@@ -6,6 +6,8 @@
 namespace nsp {
 namespace spgemm {
 
+extern __shared__ __attribute__((aligned(16))) unsigned char nsp_dyn_lds[];
+
 // ===================================================================================
 //  dense-window rows (bins 6..8)
 // ===================================================================================
@@ -31,7 +33,9 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
                                                   unsigned int *__restrict__ bm,
                                                   int *__restrict__ row_span_num)
 {
-    __shared__ __attribute__((aligned(16))) unsigned int flag4[SPAN_MAX / 4 + 8];
+    // flags: dynamic LDS sized by the widest window actually in the bin, (span/4 + 8) words -- a
+    // bin spans a 4x range of windows and a static array for its upper end would cost occupancy
+    unsigned int *flag4 = reinterpret_cast<unsigned int *>(nsp_dyn_lds);
     __shared__ int2 s_ext[BS];
     __shared__ int s_nz;
     const int slot = xcd_row_slot(bin_size);
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
     //         k_sym_dense; columns and values are emitted in ascending order.
     // MODE 2: numeric-only re-run -- C.col exists; values are gathered at its columns.
     constexpr int NW = BS / 64;
-    __shared__ __attribute__((aligned(16))) real dense[SPAN_MAX + 4];
+    real *dense = reinterpret_cast<real *>(nsp_dyn_lds);  // dynamic: (widest window of the bin + 4) values
     __shared__ int2 s_ext[BS];
     __shared__ real s_av[BS];
     __shared__ int s_wcnt[NW];
@@ -197,31 +201,47 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
         }
         return;
     }
-    // ordered emission: wave w owns the column range [w*R, (w+1)*R)
+    // Ordered emission: wavefront w owns the column range [w*R, (w+1)*R), R a multiple of 64 and
+    // at most 4096, so the range is at most 128 bitmap words: every lane fetches one or two of them (a single
+    // coalesced load -- the loop below then runs on registers, where it used to wait for a global
+    // load per 64 columns), the count is a wave sum of popcounts and the 64-column masks come from
+    // readlane instead of ballots.
+    constexpr int WPL = (SPAN_MAX / NW + 2047) / 2048;  // bitmap words per lane (1 or 2)
+    static_assert(WPL <= 2, "at most two bitmap words per lane");
     const unsigned int *bits = bm + bm_off[rid];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int R = ((span + NW * 64 - 1) / (NW * 64)) * 64;
     const int rb = w * R, re = rb + R < span ? rb + R : span;
+    const int nwords = (span + 31) >> 5, w0 = rb >> 5, rw = R >> 5;
+    unsigned int word[WPL];
     int cnt = 0;
-    for (int base = rb; base < re; base += 64) {
-        const int idx = base + lane;
-        const bool occ = idx < re && ((bits[idx >> 5] >> (idx & 31)) & 1u);
-        cnt += __popcll(__ballot(occ));
+#pragma unroll
+    for (int h = 0; h < WPL; h++) {
+        const int wi = 64 * h + lane;
+        word[h] = (wi < rw && w0 + wi < nwords) ? bits[w0 + wi] : 0u;  // bits past span are 0
+        cnt += __popc(word[h]);
     }
+    cnt = wave_sum(cnt);
     if (lane == 0) s_wcnt[w] = cnt;
     __syncthreads();
     int pos = off;
     for (int u = 0; u < w; u++) pos += s_wcnt[u];
-    for (int base = rb; base < re; base += 64) {
-        const int idx = base + lane;
-        const bool occ = idx < re && ((bits[idx >> 5] >> (idx & 31)) & 1u);
-        const unsigned long long m = __ballot(occ);
-        if (occ) {
-            const int p = pos + __popcll(m & ((1ull << lane) - 1ull));
-            ccol[p] = lo + idx;
-            cval[p] = dense[__mul24(idx & 3, Q) + (idx >> 2)];
+#pragma unroll
+    for (int h = 0; h < WPL; h++) {
+        for (int j = 32 * h; j < 32 * (h + 1) && rb + 64 * j < re; j++) {
+            const int l2 = 2 * (j - 32 * h);
+            const unsigned long long m =
+                (unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)word[h], l2) |
+                ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)word[h], l2 + 1) << 32);
+            if (m == 0) continue;  // wave-uniform
+            if ((m >> lane) & 1ull) {
+                const int idx = rb + 64 * j + lane;
+                const int p = pos + __popcll(m & ((1ull << lane) - 1ull));
+                ccol[p] = lo + idx;
+                cval[p] = dense[__mul24(idx & 3, Q) + (idx >> 2)];
+            }
+            pos += __popcll(m);
         }
-        pos += __popcll(m);
     }
 }
 

@@ -202,6 +202,16 @@ struct BinLauncher {
     }
 };
 
+// Dynamic LDS above 64 KiB has to be allowed per kernel function, once.
+template <typename K>
+static void allow_big_lds(K kernel, bool &done, int bytes_max)
+{
+    if (done) return;
+    NSP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  bytes_max));
+    done = true;
+}
+
 static int global_slab_groups(long long slice_elems, size_t bytes_per_elem, int rows)
 {
     // persistent workgroups for the overflow path: bounded by rows, by 2 per CU, and by a
@@ -220,7 +230,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
                                   const int *row_span, int *row_nz, int *row_perm, const int *hist,
                                   int max_prod, BinState *d_bs, Context &cx, float *ms_bin,
                                   int *fail_rows, const int *bm_off, unsigned int *bm,
-                                  int *row_span_num)
+                                  int *row_span_num, const int *max_span)
 {
     BinLauncher L(cx, 0, hist);
     int off[NB + 1];
@@ -243,7 +253,11 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
 #define NSP_SYM_DENSE(BIN, BS, SPAN)                                                            \
     if (hist[BIN] > 0 && now(BIN)) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
-        hipLaunchKernelGGL((k_sym_dense<BS, SPAN>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
+        static bool big_ok = false;                                                            \
+        allow_big_lds(k_sym_dense<BS, SPAN>, big_ok, SPAN + 64);                               \
+        const int span_b = max_span[BIN] < SPAN ? max_span[BIN] : SPAN;                        \
+        const size_t lds = sizeof(int) * (size_t)((span_b + 63) / 64 * 16 + 16);               \
+        hipLaunchKernelGGL((k_sym_dense<BS, SPAN>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), lds, st, \
                            arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_lo, row_span, row_nz, \
                            off[BIN], hist[BIN], b->nnz, bm_off, bm, row_span_num);             \
         NSP_LAUNCH_CHECK();                                                                    \
@@ -266,8 +280,10 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     NSP_SYM_BITS(10, 1024, 32768)
     NSP_SYM_BITS(9, 512, 8192)
     static const int tune_d6 = getenv("NSPARSE_SYMD6_BS") ? atoi(getenv("NSPARSE_SYMD6_BS")) : 128;
-    NSP_SYM_DENSE(8, 1024, 65536)
-    NSP_SYM_DENSE(7, 512, 16384)
+    static const int tune_d8 = getenv("NSPARSE_SYMD8_BS") ? atoi(getenv("NSPARSE_SYMD8_BS")) : 512;
+    if (tune_d8 == 256) { NSP_SYM_DENSE(8, 256, 65536) } else if (tune_d8 == 512) { NSP_SYM_DENSE(8, 512, 65536) } else { NSP_SYM_DENSE(8, 1024, 65536) }
+    static const int tune_d7 = getenv("NSPARSE_SYMD7_BS") ? atoi(getenv("NSPARSE_SYMD7_BS")) : 256;
+    if (tune_d7 == 128) { NSP_SYM_DENSE(7, 128, 16384) } else if (tune_d7 == 256) { NSP_SYM_DENSE(7, 256, 16384) } else { NSP_SYM_DENSE(7, 512, 16384) }
     if (tune_d6 == 128) { NSP_SYM_DENSE(6, 128, 4096) } else if (tune_d6 == 512) { NSP_SYM_DENSE(6, 512, 4096) } else { NSP_SYM_DENSE(6, 256, 4096) }
     static const int tune_s3 = getenv("NSPARSE_SYM3_BS") ? atoi(getenv("NSPARSE_SYM3_BS")) : 512;
     static const int tune_s2 = getenv("NSPARSE_SYM2_BS") ? atoi(getenv("NSPARSE_SYM2_BS")) : 128;
@@ -323,7 +339,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                                  const int *row_lo, const int *row_span, const int *row_perm,
                                  const int *hist, int max_nz, BinState *d_bs, Context &cx,
                                  float *ms_bin, int write_col, const int *bm_off,
-                                 const unsigned int *bm, int max_alen, bool b_sorted)
+                                 const unsigned int *bm, int max_alen, bool b_sorted,
+                                 const int *max_span)
 {
     BinLauncher L(cx, 1, hist);
     int off[NB + 1];
@@ -410,21 +427,27 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
 #define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
     if (hist[BIN] > 0 && now(BIN)) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
+        static bool big_ok1 = false, big_ok2 = false;                                          \
+        allow_big_lds(k_num_dense<BS, SPAN, 1>, big_ok1, (int)sizeof(real) * (SPAN + 64));     \
+        allow_big_lds(k_num_dense<BS, SPAN, 2>, big_ok2, (int)sizeof(real) * (SPAN + 64));     \
+        const int span_b = max_span[BIN] < SPAN ? max_span[BIN] : SPAN;                        \
+        const size_t lds = sizeof(real) * (size_t)((span_b + 63) / 64 * 64 + 8);               \
         if (write_col & 1)                                                                     \
             hipLaunchKernelGGL((k_num_dense<BS, SPAN, 1>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
-                               0, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
+                               lds, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
                                c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[BIN],       \
                                hist[BIN], b->nnz, bm_off, bm);                                 \
         else                                                                                   \
             hipLaunchKernelGGL((k_num_dense<BS, SPAN, 2>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
-                               0, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
+                               lds, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
                                c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[BIN],       \
                                hist[BIN], b->nnz, bm_off, bm);                                 \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
     static const int tune_nd6 = getenv("NSPARSE_NUMD6_BS") ? atoi(getenv("NSPARSE_NUMD6_BS")) : 256;
-    NSP_NUM_DENSE(8, 512, 12288)
+    static const int tune_nd8 = getenv("NSPARSE_NUMD8_BS") ? atoi(getenv("NSPARSE_NUMD8_BS")) : 512;
+    if (tune_nd8 == 256) { NSP_NUM_DENSE(8, 256, 12288) } else { NSP_NUM_DENSE(8, 512, 12288) }
     NSP_NUM_DENSE(7, 256, 4096)
     if (tune_nd6 == 128) { NSP_NUM_DENSE(6, 128, 1536) } else if (tune_nd6 == 512) { NSP_NUM_DENSE(6, 512, 1536) } else { NSP_NUM_DENSE(6, 256, 1536) }
     static const int tune_n2 = getenv("NSPARSE_NUM2_BS") ? atoi(getenv("NSPARSE_NUM2_BS")) : 256;
@@ -577,7 +600,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
     const int grid_m = ceil_div(M, 1024);
     if (!numeric_only) {
-        hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_prod, row_span, M, sym_thr, d_sym, row_perm);
+        hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_prod, row_span, (const int *)nullptr, M,
+                           sym_thr, d_sym, row_perm);
         NSP_LAUNCH_CHECK();
     }
     {
@@ -602,7 +626,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
             bm = (unsigned int *)dev_alloc(sizeof(unsigned int) * (size_t)h_sym->bm_total);
         BinLauncher LS = symbolic_phase(a, b, row_prod, row_maxb, row_lo, row_span, row_nz, row_perm, h_sym->hist,
                                         h_sym->maxv, d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows,
-                                        bm_off, bm, row_span_num);
+                                        bm_off, bm, row_span_num, h_sym->max_span);
         sym_used = LS;
         c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
         scan_tmp = scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
@@ -618,8 +642,10 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
     const int *num_span = numeric_only ? row_span : row_span_num;
     if (!numeric_only && bm == nullptr) num_thr.dense_ratio = 0;
-    hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, M, num_thr, d_num);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, M, num_thr, d_num, row_perm);
+    hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, (const int *)row_prod, M, num_thr,
+                       d_num);
+    hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, (const int *)row_prod, M,
+                       num_thr, d_num, row_perm);
     NSP_LAUNCH_CHECK();
     {
         const int seq = ++cx.seq;
@@ -646,7 +672,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_maxb, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
-                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0);
+                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span);
     tm.mark(3, s0);
     {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
         const int seq = ++cx.seq;

@@ -115,10 +115,12 @@ def row_windows(A, B):
     return prod, span
 
 
-def bins_of(n, span, ladder):
-    """numpy twin of bin_of() in csrc/spgemm/common.h; ladder = 15 ints from nsparse_get_spgemm_bins."""
+def bins_of(n, span, ladder, work=None):
+    """numpy twin of bin_of() in csrc/spgemm/common.h; ladder = 15 ints from nsparse_get_spgemm_bins.
+    work = products of the row (numeric phase; the symbolic phase bins by the products themselves)."""
     n = np.asarray(n, dtype=np.int64)
     span = np.asarray(span, dtype=np.int64)
+    work = n if work is None else np.asarray(work, dtype=np.int64)
     tiny, hash_t, dspan, ratio = ladder[0], ladder[1:5], ladder[5:8], ladder[8]
     b = 1 + sum((n > t).astype(np.int64) for t in hash_t)
     if len(ladder) > 9 and ladder[11] > 0:
@@ -128,7 +130,7 @@ def bins_of(n, span, ladder):
         bits = (n > bmin) & (span > 0) & (span <= bspan[1]) & (span <= bratio * n)
         b = np.where(bits, 9 + (span > bspan[0]), b)
     if ratio > 0:
-        dense = (span > 0) & (span <= dspan[2]) & (span <= ratio * n)
+        dense = (span > 0) & (span <= dspan[2]) & ((span <= ratio * n) | (4 * span <= ratio * work))
         b = np.where(dense, 6 + (span > dspan[0]) + (span > dspan[1]), b)
     return np.where(n <= tiny, 0, b)
 
@@ -139,7 +141,7 @@ def numeric_bins(row_nz, row_prod, span, sym, num):
     window fits the numeric ladder; everything else is binned by nnz alone."""
     span = np.asarray(span, dtype=np.int64)
     has_bm = (bins_of(row_prod, span, sym) >= 6) & (span <= num[7])
-    return bins_of(row_nz, np.where(has_bm, span, 0), num)
+    return bins_of(row_nz, np.where(has_bm, span, 0), num, work=row_prod)
 
 
 def ladders(lib):
