@@ -176,24 +176,34 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
-// Every lane takes VW consecutive entries of a B row per step: one 16-byte column load and
-// VW/2 16-byte value loads instead of VW scalar pairs, and the walk's bookkeeping (the kernels
-// are instruction-issue-bound: rocprofv3 shows VALU 73 % / SALU 83 % busy, LDS 15 %) is paid
-// once per VW products.
-constexpr int VW = 4;
-struct __attribute__((aligned(4))) IVec {
-    int v[VW];
+// Every lane takes several consecutive entries of a B row per step: 16-byte column / value loads
+// instead of scalar pairs, and the walk's bookkeeping (the kernels are instruction-issue-bound:
+// rocprofv3 shows VALU 73 % / SALU 83 % busy, LDS 15 %) is paid once per vector.  The numeric
+// walks take VW = 4 (columns + values: 12 registers per buffer); the symbolic dense-window kernel, which
+// carries columns only and serves long regular rows, takes VWS = 8 (-16 % there; 8 on the numeric side
+// costs occupancy and is 17 % slower, and in the hash symbolic kernels it pads the two- and
+// three-entry B rows of power-law inputs: webbase class +12 %).
+constexpr int VW = 4;   // numeric walks and the hash symbolic kernels
+constexpr int VWS = 8;  // symbolic dense-window kernel (k_sym_dense)
+template <int V>
+struct __attribute__((aligned(4))) IVecT {
+    int v[V];
 };
-struct __attribute__((aligned(sizeof(real) < 8 ? 4 : 8))) RVec {
-    real v[VW];
+template <int V>
+struct __attribute__((aligned(sizeof(real) < 8 ? 4 : 8))) RVecT {
+    real v[V];
 };
+using IVec = IVecT<VW>;
+using RVec = RVecT<VW>;
+using IVecS = IVecT<VWS>;
+using RVecS = RVecT<1>;  // symbolic walks carry no values
 
 // Lanes per B row for a C row with `np` products spread over `alen` entries of A, for a
 // workgroup of BS threads.  With g lanes per group the row takes
 //     ceil(alen / (BS/g)) * ceil(avg_len / (g*VW))   group steps,
 // so g trades padding of the B rows (small g pads less) against imbalance between groups
 // (large g, few groups).  The largest g with the fewest steps wins.
-__device__ __forceinline__ int group_width(int np, int alen, int BS, int maxb = 0)
+__device__ __forceinline__ int group_width(int np, int alen, int BS, int maxb = 0, int vw = VW)
 {
     if (alen <= 0) return 64;
     const int avg = (np + alen - 1) / alen;
@@ -201,11 +211,11 @@ __device__ __forceinline__ int group_width(int np, int alen, int BS, int maxb = 
 #pragma unroll
     for (int g = 64; g >= 1; g >>= 1) {
         const int ng = BS / g;
-        int t = ((alen + ng - 1) / ng) * ((avg + g * VW - 1) / (g * VW));
+        int t = ((alen + ng - 1) / ng) * ((avg + g * vw - 1) / (g * vw));
         // the group that owns the longest B row of this C row (maxb entries) cannot finish
         // earlier than that row alone takes: on power-law inputs (hub rows of hundreds of entries
         // among rows of three) this term, not the average, decides
-        const int tl = (maxb + g * VW - 1) / (g * VW);
+        const int tl = (maxb + g * vw - 1) / (g * vw);
         t = t > tl ? t : tl;
         if (t < best_t) { best_t = t; best_g = g; }
     }
@@ -244,23 +254,23 @@ __device__ __forceinline__ void wave_lds_sync()
 // The load is always the full 16-byte vector: elements past ke belong to the next row of B
 // (valid memory, masked out by the returned count); only the last VW-1 entries of the whole
 // array (i0 + VW > bnnz) take the element-wise path.
-template <bool WITH_VAL>
+template <bool WITH_VAL, int V>
 __device__ __forceinline__ int fetch_chunk(const int *__restrict__ bcol, const real *__restrict__ bval,
-                                           int i0, int ke, int bnnz, IVec &k, RVec &v)
+                                           int i0, int ke, int bnnz, IVecT<V> &k, RVecT<WITH_VAL ? V : 1> &v)
 {
     int n = ke - i0;
-    n = n < 0 ? 0 : (n > VW ? VW : n);
+    n = n < 0 ? 0 : (n > V ? V : n);
     if (n > 0) {
-        if (i0 + VW <= bnnz) {
+        if (i0 + V <= bnnz) {
             // unsigned index: zero-extension is free, so the loads use base + 32-bit offset
-            k = *reinterpret_cast<const IVec *>(bcol + (unsigned)i0);
-            if (WITH_VAL) v = *reinterpret_cast<const RVec *>(bval + (unsigned)i0);
+            k = *reinterpret_cast<const IVecT<V> *>(bcol + (unsigned)i0);
+            if (WITH_VAL) v = *reinterpret_cast<const RVecT<WITH_VAL ? V : 1> *>(bval + (unsigned)i0);
         } else {
 #pragma unroll
-            for (int i = 0; i < VW; i++) {
+            for (int i = 0; i < V; i++) {
                 const int ii = i < n ? i0 + i : i0;
                 k.v[i] = bcol[ii];
-                if (WITH_VAL) v.v[i] = bval[ii];
+                if (WITH_VAL) v.v[WITH_VAL ? i : 0] = bval[ii];
             }
         }
     }
@@ -276,7 +286,7 @@ struct DeferList {
     real av[WITH_VAL ? CAP : 1];
 };
 
-template <int BS, bool WITH_VAL, typename F>
+template <int BS, bool WITH_VAL, int V = VW, typename F>
 __device__ __forceinline__ void walk_products(const int *__restrict__ acol, const real *__restrict__ aval,
                                               const int *__restrict__ brpt, const int *__restrict__ bcol,
                                               const real *__restrict__ bval, int bnnz, int a_beg,
@@ -289,8 +299,8 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
     const int cnt = first < a_end ? (a_end - first + ngroups - 1) / ngroups : 0;
     int2 *ext = s_ext + gid * g;
     real *avs = s_av + gid * g;
-    const int lane_off = gl * VW;
-    const int stride = g * VW;
+    const int lane_off = gl * V;
+    const int stride = g * V;
     for (int b0 = 0; b0 < cnt; b0 += g) {
         const int m = b0 + gl;
         int2 e = make_int2(0, 0);
@@ -322,12 +332,12 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
         int2 cur = ext[0];
         real cav = WITH_VAL ? avs[0] : (real)0;
         int base = cur.x;
-        IVec pk;
-        RVec pv;
-        int pn = fetch_chunk<WITH_VAL>(bcol, bval, base + lane_off, cur.y, bnnz, pk, pv);
+        IVecT<V> pk;
+        RVecT<WITH_VAL ? V : 1> pv;
+        int pn = fetch_chunk<WITH_VAL, V>(bcol, bval, base + lane_off, cur.y, bnnz, pk, pv);
         while (t < nb) {
-            const IVec ck = pk;
-            const RVec cv = pv;
+            const IVecT<V> ck = pk;
+            const RVecT<WITH_VAL ? V : 1> cv = pv;
             const int cn = pn;
             const real sc = cav;
             base += stride;
@@ -339,7 +349,7 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
                     base = cur.x;
                 }
             }
-            pn = t < nb ? fetch_chunk<WITH_VAL>(bcol, bval, base + lane_off, cur.y, bnnz, pk, pv) : 0;
+            pn = t < nb ? fetch_chunk<WITH_VAL, V>(bcol, bval, base + lane_off, cur.y, bnnz, pk, pv) : 0;
             if (cn > 0) consume(ck, cv, cn, sc);
         }
         wave_lds_sync();
@@ -363,34 +373,36 @@ __device__ __forceinline__ void walk_products_mixed(const int *__restrict__ acol
     const int alen = a_end - a_beg;
     // longest row > 8 x the average (workgroup-uniform): width for the others, the long ones parked
     const bool mixed = alen > 1 && (long long)maxb * alen > 8LL * np;
-    const int g = group_width(mixed ? np - maxb : np, mixed ? alen - 1 : alen, BS, mixed ? 0 : maxb);  // once
-    walk_products<BS, WITH_VAL>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av, consume,
-                                mixed ? dl : nullptr, 8 * g * VW);
+    constexpr int V = VW;
+    const int g = group_width(mixed ? np - maxb : np, mixed ? alen - 1 : alen, BS, mixed ? 0 : maxb, V);  // once
+    walk_products<BS, WITH_VAL, V>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av, consume,
+                                   mixed ? dl : nullptr, 8 * g * V);
     if (!mixed) return;
     __syncthreads();
     const int nd = dl->n < DeferList<WITH_VAL>::CAP ? dl->n : DeferList<WITH_VAL>::CAP;
     for (int d = 0; d < nd; d++) {
         const int2 e = dl->ext[d];
         const real av = WITH_VAL ? dl->av[d] : (real)0;
-        for (int base = e.x + (int)threadIdx.x * VW; base < e.y; base += BS * VW) {
-            IVec k;
-            RVec v;
-            const int n = fetch_chunk<WITH_VAL>(bcol, bval, base, e.y, bnnz, k, v);
+        for (int base = e.x + (int)threadIdx.x * V; base < e.y; base += BS * V) {
+            IVecT<V> k;
+            RVecT<WITH_VAL ? V : 1> v;
+            const int n = fetch_chunk<WITH_VAL, V>(bcol, bval, base, e.y, bnnz, k, v);
             if (n > 0) consume(k, v, n, av);
         }
     }
 }
 
-// VW find-or-insert operations of one lane, the first probes issued back to back
-__device__ __forceinline__ void ht_insert_vec(int *tab, int mask, const IVec &k, int n, int (&h)[VW], int &fresh)
+// one find-or-insert per element of the vector, the first probes issued back to back
+template <int V>
+__device__ __forceinline__ void ht_insert_vec(int *tab, int mask, const IVecT<V> &k, int n, int (&h)[V], int &fresh)
 {
-    int old[VW];
+    int old[V];
 #pragma unroll
-    for (int i = 0; i < VW; i++) h[i] = hash_slot(k.v[i], mask);
+    for (int i = 0; i < V; i++) h[i] = hash_slot(k.v[i], mask);
 #pragma unroll
-    for (int i = 0; i < VW; i++) old[i] = i < n ? atomicCAS(tab + h[i], -1, k.v[i]) : k.v[i];
+    for (int i = 0; i < V; i++) old[i] = i < n ? atomicCAS(tab + h[i], -1, k.v[i]) : k.v[i];
 #pragma unroll
-    for (int i = 0; i < VW; i++) {
+    for (int i = 0; i < V; i++) {
         while (old[i] != -1 && old[i] != k.v[i]) {
             h[i] = (h[i] + 1) & mask;
             old[i] = atomicCAS(tab + h[i], -1, k.v[i]);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
     if (!LARGE) {
         walk_products_mixed<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz,
                                        a_beg, a_end, np, row_maxb[rid], s_ext, (real *)nullptr, &s_defer,
-                                       [&](const IVec &k, const RVec &, int n, real) {
+                                       [&](const IVec &k, const RVecT<1> &, int n, real) {
                                            int h[VW];
                                            ht_insert_vec(tab, mask, k, n, h, cnt);
                                        });

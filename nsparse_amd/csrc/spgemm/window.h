@@ -53,12 +53,12 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
     __syncthreads();
     unsigned char *flag = reinterpret_cast<unsigned char *>(flag4);
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
-    walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid], VWS);
+    walk_products<BS, false, VWS>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
                              a_end, g, s_ext, (real *)nullptr,
-                             [&](const IVec &k, const RVec &, int n, real) {
+                             [&](const IVecS &k, const RVecS &, int n, real) {
 #pragma unroll
-                                 for (int i = 0; i < VW; i++)
+                                 for (int i = 0; i < VWS; i++)
                                      if (i < n) flag[k.v[i] - lo] = 1;
                              });
     __syncthreads();
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, c
         __syncthreads();
         walk_products<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
                                  a_end, g, s_ext, (real *)nullptr,
-                                 [&](const IVec &k, const RVec &, int n, real) {
+                                 [&](const IVec &k, const RVecT<1> &, int n, real) {
 #pragma unroll
                                      for (int i = 0; i < VW; i++)
                                          if (i < n) {
