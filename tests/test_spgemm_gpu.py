@@ -68,6 +68,8 @@ def _bins_match(orc, st, row_prod, row_nz, lib, A, B=None):
 
 @pytest.mark.parametrize("kind,p,prec", [
     (0, (6, 6, 20), "d"),          # FEM brick: wide wave-per-row groups, numeric bins 1-2
+    (0, (20, 20, 6), "d"),         # wider cross-section: 5 K-column windows, window bins 7 / 8 in both phases
+    (0, (20, 20, 6), "s"),
     (1, (24, 24, 24), "d"),        # scalar stencil: 27-long B rows
     (2, (60000, 200000, 0), "s"),  # power law: bin 0 + heavy tail (webbase class, fp32)
     (2, (60000, 200000, 0), "d"),
@@ -318,3 +320,16 @@ def test_window_wider_than_the_bitmap(lib_d, oracle_d):
     got, st = spgemm(lib_d, A, B)
     assert st.sym_bin_size[10] == m and st.sym_fail_rows == 0 and st.num_bin_size[5] == m
     assert_parity(oracle_d, got, ref)
+
+
+def test_wide_windows_take_the_window_bins(lib_d, oracle_d):
+    """20 x 20 cross-section: the window of a C row is ~5 K columns for 375 non-zeros.  Symbolic bin 7,
+    numeric bins 7 / 8 through the products rule (span > 8 nnz but <= 2 products); LDS sized by the bin."""
+    A = synth(lib_d, 0, 20, 20, 6, seed=3)
+    ref = oracle_d.spgemm(A, A)
+    got, st = spgemm(lib_d, A, numeric_again=True)
+    assert_parity(oracle_d, got, ref)
+    assert st.sym_bin_size[7] > 0 and st.num_bin_size[8] > 0
+    assert st.num_bin_size[7] + st.num_bin_size[8] > 0.8 * A["M"]
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-12)  # numeric-only re-run, MODE 2
+    assert np.array_equal(got["col_again"], got["col"])
