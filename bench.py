@@ -412,6 +412,7 @@ def main():
             "spmv": spmv,
             "spmv_hbm": spmv_hbm,
         }
+        C.CDLL(None).fflush(None)  # the library's own stdio lines ("Read mtx file: ...") go out first
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
