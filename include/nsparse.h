@@ -180,7 +180,11 @@ void get_spgemm_flop(sfCSR *a, sfCSR *b, int M, long long int *flop);
  *                                               (reference nsparse.cu:300-353) */
 void check_spgemm_answer(sfCSR c, sfCSR ans);
 /* C = A B with the hash algorithm; allocates c->d_rpt/d_col/d_val, sets
- * c->M/N/nnz; synchronous on return             (reference kernel_spgemm_hash_d.cu:1035-1075) */
+ * c->M/N/nnz; synchronous on return             (reference kernel_spgemm_hash_d.cu:1035-1075)
+ * A product with nnz(C) >= 2^31 does not fit sfCSR's int row pointers: error -40, c->d_* NULL
+ * (upstream wraps silently).  Rows of B should have ascending columns (true for the loader's
+ * output on SuiteSparse files); other orders are accepted and take the slower global-table path
+ * for rows beyond the LDS tables.                                                              */
 void spgemm_kernel_hash(sfCSR *a, sfCSR *b, sfCSR *c);
 
 /* ========================================================================== */
