@@ -151,6 +151,7 @@ struct BinLauncher {
     bool used[NB] = {};
     bool serial;     // profiling mode: one stream, bins back to back
     int main_bin;    // the bin with the most rows runs on the main stream itself (no fork/join)
+    bool side_bins = false;  // some other bin has rows: only then is the fork event worth recording
     void *deferred[4] = {};  // scratch of kernels still in flight: returned to the cache by collect()
     int ndeferred = 0;
     void free_later(void *p) { deferred[ndeferred++] = p; }
@@ -161,12 +162,15 @@ struct BinLauncher {
             int best = 0;
             for (int b = 0; b < NB; b++)
                 if (hist[b] > best) { best = hist[b]; main_bin = b; }
+            for (int b = 0; b < NB; b++) side_bins |= hist[b] > 0 && b != main_bin;
+        } else {
+            side_bins = true;
         }
     }
     hipStream_t stream_of(int b) const { return (serial || b == main_bin) ? cx->stream[0] : cx->stream[b]; }
     void fork()
     {
-        if (!serial) NSP_CHECK(hipEventRecord(cx->ev_fork, cx->stream[0]));
+        if (!serial && side_bins) NSP_CHECK(hipEventRecord(cx->ev_fork, cx->stream[0]));
     }
     // The begin/end events sit on the stream the bin's kernels are launched on, so their
     // difference is the duration of those kernels whether or not other bins overlap.
