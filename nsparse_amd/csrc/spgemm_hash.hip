@@ -613,12 +613,13 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s0, d_sym, cx.d_mapped, (int)(sizeof(BinState) / 4),
                            (const int *)nullptr, cx.d_mapped + 120, seq);
         NSP_LAUNCH_CHECK();
+        tm.mark(1, s0);  // issued before the host waits: everything between the flag and the first
+                         // symbolic launch is GPU idle time
         wait_published(120, seq, s0);
     }
     S.n_prod = h_sym->total;
     S.max_prod_row = h_sym->maxv;
     for (int q = 0; q < NB; q++) S.sym_bin_size[q] = h_sym->hist[q];
-    tm.mark(1, s0);
 
     // ---- symbolic: nnz of every row of C, then C.rpt ----------------------------------
     if (!numeric_only) {
