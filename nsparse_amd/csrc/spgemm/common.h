@@ -183,6 +183,13 @@ __device__ __forceinline__ int wave_sum(int v)
 // carries columns only and serves long regular rows, takes VWS = 8 (-16 % there; 8 on the numeric side
 // costs occupancy and is 17 % slower, and in the hash symbolic kernels it pads the two- and
 // three-entry B rows of power-law inputs: webbase class +12 %).
+// LDS accumulators are double in both builds: ds_add_f32 runs at about one lane per clock on
+// gfx950 (SQ_LDS_IDX_ACTIVE: 74 cycles per instruction against 12.5 for ds_add_f64 -- the fp32
+// build of the numeric window kernel was 4x slower than the fp64 one), so the float build
+// multiplies in float, converts, and adds in double.  Tables, tiles and ladders are therefore
+// the fp64 ones for both precisions, and fp32 results carry less rounding noise than upstream's.
+using acc_t = double;
+
 constexpr int VW = 4;   // numeric walks and the hash symbolic kernels
 constexpr int VWS = 8;  // symbolic dense-window kernel (k_sym_dense)
 template <int V>

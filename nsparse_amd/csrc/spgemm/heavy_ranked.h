@@ -55,7 +55,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
     static_assert(CAP <= 65535, "ranks are kept in 16 bits");
     __shared__ __attribute__((aligned(16))) unsigned int bits[NWORD];
     __shared__ __attribute__((aligned(16))) unsigned short pref[NWORD];
-    __shared__ __attribute__((aligned(16))) real vals[CAP];
+    __shared__ __attribute__((aligned(16))) acc_t vals[CAP];
     __shared__ int4 l_meta[LCAP];
     __shared__ real l_av[LCAP];
     __shared__ int s_row, s_nlong, s_cut, s_ntile, s_total;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                     atomicOr(&bits[idx >> 5], 1u << (idx & 31));
                 } else {
                     const unsigned int below = bits[idx >> 5] & ((1u << (idx & 31)) - 1u);
-                    unsafeAtomicAdd(vals + (int)pref[idx >> 5] + __popc(below), x);
+                    unsafeAtomicAdd(vals + (int)pref[idx >> 5] + __popc(below), (acc_t)x);
                 }
             };
             // lane-serial entries: LA consecutive (column, value) pairs per round trip; the first
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                 }
             }
             for (int r = threadIdx.x; r < ntile; r += BS) {
-                cval[pos + r] = vals[r];
+                cval[pos + r] = (real)vals[r];
                 vals[r] = 0;
             }
 #pragma unroll

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
     constexpr int IT = R / 64;
     static_assert(W % (NW * 64) == 0, "tile width must split evenly over the wavefronts");
     // LONG_LEN: a B row longer than this is swept by a whole wavefront
-    __shared__ __attribute__((aligned(16))) real dense[W];
+    __shared__ __attribute__((aligned(16))) acc_t dense[W];
     __shared__ __attribute__((aligned(16))) unsigned int flag4[W / 4];
     __shared__ int4 l_meta[LCAP];   // sweep list: (chunk position, row end, stride, -)
     __shared__ real l_av[LCAP];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
             auto acc = [&](int col, real x) {
                 const int idx = col - c0;
                 flag[idx] = 1;
-                unsafeAtomicAdd(dense + idx, x);
+                unsafeAtomicAdd(dense + idx, (acc_t)x);
             };
             // ---- register-fed pass ---------------------------------------------------------
             // Everything inside the tile that is already in registers is accumulated and its
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                     const int idx = r0 + j * 64 + lane;
                     const int p = wpos + __popcll(m & ((1ull << lane) - 1ull));
                     if (write_col & 1) ccol[p] = c0 + idx;
-                    cval[p] = dense[idx];
+                    cval[p] = (real)dense[idx];
                     dense[idx] = 0;  // leave the window clean for the next tile
                     flag[idx] = 0;
                 }

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
 {
     constexpr int RPB = BS / LPR;
     __shared__ int keys[RPB * TROW];
-    __shared__ real vals[RPB * TROW];
+    __shared__ acc_t vals[RPB * TROW];
     for (int i = threadIdx.x; i < RPB * TROW; i += BS) {
         keys[i] = -1;
         vals[i] = 0;
@@ -39,14 +39,14 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
     const bool active = q < bin_size;
     int rid = 0;
     int *kt = keys + lrow * TROW;
-    real *vt = vals + lrow * TROW;
+    acc_t *vt = vals + lrow * TROW;
     if (active) {
         rid = row_perm[bin_off + q];
         const int e = arpt[rid + 1];
         auto add = [&](int key, real x) {
             int fresh;
             const int h = ht_find_or_insert(kt, TROW - 1, key, &fresh);
-            unsafeAtomicAdd(vt + h, x);
+            unsafeAtomicAdd(vt + h, (acc_t)x);
         };
         // EB of the lane's A entries at a time, their loads requested level by level (see
         // k_sym_small): ~3 memory round trips per row instead of 3 per entry
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
                 rank += (o != -1 && o < key) ? 1 : 0;
             }
             if (write_col & 1) ccol[off + rank] = key;
-            cval[off + rank] = vt[s];
+            cval[off + rank] = (real)vt[s];
         }
     }
 }
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
                                                   const int *__restrict__ row_maxb, int bin_off,
                                                int bin_size, int bnnz, int write_col)
 {
-    __shared__ __attribute__((aligned(16))) real vals[TMAX];
+    __shared__ __attribute__((aligned(16))) acc_t vals[TMAX];
     __shared__ __attribute__((aligned(16))) int keys[TMAX];
     __shared__ __attribute__((aligned(16))) int srt[PMAX];
     __shared__ int2 s_ext[BS];
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
                                       ht_insert_vec(keys, mask, k, n, h, fresh);
 #pragma unroll
                                       for (int i = 0; i < VW; i++)
-                                          if (i < n) unsafeAtomicAdd(vals + h[i], sc * v.v[i]);
+                                          if (i < n) unsafeAtomicAdd(vals + h[i], (acc_t)(sc * v.v[i]));
                                   });
     __syncthreads();
 
@@ -226,7 +226,7 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
         int h = hash_slot(key, mask);
         while (keys[h] != key) h = (h + 1) & mask;
         if (write_col & 1) ccol[off + i] = key;
-        cval[off + i] = vals[h];
+        cval[off + i] = (real)vals[h];
     }
 }
 

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
     //         k_sym_dense; columns and values are emitted in ascending order.
     // MODE 2: numeric-only re-run -- C.col exists; values are gathered at its columns.
     constexpr int NW = BS / 64;
-    real *dense = reinterpret_cast<real *>(nsp_dyn_lds);  // dynamic: (widest window of the bin + 4) values
+    acc_t *dense = reinterpret_cast<acc_t *>(nsp_dyn_lds);  // dynamic: (widest window of the bin + 4) values
     __shared__ int2 s_ext[BS];
     __shared__ real s_av[BS];
     __shared__ int s_wcnt[NW];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
                                 for (int i = 0; i < VW; i++)
                                     if (i < n) {
                                         const int idx = k.v[i] - lo;
-                                        unsafeAtomicAdd(dense + __mul24(idx & 3, Q) + (idx >> 2), sc * v.v[i]);
+                                        unsafeAtomicAdd(dense + __mul24(idx & 3, Q) + (idx >> 2), (acc_t)(sc * v.v[i]));
                                     }
                             });
     __syncthreads();
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
         const int n = crpt[rid + 1] - off;
         for (int p = threadIdx.x; p < n; p += BS) {
             const int idx = ccol[off + p] - lo;
-            cval[off + p] = dense[__mul24(idx & 3, Q) + (idx >> 2)];
+            cval[off + p] = (real)dense[__mul24(idx & 3, Q) + (idx >> 2)];
         }
         return;
     }
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
                 const int idx = rb + 64 * j + lane;
                 const int p = pos + __popcll(m & ((1ull << lane) - 1ull));
                 ccol[p] = lo + idx;
-                cval[p] = dense[__mul24(idx & 3, Q) + (idx >> 2)];
+                cval[p] = (real)dense[__mul24(idx & 3, Q) + (idx >> 2)];
             }
             pos += __popcll(m);
         }

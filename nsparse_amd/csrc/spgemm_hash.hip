@@ -356,7 +356,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // The heavy bin goes first: its few persistent workgroups want a whole CU each (LDS) and run
     // longest, so they should not queue behind a million small rows.  Nothing here waits on the
     // host; the cursor slab returns to the cache when the call has drained (collect()).
-    constexpr int kTileW = sizeof(real) == 8 ? 12288 : 24576;
+    constexpr int kTileW = 12288;  // LDS accumulators are double in both builds
     static const int tiled_on = !(getenv("NSPARSE_TILED") && getenv("NSPARSE_TILED")[0] == '0');
     static const int long_len = getenv("NSPARSE_TILED_LONG") ? atoi(getenv("NSPARSE_TILED_LONG")) : 128;
     static const int tile_sel = getenv("NSPARSE_TILED_W") ? atoi(getenv("NSPARSE_TILED_W")) : 0;
@@ -398,7 +398,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         NSP_LAUNCH_CHECK();
         // thin rows: bitmap-ranked accumulator (same stream: both kernels want the whole LDS of a CU)
         if (ranked_dens != 0) {
-            constexpr int kRankCap = sizeof(real) == 8 ? 10240 : 20480;
+            constexpr int kRankCap = 10240;
             hipLaunchKernelGGL((k_num_ranked<1024, 262144, kRankCap>), dim3(groups), dim3(1024), 0, st, arpt, acol,
                                aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin],
                                rows, d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len,
@@ -432,10 +432,10 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     if (hist[BIN] > 0 && now(BIN)) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
         static bool big_ok1 = false, big_ok2 = false;                                          \
-        allow_big_lds(k_num_dense<BS, SPAN, 1>, big_ok1, (int)sizeof(real) * (SPAN + 64));     \
-        allow_big_lds(k_num_dense<BS, SPAN, 2>, big_ok2, (int)sizeof(real) * (SPAN + 64));     \
+        allow_big_lds(k_num_dense<BS, SPAN, 1>, big_ok1, (int)sizeof(acc_t) * (SPAN + 64));     \
+        allow_big_lds(k_num_dense<BS, SPAN, 2>, big_ok2, (int)sizeof(acc_t) * (SPAN + 64));     \
         const int span_b = max_span[BIN] < SPAN ? max_span[BIN] : SPAN;                        \
-        const size_t lds = sizeof(real) * (size_t)((span_b + 63) / 64 * 64 + 8);               \
+        const size_t lds = sizeof(acc_t) * (size_t)((span_b + 63) / 64 * 64 + 8);               \
         if (write_col & 1)                                                                     \
             hipLaunchKernelGGL((k_num_dense<BS, SPAN, 1>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
                                lds, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
