@@ -22,7 +22,7 @@ namespace spgemm {
 // Cursors advance only in pass 2, so the cut costs nothing but the re-walk of the columns
 // beyond it.  Same cursor scheme as k_num_tiled: lane-serial entries (4 look-ahead loads per
 // step), long B rows dealt out in 64-entry chunks to wavefront sweep slots.
-template <int BS, int W, int CAP>
+template <int BS, int W, int CAP, int LCAP>
 __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                    const real *__restrict__ aval,
                                                    const int *__restrict__ brpt, const int *__restrict__ bcol,
@@ -48,10 +48,11 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
         }
     };
     constexpr int NW = BS / 64;
-    constexpr int LCAP = BS, EPT = 4, VMAX = 32, LA = 4;
+    constexpr int EPT = 4, VMAX = 32, LA = 4;
     constexpr int INF = 0x7fffffff;
     constexpr int NWORD = W / 32;
-    static_assert(NWORD == 8 * BS, "eight bitmap words per thread");
+    constexpr int WPT = NWORD / BS;  // bitmap words per thread
+    static_assert(NWORD == WPT * BS && WPT % 2 == 0, "an even number of bitmap words per thread");
     static_assert(CAP <= 65535, "ranks are kept in 16 bits");
     __shared__ __attribute__((aligned(16))) unsigned int bits[NWORD];
     __shared__ __attribute__((aligned(16))) unsigned short pref[NWORD];
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
     __shared__ int4 l_meta[LCAP];
     __shared__ real l_av[LCAP];
     __shared__ int s_row, s_nlong, s_cut, s_ntile, s_total;
-    __shared__ int s_wsum[8 * NW];
+    __shared__ int s_wsum[WPT * NW];
     int *st_cur = slab + (long long)blockIdx.x * stride_ints;
     int *st_end = st_cur + amax;
     int *st_next = st_end + amax;
@@ -293,13 +294,13 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             walk(std::false_type{}, t_max);
             lds_barrier();
             tick(t_lo == lo ? 7 : 1);
-            // ---- scan: thread t owns words t, t + BS, ..., t + 7 BS ----------------------------
+            // ---- scan: thread t owns words t, t + BS, ..., t + (WPT-1) BS -----------------------
             // (strided, so that the dense low-column stretch of a power-law row is shared by many
             // threads when the columns are written out)
-            unsigned int wd[8];
-            int pc[8];  // becomes the exclusive prefix of the word
+            unsigned int wd[WPT];
+            int pc[WPT];  // becomes the exclusive prefix of the word
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < WPT; j++) {
                 wd[j] = bits[threadIdx.x + j * BS];
                 const int c = __popc(wd[j]);
                 const int incl = wave_incl_scan(c);
@@ -308,25 +309,34 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             }
             if (threadIdx.x == 0) s_cut = t_max;
             lds_barrier();
-            if (w == 0) {  // 8 * NW partial sums in (segment, wavefront) order -> exclusive offsets
-                static_assert(8 * NW <= 128, "two partial sums per lane");
-                const int i0 = 2 * lane, i1 = 2 * lane + 1;
-                const int a0 = i0 < 8 * NW ? s_wsum[i0] : 0, a1 = i1 < 8 * NW ? s_wsum[i1] : 0;
-                const int incl = wave_incl_scan(a0 + a1);
-                if (i0 < 8 * NW) s_wsum[i0] = incl - a0 - a1;
-                if (i1 < 8 * NW) s_wsum[i1] = incl - a1;
-                if (lane == 63) s_total = incl;
+            if (w == 0) {  // WPT * NW partial sums in (segment, wavefront) order -> exclusive offsets
+                constexpr int NP = WPT * NW, PPL = (NP + 63) / 64;  // partial sums per lane
+                int a[PPL], sum = 0;
+#pragma unroll
+                for (int u = 0; u < PPL; u++) {
+                    const int i = PPL * lane + u;
+                    a[u] = i < NP ? s_wsum[i] : 0;
+                    sum += a[u];
+                }
+                int run = wave_incl_scan(sum) - sum;
+#pragma unroll
+                for (int u = 0; u < PPL; u++) {
+                    const int i = PPL * lane + u;
+                    if (i < NP) s_wsum[i] = run;
+                    run += a[u];
+                }
+                if (lane == 63) s_total = run;
             }
             lds_barrier();
             const int total = s_total;
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
+            for (int j = 0; j < WPT; j++) {
                 pc[j] += s_wsum[j * NW + w];
                 pref[threadIdx.x + j * BS] = (unsigned short)pc[j];
             }
             if (total > CAP) {  // cut at the word where the running count would pass CAP
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < WPT; j++) {
                     const int p1 = pc[j] + __popc(wd[j]);
                     if (pc[j] <= CAP && p1 > CAP) {
                         s_cut = t_lo + 32 * (threadIdx.x + j * BS);
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             // ---- emission (words and prefixes are read back: not kept live across pass 2) ------
             if (write_col & 1) {
 #pragma unroll
-                for (int j = 0; j < 8; j++) {
+                for (int j = 0; j < WPT; j++) {
                     unsigned int m = bits[threadIdx.x + j * BS];
                     const int cbase = t_lo + 32 * (threadIdx.x + j * BS);
                     int p = pos + (int)pref[threadIdx.x + j * BS];
@@ -363,7 +373,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                 vals[r] = 0;
             }
 #pragma unroll
-            for (int j = 0; j < 8; j++) bits[threadIdx.x + j * BS] = 0;
+            for (int j = 0; j < WPT; j++) bits[threadIdx.x + j * BS] = 0;
             pos += ntile;
             t_lo = t_hi;
             lds_barrier();
