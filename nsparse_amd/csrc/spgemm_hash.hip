@@ -293,7 +293,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     static const int tune_s2 = getenv("NSPARSE_SYM2_BS") ? atoi(getenv("NSPARSE_SYM2_BS")) : 128;
     NSP_SYM_TB(4, 1024, 32768)
     if (tune_s3 == 512) { NSP_SYM_TB(3, 512, 8192) } else if (tune_s3 == 1024) { NSP_SYM_TB(3, 1024, 8192) } else { NSP_SYM_TB(3, 256, 8192) }
-    if (tune_s2 == 256) { NSP_SYM_TB(2, 256, 2048) } else { NSP_SYM_TB(2, 128, 2048) }
+    if (tune_s2 == 256) { NSP_SYM_TB(2, 256, 2048) } else if (tune_s2 == 64) { NSP_SYM_TB(2, 64, 2048) } else { NSP_SYM_TB(2, 128, 2048) }
     NSP_SYM_TB(1, 64, 512)
     if (hist[0] > 0 && now(0)) {
         hipStream_t st = L.begin(0);
