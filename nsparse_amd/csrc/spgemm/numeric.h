@@ -98,10 +98,45 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
     }
 }
 
-// In-LDS bitonic sort of P (power of two) ints, ascending.  Stages whose partner distance
-// is < 128 keep every compare-exchange pair inside one wavefront's 128-element segment and
-// run back to back with wave-level ordering only; only the wider stages need a workgroup
-// barrier.
+// Value of lane (l ^ J): upper / lower half exchange by v_permlane32_swap (VALU), smaller
+// distances by ds_swizzle (LDS crossbar, no memory access).
+template <int J>
+__device__ __forceinline__ int lane_xor(int v)
+{
+    if constexpr (J == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned int)v, (unsigned int)v, false, false);
+        return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
+    } else {
+        return __builtin_amdgcn_ds_swizzle(v, (J << 10) | 0x1f);  // bit-mask mode: and 0x1f, xor J
+    }
+}
+
+// The compare-exchange stages at partner distances J, J/2, ..., 1 of merge size k on the 128
+// elements of one wavefront's segment, held two per lane: r0 = element e0 = seg*128 + lane,
+// r1 = element e0 + 64.
+template <int J>
+__device__ __forceinline__ void bitonic_stages_reg(int &r0, int &r1, int e0, int k, int lane)
+{
+    if constexpr (J == 64) {
+        const bool up = (e0 & k) == 0;
+        const int lo = r0 < r1 ? r0 : r1, hi = r0 < r1 ? r1 : r0;
+        r0 = up ? lo : hi;
+        r1 = up ? hi : lo;
+    } else {
+        const bool lower = (lane & J) == 0;
+        const int q0 = lane_xor<J>(r0), q1 = lane_xor<J>(r1);
+        const bool min0 = lower == ((e0 & k) == 0), min1 = lower == (((e0 + 64) & k) == 0);
+        r0 = min0 ? (r0 < q0 ? r0 : q0) : (r0 < q0 ? q0 : r0);
+        r1 = min1 ? (r1 < q1 ? r1 : q1) : (r1 < q1 ? q1 : r1);
+    }
+    if constexpr (J > 1) bitonic_stages_reg<J / 2>(r0, r1, e0, k, lane);
+}
+
+// In-LDS bitonic sort of P (power of two) ints, ascending.  Stages whose partner distance is below
+// 128 stay inside one wavefront's 128-element segment: the segment is taken into registers (two
+// elements per lane), the stages run on lane exchanges, and it is written back -- the first
+// version did every one of them as two LDS reads and two conditional LDS writes.  Only the wider
+// stages go through LDS with a workgroup barrier.
 template <int BS>
 __device__ __forceinline__ void bitonic_sort_lds(int *s, int P)
 {
@@ -116,19 +151,19 @@ __device__ __forceinline__ void bitonic_sort_lds(int *s, int P)
         const bool up = (i & k) == 0;
         if ((a > b) == up) { s[i] = b; s[p] = a; }
     };
-    auto wave_sync = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-    };
     // phase 1: every merge size up to 128 stays inside a 128-element segment
-    const int kmax1 = P < 128 ? P : 128;
     for (int seg = wid; seg * 128 < P; seg += NW) {
-        const int t = seg * 64 + lane;
-        for (int k = 2; k <= kmax1; k <<= 1)
-            for (int j = k >> 1; j >= 1; j >>= 1) {
-                if (t < P / 2) cex(t, j, k);
-                wave_sync();
-            }
+        const int e0 = seg * 128 + lane;
+        int r0 = e0 < P ? s[e0] : 0x7fffffff, r1 = e0 + 64 < P ? s[e0 + 64] : 0x7fffffff;
+        if (P >= 2) bitonic_stages_reg<1>(r0, r1, e0, 2, lane);
+        if (P >= 4) bitonic_stages_reg<2>(r0, r1, e0, 4, lane);
+        if (P >= 8) bitonic_stages_reg<4>(r0, r1, e0, 8, lane);
+        if (P >= 16) bitonic_stages_reg<8>(r0, r1, e0, 16, lane);
+        if (P >= 32) bitonic_stages_reg<16>(r0, r1, e0, 32, lane);
+        if (P >= 64) bitonic_stages_reg<32>(r0, r1, e0, 64, lane);
+        if (P >= 128) bitonic_stages_reg<64>(r0, r1, e0, 128, lane);
+        if (e0 < P) s[e0] = r0;
+        if (e0 + 64 < P) s[e0 + 64] = r1;
     }
     __syncthreads();
     // phase 2: wide stages with workgroup barriers, then the sub-segment tail of each merge
@@ -138,11 +173,11 @@ __device__ __forceinline__ void bitonic_sort_lds(int *s, int P)
             __syncthreads();
         }
         for (int seg = wid; seg * 128 < P; seg += NW) {
-            const int t = seg * 64 + lane;
-            for (int j = 64; j >= 1; j >>= 1) {
-                cex(t, j, k);
-                wave_sync();
-            }
+            const int e0 = seg * 128 + lane;
+            int r0 = s[e0], r1 = s[e0 + 64];
+            bitonic_stages_reg<64>(r0, r1, e0, k, lane);
+            s[e0] = r0;
+            s[e0 + 64] = r1;
         }
         __syncthreads();
     }
