@@ -408,14 +408,28 @@ __device__ __forceinline__ void ht_insert_vec(int *tab, int mask, const IVecT<V>
     for (int i = 0; i < V; i++) h[i] = hash_slot(k.v[i], mask);
 #pragma unroll
     for (int i = 0; i < V; i++) old[i] = i < n ? atomicCAS(tab + h[i], -1, k.v[i]) : k.v[i];
+    // collisions of all V elements are resolved in ONE loop (its exit test is the only branch: V
+    // separate probe loops cost V exec-mask save / restore sequences per step even when nothing collides)
+    bool pend[V], any = false;
 #pragma unroll
     for (int i = 0; i < V; i++) {
-        while (old[i] != -1 && old[i] != k.v[i]) {
-            h[i] = (h[i] + 1) & mask;
-            old[i] = atomicCAS(tab + h[i], -1, k.v[i]);
-        }
-        fresh += old[i] == -1;
+        pend[i] = old[i] != -1 && old[i] != k.v[i];
+        any |= pend[i];
     }
+    while (any) {
+        any = false;
+#pragma unroll
+        for (int i = 0; i < V; i++) {
+            if (pend[i]) {
+                h[i] = (h[i] + 1) & mask;
+                old[i] = atomicCAS(tab + h[i], -1, k.v[i]);
+                pend[i] = old[i] != -1 && old[i] != k.v[i];
+                any |= pend[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; i++) fresh += old[i] == -1;
 }
 
 
