@@ -52,14 +52,16 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
     if (threadIdx.x == 0) s_nz = 0;
     __syncthreads();
     unsigned char *flag = reinterpret_cast<unsigned char *>(flag4);
+    // lanes past the end of a B row store into scratch bytes behind the flags instead of being
+    // masked off: a select costs less than an exec-mask save / restore per element
+    const int dummy = 4 * words + 32 + (threadIdx.x & 31);
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
     const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid], VWS);
     walk_products<BS, false, VWS>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
                              a_end, g, s_ext, (real *)nullptr,
                              [&](const IVecS &k, const RVecS &, int n, real) {
 #pragma unroll
-                                 for (int i = 0; i < VWS; i++)
-                                     if (i < n) flag[k.v[i] - lo] = 1;
+                                 for (int i = 0; i < VWS; i++) flag[i < n ? k.v[i] - lo : dummy] = 1;
                              });
     __syncthreads();
     int cnt = 0;
