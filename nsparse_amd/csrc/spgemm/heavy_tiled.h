@@ -46,7 +46,7 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
     // LONG_LEN: a B row longer than this is swept by a whole wavefront
     __shared__ __attribute__((aligned(16))) acc_t dense[W];
     __shared__ __attribute__((aligned(16))) unsigned int flag4[W / 4];
-    __shared__ int4 l_meta[LCAP];   // sweep list: (chunk position, row end, stride, -)
+    __shared__ int4 l_meta[LCAP];   // sweep list: (chunk position, row end, stride, next unused column)
     __shared__ real l_av[LCAP];
     __shared__ int s_row;
     __shared__ int s_nlong;
@@ -234,34 +234,82 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                 tick(2);
             }
             // ---- overflow paths: state in LDS / global memory --------------------------------
-            // sweep slots beyond the register ones: same chunk walk, one round trip per chunk
-            for (int i = w + KS * NW; i < nlong; i += NW) {
-                int4 mt = l_meta[i];
-                const real av = l_av[i];
-                while (true) {
-                    const int k = mt.x + lane;
-                    const int col = k < mt.y ? bcol[k] : INF;
-                    const real bv = k < mt.y ? bval[k] : (real)0;
-                    if ((unsigned)(col - c0) < (unsigned)tw) acc(col, av * bv);
-                    if (__builtin_amdgcn_readlane(col, 63) >= tile_end) break;
-                    mt.x += mt.z;
+            // sweep slots beyond the register ones: same chunk walk with the state in LDS.  A slot
+            // remembers the first column it has not used yet (l_meta.w), so tiles it has nothing in
+            // cost no load, and the current chunks of SB slots are requested together.
+            constexpr int SB = 4;
+            for (int i0 = w + KS * NW; i0 < nlong; i0 += SB * NW) {
+                int4 mt[SB];
+                int col[SB];
+                real bv[SB];
+#pragma unroll
+                for (int j = 0; j < SB; j++) {
+                    const int i = i0 + j * NW;
+                    mt[j] = i < nlong ? l_meta[i] : make_int4(0, 0, 64, INF);
+                    const int k = mt[j].x + lane;
+                    const bool ld = mt[j].w < tile_end && k < mt[j].y;
+                    col[j] = ld ? bcol[k] : INF;
+                    bv[j] = ld ? bval[k] : (real)0;
                 }
-                if (lane == 0) l_meta[i].x = mt.x;
+#pragma unroll
+                for (int j = 0; j < SB; j++) {
+                    if (mt[j].w >= tile_end) continue;  // wave-uniform
+                    const int i = i0 + j * NW;
+                    const real av = l_av[i];
+                    int c = col[j];
+                    real x = bv[j];
+                    int cp = mt[j].x;  // chunk position
+                    while (true) {
+                        if ((unsigned)(c - c0) < (unsigned)tw) acc(c, av * x);
+                        if (__builtin_amdgcn_readlane(c, 63) >= tile_end) break;
+                        cp += mt[j].z;
+                        const int k = cp + lane;
+                        c = k < mt[j].y ? bcol[k] : INF;
+                        x = k < mt[j].y ? bval[k] : (real)0;
+                    }
+                    // columns ascend across the lanes: the first lane at or beyond the tile end holds
+                    // the next column this slot will contribute
+                    const unsigned long long beyond = __ballot(c >= tile_end);
+                    const int nxt = __builtin_amdgcn_readlane(c, __ffsll((long long)beyond) - 1);
+                    if (lane == 0) {
+                        l_meta[i].x = cp;
+                        l_meta[i].w = nxt;
+                    }
+                }
             }
-            // A entries beyond EPT * BS: one product per memory round trip
+            // A entries beyond EPT * BS (cursor in the global slice): the state reads of all of a
+            // thread's entries go out together, then LA look-ahead pairs per round trip
+            constexpr int LA = 4;
             for (int e = threadIdx.x + EPT * BS; e < alen; e += BS) {
                 int col = st_next[e];
                 if (col < tile_end) {
                     int cur = st_cur[e];
                     const int end = st_end[e];
                     const real av = st_av[e];
-                    do {
-                        const real bv = bval[cur];
-                        cur++;
-                        const int ncol = cur < end ? bcol[cur] : INF;  // issued with bv
-                        acc(col, av * bv);
-                        col = ncol;
-                    } while (col < tile_end);
+                    while (col < tile_end) {
+                        int c[LA];
+                        real v[LA];
+                        c[0] = col;
+#pragma unroll
+                        for (int j = 1; j < LA; j++) c[j] = cur + j < end ? bcol[cur + j] : INF;
+#pragma unroll
+                        for (int j = 0; j < LA; j++) v[j] = cur + j < end ? bval[cur + j] : (real)0;
+                        int n = 0;
+                        col = INF;
+#pragma unroll
+                        for (int j = 0; j < LA; j++) {
+                            if (n == j) {
+                                if (c[j] < tile_end) {
+                                    acc(c[j], av * v[j]);
+                                    n = j + 1;
+                                } else {
+                                    col = c[j];
+                                }
+                            }
+                        }
+                        cur += n;
+                        if (n == LA) col = cur < end ? bcol[cur] : INF;
+                    }
                     st_cur[e] = cur;
                     st_next[e] = col;
                 }
