@@ -13,12 +13,17 @@ constexpr int NB = kMaxBins;
 // ---- bin ladders ------------------------------------------------------------------
 // Symbolic, n = intermediate products of the row (upper bound of its nnz):
 //   bin 0  n <= 32      sub-wave rows, 4 lanes per row, 64-key table per row
-//   bin 1  n <= 512     one workgroup per row,   64 threads, table <=   512 keys ( 2 KiB)
-//   bin 2  n <= 2048                            128 threads,        <=  2048      ( 8 KiB)
-//   bin 3  n <= 8192                            256 threads,        <=  8192      (32 KiB)
-//   bin 4  n <= 32768                          1024 threads,        <= 32768      (128 KiB)
-//   bin 5  n  > 32768   1024 threads, 32768 keys, row FAILS over to the global table when
+//   bin 1  n <= 435     one workgroup per row,   64 threads, table <=   512 keys ( 2 KiB)
+//   bin 2  n <= 1740                            128 threads,        <=  2048      ( 8 KiB)
+//   bin 3  n <= 6963                            256 threads,        <=  8192      (32 KiB)
+//   bin 4  n <= 27852                          1024 threads,        <= 32768      (128 KiB)
+//   bin 5  n  > 27852   1024 threads, 32768 keys, row FAILS over to the global table when
 //                       it holds more than 24576 distinct keys
+//   (thresholds = 85 % of the largest table of the bin, and the table of a row is
+//   pow2_ceil(1.5 n) up to that size: the reference fills a bin up to its table size, and a row
+//   whose products hardly repeat -- power-law inputs -- then probes a full table.  Measured on
+//   the webbase class: rows with 253 or 500 products in 256- and 512-key tables took 150-250 us
+//   each and were the whole duration of their kernel, 0.22 ms; now 0.05 ms.)
 // Numeric, n = exact nnz of the C row, table = pow2_ceil(1.5 n) (load factor <= 2/3):
 //   bin 0  n <= 16      sub-wave rows, 4 lanes per row, 32 slots per row
 //   bin 1  n <= 170     64 threads,  table <=  256 slots
@@ -46,7 +51,7 @@ struct Thr {
     int bits_wide_span;  // the brim, or overflow them) and span <= bits_wide_span -> bin 10, which
                          // then covers the window in pieces of bits_span[1] columns; 0 disables
 };
-constexpr Thr kSymThr = {32,   {512, 2048, 8192, 32768}, {4096, 16384, 65536}, 8, {262144, 1048576}, 64, 2048,
+constexpr Thr kSymThr = {32,   {435, 1740, 6963, 27852}, {4096, 16384, 65536}, 8, {262144, 1048576}, 64, 2048,
                          8192, 16 * 1048576};
 constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8, {0, 0}, 0, 0, 0, 0};
 constexpr int kSymLargeBin = 5;

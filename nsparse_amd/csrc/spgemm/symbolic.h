@@ -99,7 +99,7 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
     if (slot < 0) return;
     const int rid = row_perm[bin_off + slot];
     const int np = row_prod[rid];
-    int T = LARGE ? TMAX : pow2_ceil(np);
+    int T = LARGE ? TMAX : pow2_ceil(np + (np >> 1));  // load factor <= 2/3 where the bin's table allows
     if (T < 64) T = 64;
     if (T > TMAX) T = TMAX;
     const int mask = T - 1;
