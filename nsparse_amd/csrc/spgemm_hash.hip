@@ -277,10 +277,17 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         L.end(BIN);                                                                            \
     }
     // Host launch cost is on the critical path (~14 us per bin: stream wait, two event records,
-    // the launch): the bin with the most rows -- the one on the main stream -- goes out first, the
+    // the launch): the bin with the most rows -- the one on the main stream -- goes out early, the
     // others follow biggest rows first.
-    for (int pass = 0; pass < 2; pass++) {
-    auto now = [&](int bin) { return (pass == 0) == (bin == L.main_bin); };
+    // Workgroups that need (nearly) the whole LDS of a CU -- the 2^20-bit window, the 32768-key
+    // table -- are issued before the flood of small workgroups: behind it they would wait for a CU
+    // to drain completely, i.e. for the end of the biggest kernel (webbase class: one hub row then
+    // ran alone for 128 us at the end of the phase).
+    for (int pass = 0; pass < 3; pass++) {
+    auto now = [&](int bin) {
+        const bool big = bin == 10 || bin == 4;
+        return bin == L.main_bin ? pass == 1 : (big ? pass == 0 : pass == 2);
+    };
     NSP_SYM_BITS(10, 1024, 32768)
     NSP_SYM_BITS(9, 512, 8192)
     static const int tune_d6 = getenv("NSPARSE_SYMD6_BS") ? atoi(getenv("NSPARSE_SYMD6_BS")) : 128;
@@ -367,10 +374,13 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // taking the wide rows there is no limit
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
                            (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
-    // launch order: the bin with the most rows (main stream) first, then the heavy bin, then the
-    // rest biggest rows first (see symbolic_phase)
-    for (int pass = 0; pass < 2; pass++) {
-    auto now = [&](int bin) { return (pass == 0) == (bin == L.main_bin); };
+    // launch order: the heavy bin, then the bin with the most rows (main stream), then the rest
+    // biggest rows first (see symbolic_phase)
+    for (int pass = 0; pass < 3; pass++) {
+    auto now = [&](int bin) {
+        const bool big = bin == kNumGlobalBin;  // persistent workgroups that own a CU's LDS
+        return bin == L.main_bin ? pass == 1 : (big ? pass == 0 : pass == 2);
+    };
     if (use_tiled && now(kNumGlobalBin)) {
         hipStream_t st = L.begin(kNumGlobalBin);
         const int rows = hist[kNumGlobalBin];
