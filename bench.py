@@ -129,6 +129,7 @@ def main():
     import nsparse_amd as ns
     from nsparse_amd.dist import make_gpu_sharded_spmv, row_partition
     lib = ns.load("d")
+    lib.nsparse_set_bin_timing(1)  # the roofline leg needs the kernel time of the dominant bin
     w = 8
 
     # ------------------------------------------------------------------ workload ----

@@ -254,9 +254,14 @@ void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out);
 void nsparse_get_spgemm_bins(int *sym_thresholds, int *num_thresholds);
 
 /* 1: serialise the row bins on one stream (clean per-kernel durations for roofline work
- *    and rocprof); 0 (default): bins overlap on their own streams.  The per-bin HIP-event
- *    timings in nsparse_spgemm_stats are recorded in both modes.                */
+ *    and rocprof, per-bin timings on); 0 (default): bins overlap on their own streams.  */
 void nsparse_set_profiling(int on);
+
+/* Per-bin kernel times in nsparse_spgemm_stats (ms_sym_bin / ms_num_bin): HIP events around the
+ * kernels of every bin.  Off by default -- two runtime calls per bin on the launch path, which is
+ * the critical path of matrices that use many bins; the phase times (ms_setup ... ms_total) are
+ * always measured.  Profiling mode implies it.  Returns the previous setting.                  */
+int nsparse_set_bin_timing(int on);
 
 /* 1 (default): device blocks released by release_csr/release_amb and the internal
  * workspaces are kept in a cache and reused; 0: every call hipMalloc/hipFree's

@@ -83,6 +83,7 @@ SIGNATURES = {
     "nsparse_spgemm_set_sorted": (C.c_int, [C.c_int]),
     "nsparse_get_spgemm_bins": (None, [c_int_p, c_int_p]),
     "nsparse_set_profiling": (None, [C.c_int]),
+    "nsparse_set_bin_timing": (C.c_int, [C.c_int]),
     "nsparse_set_workspace_cache": (None, [C.c_int]),
     "nsparse_trim_workspace": (None, []),
     "nsparse_last_spmv_ms": (C.c_float, []),

@@ -136,6 +136,12 @@ extern "C" {
 void nsparse_set_workspace_cache(int on) { nsp::dev_cache_enable(on != 0); }
 void nsparse_trim_workspace(void) { nsp::dev_cache_trim(); }
 void nsparse_set_profiling(int on) { nsp::ctx().profiling = (on != 0); }
+int nsparse_set_bin_timing(int on)
+{
+    const int old = nsp::ctx().bin_timing;
+    nsp::ctx().bin_timing = (on != 0);
+    return old;
+}
 
 void csr_memcpy(sfCSR *mat)
 {

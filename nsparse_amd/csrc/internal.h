@@ -51,6 +51,7 @@ struct Context {
     int *d_mapped = nullptr;            // device address of h_mapped
     int seq = 0;                        // publish sequence number
     bool profiling = false;
+    bool bin_timing = false;            // per-bin begin / end events in spgemm_kernel_hash (two API calls per bin)
     bool ready = false;
 };
 Context &ctx();

@@ -150,13 +150,14 @@ struct BinLauncher {
     hipEvent_t *ev;  // 2 * NB events: begin/end of every bin
     bool used[NB] = {};
     bool serial;     // profiling mode: one stream, bins back to back
+    bool timed;      // begin / end events per bin (nsparse_set_bin_timing, or profiling mode)
     int main_bin;    // the bin with the most rows runs on the main stream itself (no fork/join)
     bool side_bins = false;  // some other bin has rows: only then is the fork event worth recording
     void *deferred[4] = {};  // scratch of kernels still in flight: returned to the cache by collect()
     int ndeferred = 0;
     void free_later(void *p) { deferred[ndeferred++] = p; }
     BinLauncher(Context &c, int phase, const int *hist = nullptr)
-        : cx(&c), ev(c.ev_bin + phase * 2 * NB), serial(c.profiling), main_bin(-1)
+        : cx(&c), ev(c.ev_bin + phase * 2 * NB), serial(c.profiling), timed(c.profiling || c.bin_timing), main_bin(-1)
     {
         if (hist) {
             int best = 0;
@@ -179,10 +180,13 @@ struct BinLauncher {
         hipStream_t st = stream_of(b);
         if (st != cx->stream[0] && !used[b]) NSP_CHECK(hipStreamWaitEvent(st, cx->ev_fork, 0));
         used[b] = true;
-        NSP_CHECK(hipEventRecord(ev[2 * b], st));
+        if (timed) NSP_CHECK(hipEventRecord(ev[2 * b], st));
         return st;
     }
-    void end(int b) { NSP_CHECK(hipEventRecord(ev[2 * b + 1], stream_of(b))); }
+    void end(int b)
+    {
+        if (timed) NSP_CHECK(hipEventRecord(ev[2 * b + 1], stream_of(b)));
+    }
     void join()
     {
         for (int b = 0; b < NB; b++) {
@@ -197,7 +201,7 @@ struct BinLauncher {
         ndeferred = 0;
         for (int b = 0; b < NB; b++) {
             out[b] = 0;
-            if (used[b]) {
+            if (used[b] && timed) {
                 // the flag poll proves the GPU is done, not that the runtime has retired the event
                 NSP_CHECK(hipEventSynchronize(ev[2 * b + 1]));
                 NSP_CHECK(hipEventElapsedTime(&out[b], ev[2 * b], ev[2 * b + 1]));

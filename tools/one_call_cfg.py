@@ -6,7 +6,7 @@ import nsparse_amd as ns
 from gpu_util import synth
 from tools.run_configs import CASES
 prec, kind, p = CASES[sys.argv[1]]
-lib = ns.load(prec); A = synth(lib, kind, *p, seed=0x5EED0022)
+lib = ns.load(prec); lib.nsparse_set_bin_timing(1); A = synth(lib, kind, *p, seed=0x5EED0022)
 a = lib.csr_from_numpy(A["rpt"], A["col"], A["val"], A["N"]); b = lib.csr_from_numpy(A["rpt"], A["col"], A["val"], A["N"])
 lib.csr_memcpy(C.byref(a)); lib.csr_memcpy(C.byref(b)); c = ns.sfCSR()
 serial = os.environ.get("NSPARSE_SERIAL") == "1"

@@ -40,6 +40,7 @@ CASES = {
 def run(name, check=True, reps=3):
     prec, kind, p = CASES[name]
     lib, orc = ns.load(prec), Oracle(prec)
+    lib.nsparse_set_bin_timing(int(os.environ.get("NSPARSE_BIN_TIMING", "0")))  # off: what a caller gets
     t = time.time()
     A = synth(lib, kind, *p, seed=0x5EED0022)
     gen = time.time() - t
