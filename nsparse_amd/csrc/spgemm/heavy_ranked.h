@@ -22,7 +22,13 @@ namespace spgemm {
 // Cursors advance only in pass 2, so the cut costs nothing but the re-walk of the columns
 // beyond it.  Same cursor scheme as k_num_tiled: lane-serial entries (4 look-ahead loads per
 // step), long B rows dealt out in 64-entry chunks to wavefront sweep slots.
-template <int BS, int W, int CAP, int LCAP>
+//
+// SYM = true is the SYMBOLIC twin for rows whose window is wider than the 2^20-bit window of
+// k_sym_bits: the same cursors, one walk per tile that only sets bits (and commits), a popcount,
+// no ranks, no values -- W = 2^20 columns per tile.  k_sym_bits covers such a window in pieces and
+// walks ALL products for every piece (R-MAT-22: 4 pieces); with cursors every product is seen once.
+// Needs sorted rows of B like the numeric kernels; writes row_nz_out[rid].
+template <int BS, int W, int CAP, int LCAP, bool SYM = false>
 __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                    const real *__restrict__ aval,
                                                    const int *__restrict__ brpt, const int *__restrict__ bcol,
@@ -34,7 +40,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                                                    const int *__restrict__ row_span, int *__restrict__ slab,
                                                    long long stride_ints, int amax, int write_col,
                                                    int LONG_LEN, int dens, int tiled_w,
-                                                   unsigned long long *prof)
+                                                   unsigned long long *prof, int *__restrict__ row_nz_out = nullptr)
 {
     // prof (NSPARSE_TILED_PROF=1), 100 MHz ticks of thread 0: 0 set-up, 1 pass 1, 2 scan, 3 pass 2,
     // 4 emission; 5 tiles, 6 rows
@@ -55,8 +61,8 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
     static_assert(NWORD == WPT * BS && WPT % 2 == 0, "an even number of bitmap words per thread");
     static_assert(CAP <= 65535, "ranks are kept in 16 bits");
     __shared__ __attribute__((aligned(16))) unsigned int bits[NWORD];
-    __shared__ __attribute__((aligned(16))) unsigned short pref[NWORD];
-    __shared__ __attribute__((aligned(16))) acc_t vals[CAP];
+    __shared__ __attribute__((aligned(16))) unsigned short pref[SYM ? 8 : NWORD];
+    __shared__ __attribute__((aligned(16))) acc_t vals[SYM ? 8 : CAP];
     __shared__ int4 l_meta[LCAP];
     __shared__ real l_av[LCAP];
     __shared__ int s_row, s_nlong, s_cut, s_ntile, s_total;
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
     real *st_av = reinterpret_cast<real *>(st_next + amax);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < NWORD; i += BS) bits[i] = 0;
-    for (int i = threadIdx.x; i < CAP; i += BS) vals[i] = 0;
+    for (int i = threadIdx.x; i < (SYM ? 8 : CAP); i += BS) vals[i] = 0;
     while (true) {
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -79,17 +85,19 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
         if (q >= count) break;
         const int rid = row_perm[bin_off + q];
         const int lo = row_lo[rid], span = row_span[rid];
-        int pos = crpt[rid];
+        int pos = SYM ? 0 : crpt[rid];
+        const int pos0 = pos;
+        const int row_nnz = SYM ? 0 : crpt[rid + 1] - pos;
         // dens > 0: only rows thinner than one non-zero per `dens` columns or wider than 32 dense
         // tiles (the rest belong to k_num_tiled); dens <= 0: every row
-        if (dens > 0 && (long long)(crpt[rid + 1] - pos) * dens >= span && span <= 32 * tiled_w) continue;
+        if (!SYM && dens > 0 && (long long)row_nnz * dens >= span && span <= 32 * tiled_w) continue;
         const int a_beg = arpt[rid], alen = arpt[rid + 1] - a_beg;
-        const int split = 64 * ((span + W - 1) / W + (crpt[rid + 1] - pos) / CAP + 1);
+        const int split = 64 * ((span + W - 1) / W + row_nnz / CAP + 1);
         auto init_entry = [&](int e, int &cur, int &end, real &av) -> bool {
             const int c = acol[a_beg + e];
             cur = brpt[c];
             end = brpt[c + 1];
-            av = aval[a_beg + e];
+            av = SYM ? (real)0 : aval[a_beg + e];
             const int len = end - cur;
             if (len <= LONG_LEN) return true;
             int V = (len + split - 1) / split;
@@ -126,6 +134,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
         const int nlong = s_nlong < LCAP ? s_nlong : LCAP;
         const int row_end = lo + span;
         int t_lo = lo;
+        int sym_cnt = 0;
         tick(0);
         if (prof) {
             t_acc[6]++;
@@ -137,8 +146,10 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             // Pass 1 runs to t_max and everything beyond the cut is walked again by the next tile,
             // so t_max aims at ~7/8 of CAP columns at the density of what is left of the row.
             int t_max;
-            {
-                const long long rem_nnz = crpt[rid + 1] - pos, rem_span = row_end - t_lo;
+            if (SYM) {
+                t_max = row_end - t_lo <= W ? row_end : t_lo + W;
+            } else {
+                const long long rem_nnz = row_nnz - (pos - pos0), rem_span = row_end - t_lo;
                 long long wd_est = rem_nnz > 0 ? (long long)(CAP - CAP / 8) * rem_span / rem_nnz : rem_span;
                 wd_est = (wd_est + 31) & ~31LL;
                 if (wd_est > W) wd_est = W;
@@ -149,7 +160,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             // PASS2 = true: accumulate by rank and commit the cursors.
             auto touch = [&](auto pass2, int col, real x) {
                 const unsigned int idx = (unsigned int)(col - t_lo);
-                if (!decltype(pass2)::value) {
+                if (SYM || !decltype(pass2)::value) {
                     atomicOr(&bits[idx >> 5], 1u << (idx & 31));
                 } else {
                     const unsigned int below = bits[idx >> 5] & ((1u << (idx & 31)) - 1u);
@@ -162,7 +173,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                 c[0] = c0;
 #pragma unroll
                 for (int j = 1; j < LA; j++) c[j] = k + j < end ? bcol[k + j] : INF;
-                if (decltype(pass2)::value) {
+                if (!SYM && decltype(pass2)::value) {
 #pragma unroll
                     for (int j = 0; j < LA; j++) v[j] = k + j < end ? bval[k + j] : (real)0;
                 }
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                 for (int j = 0; j < LA; j++) {
                     if (n == j) {
                         if (c[j] < t_hi) {
-                            touch(pass2, c[j], decltype(pass2)::value ? av * v[j] : (real)0);
+                            touch(pass2, c[j], (!SYM && decltype(pass2)::value) ? av * v[j] : (real)0);
                             n = j + 1;
                         } else {
                             next = c[j];
@@ -211,7 +222,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                         const int kk = mt[j].x + lane;
                         col[j] = kk < mt[j].y ? bcol[kk] : INF;
                         bv[j] = 0;
-                        if (P2) bv[j] = kk < mt[j].y ? bval[kk] : (real)0;
+                        if (P2 && !SYM) bv[j] = kk < mt[j].y ? bval[kk] : (real)0;
                     }
                 };
                 auto sweep_use = [&](int i0, const int4(&mt)[SB], const int(&col)[SB], const real(&bv)[SB]) {
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                             k += mt[j].z;
                             const int kk = k + lane;
                             c = kk < mt[j].y ? bcol[kk] : INF;
-                            if (P2) x = kk < mt[j].y ? bval[kk] : (real)0;
+                            if (P2 && !SYM) x = kk < mt[j].y ? bval[kk] : (real)0;
                         }
                         if (P2 && lane == 0) l_meta[i].x = k;
                     }
@@ -291,6 +302,18 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                     }
                 }
             };
+            if (SYM) {  // one committing walk that only sets bits, then count and clear
+                walk(std::true_type{}, t_max);
+                lds_barrier();
+#pragma unroll
+                for (int j = 0; j < WPT; j++) {
+                    sym_cnt += __popc(bits[threadIdx.x + j * BS]);
+                    bits[threadIdx.x + j * BS] = 0;
+                }
+                t_lo = t_max;
+                lds_barrier();
+                continue;
+            }
             walk(std::false_type{}, t_max);
             lds_barrier();
             tick(t_lo == lo ? 7 : 1);
@@ -379,6 +402,16 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             lds_barrier();
             tick(4);
             if (prof) t_acc[5]++;
+        }
+        if (SYM) {  // nnz of the row = bits seen over all tiles
+            sym_cnt = wave_sum(sym_cnt);
+            if (lane == 0) s_wsum[w] = sym_cnt;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                int tot = 0;
+                for (int u = 0; u < NW; u++) tot += s_wsum[u];
+                row_nz_out[rid] = tot;
+            }
         }
     }
     if (prof && threadIdx.x == 0)

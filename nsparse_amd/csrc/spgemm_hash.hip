@@ -238,7 +238,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
                                   const int *row_span, int *row_nz, int *row_perm, const int *hist,
                                   int max_prod, BinState *d_bs, Context &cx, float *ms_bin,
                                   int *fail_rows, const int *bm_off, unsigned int *bm,
-                                  int *row_span_num, const int *max_span)
+                                  int *row_span_num, const int *max_span, int max_alen, bool b_sorted)
 {
     BinLauncher L(cx, 0, hist);
     int off[NB + 1];
@@ -292,7 +292,26 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         const bool big = bin == 10 || bin == 4;
         return bin == L.main_bin ? pass == 1 : (big ? pass == 0 : pass == 2);
     };
-    NSP_SYM_BITS(10, 1024, 32768)
+    // bin 10 with windows wider than the 2^20-bit window and sorted rows of B: cursor kernel, every
+    // product seen once (k_sym_bits would walk all products once per 2^20-column piece)
+    static const int sym_cursor_on = !(getenv("NSPARSE_SYM_CURSOR") && getenv("NSPARSE_SYM_CURSOR")[0] == '0');
+    if (hist[10] > 0 && now(10) && sym_cursor_on && b_sorted && max_span[10] > 32768 * 32 && max_alen > 0) {
+        hipStream_t st = L.begin(10);
+        const int rows = hist[10];
+        const int amax = (max_alen + 1) & ~1;
+        const long long stride_ints = 3LL * amax + (long long)amax * (sizeof(real) / sizeof(int));
+        const int groups = rows < 1024 ? rows : 1024;
+        int *slab = (int *)dev_alloc(sizeof(int) * (size_t)stride_ints * groups);
+        hipLaunchKernelGGL((k_num_ranked<1024, 1048576, 8, 1024, true>), dim3(groups), dim3(1024), 0, st, arpt, acol,
+                           (const real *)nullptr, brpt, bcol, (const real *)nullptr, (const int *)nullptr,
+                           (int *)nullptr, (real *)nullptr, row_perm, off[10], rows, d_bs, row_lo, row_span, slab,
+                           stride_ints, amax, 0, 128, -1, 0, (unsigned long long *)nullptr, row_nz);
+        NSP_LAUNCH_CHECK();
+        L.end(10);
+        L.free_later(slab);
+    } else {
+        NSP_SYM_BITS(10, 1024, 32768)
+    }
     NSP_SYM_BITS(9, 512, 8192)
     static const int tune_d6 = getenv("NSPARSE_SYMD6_BS") ? atoi(getenv("NSPARSE_SYMD6_BS")) : 128;
     static const int tune_d8 = getenv("NSPARSE_SYMD8_BS") ? atoi(getenv("NSPARSE_SYMD8_BS")) : 512;
@@ -654,7 +673,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
             bm = (unsigned int *)dev_alloc(sizeof(unsigned int) * (size_t)h_sym->bm_total);
         BinLauncher LS = symbolic_phase(a, b, row_prod, row_maxb, row_lo, row_span, row_nz, row_perm, h_sym->hist,
                                         h_sym->maxv, d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows,
-                                        bm_off, bm, row_span_num, h_sym->max_span);
+                                        bm_off, bm, row_span_num, h_sym->max_span, (int)h_sym->max_alen,
+                                        h_sym->b_unsorted == 0);
         sym_used = LS;
         c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
         scan_tmp = scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
