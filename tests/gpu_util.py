@@ -151,9 +151,9 @@ def ladders(lib):
     return list(sym), list(num)
 
 
-def spgemm_subprocess(A, env, prec="d"):
-    """Run spgemm() on A in a fresh interpreter with extra environment (the library reads its
-    tuning switches once per process).  Returns (C dict, dict of stats lists)."""
+def spgemm_subprocess(A, env, prec="d", B=None):
+    """Run spgemm() on A (times B, default A) in a fresh interpreter with extra environment (the
+    library reads its tuning switches once per process).  Returns (C dict, dict of stats lists)."""
     import json
     import os
     import subprocess
@@ -162,18 +162,22 @@ def spgemm_subprocess(A, env, prec="d"):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.TemporaryDirectory() as td:
         np.savez(os.path.join(td, "a.npz"), rpt=A["rpt"], col=A["col"], val=A["val"], M=A["M"], N=A["N"])
+        Bm = A if B is None else B
+        np.savez(os.path.join(td, "b.npz"), rpt=Bm["rpt"], col=Bm["col"], val=Bm["val"], M=Bm["M"], N=Bm["N"])
         code = (
             "import sys, json, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r);"
             "import nsparse_amd as ns; from gpu_util import spgemm;"
-            "z = np.load(%r); A = dict(rpt=z['rpt'], col=z['col'], val=z['val'], M=int(z['M']), N=int(z['N']));"
-            "got, st = spgemm(ns.load(%r), A);"
+            "ld = lambda f: (lambda z: dict(rpt=z['rpt'], col=z['col'], val=z['val'], M=int(z['M']), N=int(z['N'])))(np.load(f));"
+            "A = ld(%r); B = ld(%r);"
+            "got, st = spgemm(ns.load(%r), A, B);"
             "np.savez(%r, rpt=got['rpt'], col=got['col'], val=got['val']);"
             "print(json.dumps(dict(sym=list(st.sym_bin_size), num=list(st.num_bin_size), fails=st.sym_fail_rows)))"
-        ) % (root, os.path.join(root, "tests"), os.path.join(td, "a.npz"), prec, os.path.join(td, "c.npz"))
+        ) % (root, os.path.join(root, "tests"), os.path.join(td, "a.npz"), os.path.join(td, "b.npz"), prec,
+             os.path.join(td, "c.npz"))
         r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
                            env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-3000:]
         stats = json.loads(r.stdout.strip().splitlines()[-1])
         z = np.load(os.path.join(td, "c.npz"))
-        got = dict(M=A["M"], N=A["N"], nnz=int(z["rpt"][-1]), rpt=z["rpt"], col=z["col"], val=z["val"])
+        got = dict(M=A["M"], N=Bm["N"], nnz=int(z["rpt"][-1]), rpt=z["rpt"], col=z["col"], val=z["val"])
     return got, stats

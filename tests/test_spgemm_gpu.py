@@ -304,8 +304,9 @@ def test_heavy_rows_tiled_and_ranked_kernels_agree(prec, lib_d, lib_s, oracle_d,
 
 
 def test_window_wider_than_the_bitmap(lib_d, oracle_d):
-    """3 M columns: the symbolic bit window (2^20 columns of LDS) covers the rows in three pieces
-    (bin 10), the numeric phase takes the ranked kernel (a dense tiling would need 245 tiles)."""
+    """3 M columns: symbolic bin 10 -- the cursor kernel over three 2^20-column tiles, or with
+    NSPARSE_SYM_CURSOR=0 the bit window in three pieces --, the numeric phase takes the ranked kernel
+    (a dense tiling would need 245 tiles)."""
     import scipy.sparse as sp
     rng = np.random.default_rng(77)
     m, k, n = 48, 3000, 3_000_000
@@ -320,6 +321,10 @@ def test_window_wider_than_the_bitmap(lib_d, oracle_d):
     got, st = spgemm(lib_d, A, B)
     assert st.sym_bin_size[10] == m and st.sym_fail_rows == 0 and st.num_bin_size[5] == m
     assert_parity(oracle_d, got, ref)
+    # the same rows without the symbolic cursor kernel: bit window in three pieces
+    got2, st2 = spgemm_subprocess(A, {"NSPARSE_SYM_CURSOR": "0"}, B=B)
+    assert st2["sym"][10] == m
+    assert_parity(oracle_d, got2, ref)
 
 
 def test_wide_windows_take_the_window_bins(lib_d, oracle_d):
