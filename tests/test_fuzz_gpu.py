@@ -1,0 +1,45 @@
+"""Randomised parity sweep through the C-ABI: many small A (M x K) * B (K x N) of mixed shape,
+density and row-length distribution against the CPU oracle -- structure exact, values to the
+reference tolerance.  Catches the corners the targeted tests do not name (empty rows / columns,
+1 x N, N x 1, hub rows next to empty ones, every mix of bins in one call)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from gpu_util import spgemm
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_csr(rng, m, n, kind):
+    if kind == 0:      # uniform density
+        d = rng.choice([0.0, 0.002, 0.01, 0.05, 0.3])
+        a = sp.random(m, n, density=d, format="csr", random_state=rng, dtype=np.float64)
+    elif kind == 1:    # power-law row lengths, hub columns
+        lens = np.minimum((rng.pareto(1.2, m) * 2).astype(np.int64), n)
+        rows = np.repeat(np.arange(m), lens)
+        cols = np.minimum((rng.pareto(0.8, rows.size) * 3).astype(np.int64), n - 1)
+        a = sp.csr_matrix((rng.random(rows.size) + 0.1, (rows, cols)), shape=(m, n))
+        a.sum_duplicates()
+    else:              # banded
+        bw = int(rng.integers(1, 40))
+        offs = [o for o in range(-bw, bw + 1) if -m < o < n]
+        diags = [rng.random(max(m, n)) + 0.1 for _ in offs]
+        a = sp.diags(diags, offs, shape=(m, n), format="csr")
+    a.sort_indices()
+    return dict(M=m, N=n, rpt=a.indptr.astype(np.int32), col=a.indices.astype(np.int32),
+                val=a.data.astype(np.float64))
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_products(seed, lib_d, oracle_d):
+    rng = np.random.default_rng(1000 + seed)
+    m, k, n = (int(rng.choice([1, 2, 7, 63, 64, 65, 300, 1500, 4000, 20000])) for _ in range(3))
+    A = _rand_csr(rng, m, k, int(rng.integers(0, 3)))
+    B = _rand_csr(rng, k, n, int(rng.integers(0, 3)))
+    ref = oracle_d.spgemm(A, B)
+    got, st = spgemm(lib_d, A, B)
+    assert got["nnz"] == ref["nnz"]
+    assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
+    assert oracle_d.check_spgemm(got, ref) == 0
+    assert sum(st.sym_bin_size) == m and sum(st.num_bin_size) == m
