@@ -134,6 +134,36 @@ __device__ __forceinline__ void bitonic_stages_reg(int &r0, int &r1, int e0, int
     if constexpr (J > 1) bitonic_stages_reg<J / 2>(r0, r1, e0, k, lane);
 }
 
+// The same for big sorts: 512 elements per wavefront, eight consecutive ones per lane
+// (element = seg*512 + lane*8 + i).  Distances 4, 2, 1 are inside the thread, 8 ... 256 are lane
+// exchanges (lane ^ J/8): only distances of 512 and more cross wavefronts.
+template <int J>
+__device__ __forceinline__ void bitonic_stages_reg8(int (&r)[8], int ebase, int k, int lane)
+{
+    if constexpr (J >= 8) {
+        constexpr int L = J / 8;
+        const bool lower = (lane & L) == 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int q = lane_xor<L>(r[i]);
+            const bool mn = lower == (((ebase + i) & k) == 0);
+            r[i] = mn ? (r[i] < q ? r[i] : q) : (r[i] < q ? q : r[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if ((i & J) == 0) {
+                const bool up = ((ebase + i) & k) == 0;
+                const int a = r[i], b = r[i | J];
+                const int lo = a < b ? a : b, hi = a < b ? b : a;
+                r[i] = up ? lo : hi;
+                r[i | J] = up ? hi : lo;
+            }
+        }
+    }
+    if constexpr (J > 1) bitonic_stages_reg8<J / 2>(r, ebase, k, lane);
+}
+
 // In-LDS bitonic sort of P (power of two) ints, ascending.  Stages whose partner distance is below
 // 128 stay inside one wavefront's 128-element segment: the segment is taken into registers (two
 // elements per lane), the stages run on lane exchanges, and it is written back -- the first
@@ -153,6 +183,47 @@ __device__ __forceinline__ void bitonic_sort_lds(int *s, int P)
         const bool up = (i & k) == 0;
         if ((a > b) == up) { s[i] = b; s[p] = a; }
     };
+    if (P >= 1024) {  // big sorts: 512-element register segments, LDS only for distances >= 512
+        auto load8 = [&](int ebase, int(&r)[8]) {
+            const int4 a = *reinterpret_cast<const int4 *>(s + ebase), b = *reinterpret_cast<const int4 *>(s + ebase + 4);
+            r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
+        };
+        auto store8 = [&](int ebase, const int(&r)[8]) {
+            *reinterpret_cast<int4 *>(s + ebase) = make_int4(r[0], r[1], r[2], r[3]);
+            *reinterpret_cast<int4 *>(s + ebase + 4) = make_int4(r[4], r[5], r[6], r[7]);
+        };
+        for (int seg = wid; seg * 512 < P; seg += NW) {
+            const int ebase = seg * 512 + lane * 8;
+            int r[8];
+            load8(ebase, r);
+            bitonic_stages_reg8<1>(r, ebase, 2, lane);
+            bitonic_stages_reg8<2>(r, ebase, 4, lane);
+            bitonic_stages_reg8<4>(r, ebase, 8, lane);
+            bitonic_stages_reg8<8>(r, ebase, 16, lane);
+            bitonic_stages_reg8<16>(r, ebase, 32, lane);
+            bitonic_stages_reg8<32>(r, ebase, 64, lane);
+            bitonic_stages_reg8<64>(r, ebase, 128, lane);
+            bitonic_stages_reg8<128>(r, ebase, 256, lane);
+            bitonic_stages_reg8<256>(r, ebase, 512, lane);
+            store8(ebase, r);
+        }
+        __syncthreads();
+        for (int k = 1024; k <= P; k <<= 1) {
+            for (int j = k >> 1; j >= 512; j >>= 1) {
+                for (int t = threadIdx.x; t < P / 2; t += BS) cex(t, j, k);
+                __syncthreads();
+            }
+            for (int seg = wid; seg * 512 < P; seg += NW) {
+                const int ebase = seg * 512 + lane * 8;
+                int r[8];
+                load8(ebase, r);
+                bitonic_stages_reg8<256>(r, ebase, k, lane);
+                store8(ebase, r);
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // phase 1: every merge size up to 128 stays inside a 128-element segment
     for (int seg = wid; seg * 128 < P; seg += NW) {
         const int e0 = seg * 128 + lane;
