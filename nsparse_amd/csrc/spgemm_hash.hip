@@ -318,7 +318,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     if (tune_d8 == 256) { NSP_SYM_DENSE(8, 256, 65536) } else if (tune_d8 == 512) { NSP_SYM_DENSE(8, 512, 65536) } else { NSP_SYM_DENSE(8, 1024, 65536) }
     static const int tune_d7 = getenv("NSPARSE_SYMD7_BS") ? atoi(getenv("NSPARSE_SYMD7_BS")) : 256;
     if (tune_d7 == 128) { NSP_SYM_DENSE(7, 128, 16384) } else if (tune_d7 == 256) { NSP_SYM_DENSE(7, 256, 16384) } else { NSP_SYM_DENSE(7, 512, 16384) }
-    if (tune_d6 == 128) { NSP_SYM_DENSE(6, 128, 4096) } else if (tune_d6 == 512) { NSP_SYM_DENSE(6, 512, 4096) } else { NSP_SYM_DENSE(6, 256, 4096) }
+    if (tune_d6 == 128) { NSP_SYM_DENSE(6, 128, 4096) } else if (tune_d6 == 64) { NSP_SYM_DENSE(6, 64, 4096) } else if (tune_d6 == 512) { NSP_SYM_DENSE(6, 512, 4096) } else { NSP_SYM_DENSE(6, 256, 4096) }
     static const int tune_s3 = getenv("NSPARSE_SYM3_BS") ? atoi(getenv("NSPARSE_SYM3_BS")) : 512;
     static const int tune_s2 = getenv("NSPARSE_SYM2_BS") ? atoi(getenv("NSPARSE_SYM2_BS")) : 128;
     NSP_SYM_TB(4, 1024, 32768)
