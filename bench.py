@@ -234,10 +234,10 @@ def main():
                           "frac": round(traffic / (bin_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                          if traffic and bin_ms[dom] > 0 else None),
         # what actually limits a window-bin kernel: one LDS fp64 atomic per product, at the rate the SQ
-        # counters show on gfx950 (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS: ~2.8 lanes per clock per CU)
-        "lds_atomic_ceiling": ({"lanes_per_clk_per_cu": 2.8, "cus": 256, "clock_ghz": 2.4,
-                                "floor_ms": round(prods_bin[dom] / (2.8 * 256 * 2.4e9) * 1e3, 4),
-                                "frac": round(prods_bin[dom] / (2.8 * 256 * 2.4e9) * 1e3 / bin_ms[dom], 4)}
+        # counters show on gfx950 (SQ_LDS_IDX_ACTIVE / SQ_INSTS_LDS: ~1.9 lanes per clock per CU)
+        "lds_atomic_ceiling": ({"lanes_per_clk_per_cu": 1.94, "cus": 256, "clock_ghz": 2.4,
+                                "floor_ms": round(prods_bin[dom] / (1.94 * 256 * 2.4e9) * 1e3, 4),
+                                "frac": round(prods_bin[dom] / (1.94 * 256 * 2.4e9) * 1e3 / bin_ms[dom], 4)}
                                if dom >= 6 and bin_ms[dom] > 0 else None),
         "whole_call": {"bytes_model": int(b_spgemm),
                        "achieved": round(b_spgemm / (ms_per_step * 1e-3) / 1e9, 1),
