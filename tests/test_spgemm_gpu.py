@@ -225,6 +225,16 @@ def test_workspace_cache_off_is_identical(lib_d, oracle_d):
     assert np.array_equal(a["col"], b["col"]) and np.array_equal(a["rpt"], b["rpt"])
 
 
+def test_full_size_cant_class_fp32(lib_s, oracle_s):
+    """The same matrix through the float build: structure exact, values to the reference's 1e-6
+    (the LDS accumulators are double in this build too, so the sums are the better-rounded side)."""
+    A = synth(lib_s, 0, 9, 9, 257, seed=0x5EED0022)
+    got, st = spgemm(lib_s, A)
+    ref = oracle_s.spgemm(A, A)
+    assert st.num_bin_size[6] == A["M"]
+    assert_parity(oracle_s, got, ref)
+
+
 def test_full_size_cant_class_properties(lib_d, oracle_d):
     """BASELINE config 2 size (62,451 rows, ~4.3 M nnz, ~0.3 G products).  Oracle parity on the
     full matrix (the C oracle needs ~1 s) plus size-independent properties: ascending columns,
