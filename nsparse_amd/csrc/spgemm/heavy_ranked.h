@@ -65,8 +65,8 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
     __shared__ __attribute__((aligned(16))) acc_t vals[SYM ? 8 : CAP];
     __shared__ int4 l_meta[LCAP];
     __shared__ real l_av[LCAP];
-    __shared__ int s_row, s_nlong, s_cut, s_ntile, s_total;
-    __shared__ int s_wsum[WPT * NW];
+    __shared__ int s_row, s_nlong, s_cut, s_ntile;
+    __shared__ int s_wsum[NW];
     int *st_cur = slab + (long long)blockIdx.x * stride_ints;
     int *st_end = st_cur + amax;
     int *st_next = st_end + amax;
@@ -317,52 +317,56 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             walk(std::false_type{}, t_max);
             lds_barrier();
             tick(t_lo == lo ? 7 : 1);
-            // ---- scan: thread t owns words t, t + BS, ..., t + (WPT-1) BS -----------------------
-            // (strided, so that the dense low-column stretch of a power-law row is shared by many
-            // threads when the columns are written out)
+            // ---- scan: thread t scans its WPT consecutive words (one wave scan, one barrier); the
+            // columns are written out below with strided ownership (thread t: words t, t + BS, ...),
+            // which shares the dense low-column stretch of a power-law row among many threads.
+            // (Strided ownership in the scan as well costs a wave scan per word slot: R-MAT-22 +3 %;
+            //  consecutive ownership in the emission costs balance: +5 %.)
+            auto widx = [&](int j) { return (int)threadIdx.x * WPT + j; };
             unsigned int wd[WPT];
             int pc[WPT];  // becomes the exclusive prefix of the word
+            int total;
+            int tsum = 0;
+            static_assert(WPT % 4 == 0, "vector loads of the thread's words");
+#pragma unroll
+            for (int j = 0; j < WPT; j += 4) {
+                const uint4 q = reinterpret_cast<const uint4*>(bits)[(threadIdx.x * WPT + j) >> 2];
+                wd[j] = q.x, wd[j + 1] = q.y, wd[j + 2] = q.z, wd[j + 3] = q.w;
+            }
 #pragma unroll
             for (int j = 0; j < WPT; j++) {
-                wd[j] = bits[threadIdx.x + j * BS];
-                const int c = __popc(wd[j]);
-                const int incl = wave_incl_scan(c);
-                pc[j] = incl - c;
-                if (lane == 63) s_wsum[j * NW + w] = incl;
+                pc[j] = tsum;
+                tsum += __popc(wd[j]);
             }
+            const int incl = wave_incl_scan(tsum);
+            if (lane == 63) s_wsum[w] = incl;
             if (threadIdx.x == 0) s_cut = t_max;
             lds_barrier();
-            if (w == 0) {  // WPT * NW partial sums in (segment, wavefront) order -> exclusive offsets
-                constexpr int NP = WPT * NW, PPL = (NP + 63) / 64;  // partial sums per lane
-                int a[PPL], sum = 0;
+            int base = incl - tsum;
+            total = 0;
 #pragma unroll
-                for (int u = 0; u < PPL; u++) {
-                    const int i = PPL * lane + u;
-                    a[u] = i < NP ? s_wsum[i] : 0;
-                    sum += a[u];
-                }
-                int run = wave_incl_scan(sum) - sum;
-#pragma unroll
-                for (int u = 0; u < PPL; u++) {
-                    const int i = PPL * lane + u;
-                    if (i < NP) s_wsum[i] = run;
-                    run += a[u];
-                }
-                if (lane == 63) s_total = run;
+            for (int u = 0; u < NW; u++) {
+                const int c = s_wsum[u];
+                base += u < w ? c : 0;
+                total += c;
             }
-            lds_barrier();
-            const int total = s_total;
 #pragma unroll
-            for (int j = 0; j < WPT; j++) {
-                pc[j] += s_wsum[j * NW + w];
-                pref[threadIdx.x + j * BS] = (unsigned short)pc[j];
+            for (int j = 0; j < WPT; j++) pc[j] += base;
+#pragma unroll
+            for (int j = 0; j < WPT; j += 8) {
+                uint4 q;
+                // (prefixes past the cut may exceed 16 bits: they are never read, but must not spill
+                //  into their neighbour)
+                q.x = (pc[j] & 0xffff) | (pc[j + 1] << 16), q.y = (pc[j + 2] & 0xffff) | (pc[j + 3] << 16);
+                q.z = (pc[j + 4] & 0xffff) | (pc[j + 5] << 16), q.w = (pc[j + 6] & 0xffff) | (pc[j + 7] << 16);
+                reinterpret_cast<uint4*>(pref)[(threadIdx.x * WPT + j) >> 3] = q;
             }
             if (total > CAP) {  // cut at the word where the running count would pass CAP
 #pragma unroll
                 for (int j = 0; j < WPT; j++) {
                     const int p1 = pc[j] + __popc(wd[j]);
                     if (pc[j] <= CAP && p1 > CAP) {
-                        s_cut = t_lo + 32 * (threadIdx.x + j * BS);
+                        s_cut = t_lo + 32 * widx(j);
                         s_ntile = pc[j];
                     }
                 }

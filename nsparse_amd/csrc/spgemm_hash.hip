@@ -433,7 +433,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         if (ranked_dens != 0) {
             constexpr int kRankCap = 10240;
             // Matrices wider than 2^20 columns take tiles of 2^19 columns with a smaller value array:
-            // their thin rows are bound by the number of tiles (R-MAT-22: 116 -> 110 ms), while on
+            // their thin rows are bound by the number of tiles (R-MAT-22: -5 %), while on
             // narrower matrices the smaller array costs cuts (R-MAT-18: +4 %).  NSPARSE_RANKED_SEL=0/1 forces.
             static const int ranked_env = getenv("NSPARSE_RANKED_SEL") ? atoi(getenv("NSPARSE_RANKED_SEL")) : -1;
             const int ranked_sel = ranked_env >= 0 ? ranked_env : (b->N > (1 << 20) ? 1 : 0);
