@@ -230,7 +230,8 @@ typedef struct {
     long long nnz_c;          /* 64-bit: reported even when it does not fit sfCSR's int (error -40) */
     int max_prod_row;         /* longest row of intermediate products               */
     int max_nnz_row;          /* longest row of C                                   */
-    int sym_bin_size[12];     /* rows per symbolic bin (0 tiny, 1-5 hash, 6-8 dense window, 9-10 bit window) */
+    int sym_bin_size[12];     /* rows per symbolic bin (0 tiny, 1-5 hash, 6-8 dense window, 9-10 bit window);
+                               * twin rows (below) are in none                        */
     int num_bin_size[12];     /* rows per numeric bin                               */
     int sym_fail_rows;        /* rows that overflowed LDS and went to the global table */
     float ms_setup;           /* products + binning              (HIP events)       */
@@ -239,6 +240,8 @@ typedef struct {
     float ms_total;           /* whole call                                         */
     float ms_sym_bin[12];      /* per-bin kernel time, HIP events on the bin's own stream */
     float ms_num_bin[12];
+    int twin_rows;            /* rows with the column pattern of the row before them: not in the
+                               * symbolic bins, they take that row's structure               */
 } nsparse_spgemm_stats;
 void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out);
 

@@ -48,7 +48,7 @@ class SpgemmStats(C.Structure):
                 ("max_nnz_row", C.c_int), ("sym_bin_size", C.c_int * 12), ("num_bin_size", C.c_int * 12),
                 ("sym_fail_rows", C.c_int), ("ms_setup", C.c_float), ("ms_symbolic", C.c_float),
                 ("ms_numeric", C.c_float), ("ms_total", C.c_float), ("ms_sym_bin", C.c_float * 12),
-                ("ms_num_bin", C.c_float * 12)]
+                ("ms_num_bin", C.c_float * 12), ("twin_rows", C.c_int)]
 
 
 # every entry point declared in include/nsparse.h: name -> (restype, argtypes)

@@ -172,10 +172,15 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
                                                       int *__restrict__ row_nz,
                                                       int *__restrict__ row_maxb,
                                                       int *__restrict__ long_list, int *long_cnt,
-                                                      int long_len, const int *__restrict__ todo)
+                                                      int long_len, const int *__restrict__ todo,
+                                                      unsigned char *__restrict__ twin)
 {
     // todo == nullptr: bulk pass, rows of A longer than long_len are deferred to long_list;
     // todo != nullptr: the deferred rows (see kLongFactor)
+    // twin != nullptr: twin[row] = 1 when the row has the column pattern of the row before it (the
+    // degrees of freedom of one node of a finite-element mesh).  Its row of C then has the structure
+    // of that row's: it is left out of the symbolic bins and k_twin_copy hands it the result.  Every
+    // kTwinRun-th row is kept, so a run of twins is at most kTwinRun - 1 rows long.
     const int nrows = todo ? (*long_cnt < kLongCap ? *long_cnt : kLongCap) : M;
     if (!todo && blockIdx.x == 0 && threadIdx.x == 0) {  // scan tails (instead of two memset launches)
         bm_words[M] = 0;
@@ -210,14 +215,26 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             }
             if (__shfl(ok, 0, W) != 0) row = M;  // deferred: nothing to do for this group now
         }
+        int differs = 1;  // from the row before
         if (row < M) {
             const int e = arpt[row + 1];
+            const int len = e - arpt[row];
+            // candidate twin: same length as the row before, which then ends where this one starts
+            // (and the same first column: rows of equal length that are NOT twins -- a stencil -- then skip
+            //  the comparison of the other entries)
+            const bool cand = twin && !todo && len > 0 && row % kTwinRun != 0 && arpt[row] - arpt[row - 1] == len &&
+                              acol[arpt[row]] == acol[arpt[row] - len];
+            differs = cand ? 0 : 1;
             int j = arpt[row] + lane;
             for (; j + 3 * W < e; j += 4 * W) {  // four independent gathers in flight
                 int c[4];
                 BInfo bi[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) c[u] = __builtin_nontemporal_load(acol + j + u * W);
+                if (cand) {
+#pragma unroll
+                    for (int u = 0; u < 4; u++) differs |= acol[j + u * W - len] != c[u];
+                }
 #pragma unroll
                 for (int u = 0; u < 4; u++) bi[u] = binfo[c[u]];
 #pragma unroll
@@ -230,6 +247,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             }
             for (; j < e; j += W) {
                 const int c = __builtin_nontemporal_load(acol + j);
+                if (cand) differs |= acol[j - len] != c;
                 const BInfo bi = binfo[c];
                 n += bi.len;
                 mb = bi.len > mb ? bi.len : mb;
@@ -241,6 +259,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
         for (int o = W / 2; o >= 1; o >>= 1) {
             n += __shfl_xor(n, o);
             const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o), m2 = __shfl_xor(mb, o);
+            differs |= __shfl_xor(differs, o);
             lo = l < lo ? l : lo;
             hi = h > hi ? h : hi;
             mb = m2 > mb ? m2 : mb;
@@ -255,13 +274,15 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             row_span[row] = span;
             row_maxb[row] = mb;
             // words of the column bitmap the symbolic dense kernel hands to the numeric one
-            const int bw = (span > 0 && span <= bm_span_max) ? (span + 31) >> 5 : 0;
+            const bool is_twin = differs == 0;
+            if (twin) twin[row] = is_twin ? 1 : 0;  // (deferred long rows: never twins)
+            const int bw = (span > 0 && span <= bm_span_max && !is_twin) ? (span + 31) >> 5 : 0;  // twins share
             bm_words[row] = bw;
             row_span_num[row] = 0;  // set by k_sym_dense when it hands a bitmap over
-            bin = bin_of(ni, span, thr, ni);
+            bin = is_twin ? -1 : bin_of(ni, span, thr, ni);
             const int al = arpt[row + 1] - arpt[row];
             if (W >= 16) {  // at most 4 rows per wave: direct LDS atomics are cheapest
-                atomicAdd(&s_hist[bin], 1);
+                if (bin >= 0) atomicAdd(&s_hist[bin], 1);
                 atomicMax(&s_max, ni);
                 atomicMax(&s_alen, al);
                 atomicAdd(&s_total, (unsigned long long)n);
@@ -362,6 +383,20 @@ __global__ __launch_bounds__(64) void k_publish(const BinState *__restrict__ src
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Rows left out of the symbolic bins as twins take the result of the row they repeat.
+__global__ __launch_bounds__(256) void k_twin_copy(const unsigned char *__restrict__ twin, int M,
+                                                   int *__restrict__ row_nz, int *__restrict__ row_span_num,
+                                                   int *__restrict__ bm_off)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= M || !twin[r]) return;
+    int l = r - 1;
+    while (l > 0 && twin[l]) l--;  // at most kTwinRun - 2 steps; row 0 is never a twin
+    row_nz[r] = row_nz[l];
+    row_span_num[r] = row_span_num[l];
+    if (bm_off) bm_off[r] = bm_off[l];
+}
+
 // histogram of an existing per-row count (numeric binning, set_min_bin :201-246)
 __global__ __launch_bounds__(1024) void k_hist(const int *__restrict__ n, const int *__restrict__ span,
                                               const int *__restrict__ work, int M, Thr thr, BinState *bs)
@@ -419,7 +454,8 @@ __global__ __launch_bounds__(256) void k_row_len(const int *__restrict__ rpt, in
 __global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
                                                      const int *__restrict__ span,
                                                      const int *__restrict__ work, int M, Thr thr,
-                                                     BinState *bs, int *__restrict__ perm)
+                                                     BinState *bs, int *__restrict__ perm,
+                                                     const unsigned char *__restrict__ skip)
 {
     __shared__ int s_cnt[NB];
     __shared__ int s_base[NB];
@@ -431,7 +467,8 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
     __syncthreads();
     const int i = blockIdx.x * 1024 + threadIdx.x;
     int b = -1, r = 0;
-    if (i < M) {
+    const bool in = i < M && !(skip && skip[i]);  // skip: twin rows (symbolic phase)
+    if (in) {
         const int ni = n[i];
         b = bin_of(ni, span[i], thr, work ? work[i] : ni);
         if (b >= kDenseBin0) atomicMax(&s_span[b], span[i]);  // window bins only
@@ -459,7 +496,7 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
         if (s_span[threadIdx.x]) atomicMax(&bs->max_span[threadIdx.x], s_span[threadIdx.x]);
     }
     __syncthreads();
-    if (i < M) perm[s_base[b] + r] = i;
+    if (in) perm[s_base[b] + r] = i;
 }
 
 }  // namespace spgemm

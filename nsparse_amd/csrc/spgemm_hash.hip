@@ -97,7 +97,7 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *bin
                                 int *row_prod, int *row_lo, int *row_span, int *bm_words,
                                 int bm_span_max, const Thr &thr, BinState *d_bs, long long *partial,
                                 int *row_span_num, int *row_nz, int *row_maxb, int *long_list,
-                                int *long_cnt, hipStream_t st)
+                                int *long_cnt, unsigned char *twin, hipStream_t st)
 {
     const int M = a->M;
     const int w = pick_w(a->nnz, M);
@@ -112,7 +112,7 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *bin
         hipLaunchKernelGGL(k_row_products<W>, dim3(grid), dim3(256), 0, st, a->d_rpt, a->d_col, \
                            binfo, M, row_prod, row_lo, row_span, bm_words, bm_span_max, thr,   \
                            partial, row_span_num, row_nz, row_maxb, long_list, long_cnt,       \
-                           kLongFactor * W, no_todo);                                          \
+                           kLongFactor * W, no_todo, twin);                                    \
         break;
     switch (w) {
         NSP_RP(1) NSP_RP(2) NSP_RP(4) NSP_RP(8) NSP_RP(16) NSP_RP(32) NSP_RP(64)
@@ -123,7 +123,7 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *bin
         hipLaunchKernelGGL(k_row_products<64>, dim3(256), dim3(256), 0, st, a->d_rpt, a->d_col, binfo, M,
                            row_prod, row_lo, row_span, bm_words, bm_span_max, thr,
                            partial + (long long)grid * kPartialStride, row_span_num, row_nz, row_maxb,
-                           (int *)nullptr, long_cnt, 0, (const int *)long_list);
+                           (int *)nullptr, long_cnt, 0, (const int *)long_list, twin);
         grid += 256;
     }
     hipLaunchKernelGGL(k_reduce_partials, dim3(grid < 32 ? grid : 32), dim3(256), 0, st, partial, grid, d_bs);
@@ -640,14 +640,18 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     int *bm_off = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_span_num = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
+    // rows that repeat the column pattern of the row before them are not run through the symbolic
+    // phase: they take that row's result (k_twin_copy).  NSPARSE_TWINS=0 switches the detection off.
+    static const bool twins_on = !(getenv("NSPARSE_TWINS") && atoi(getenv("NSPARSE_TWINS")) == 0);
+    unsigned char *twin = (!numeric_only && twins_on && M > 1) ? (unsigned char *)dev_alloc((size_t)M) : nullptr;
     launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
-                        use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, s0);
+                        use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, twin, s0);
     void *bm_scan_tmp = nullptr;
     if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
     const int grid_m = ceil_div(M, 1024);
     if (!numeric_only) {
         hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_prod, row_span, (const int *)nullptr, M,
-                           sym_thr, d_sym, row_perm);
+                           sym_thr, d_sym, row_perm, (const unsigned char *)twin);
         NSP_LAUNCH_CHECK();
     }
     {
@@ -676,6 +680,16 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
                                         bm_off, bm, row_span_num, h_sym->max_span, (int)h_sym->max_alen,
                                         h_sym->b_unsorted == 0);
         sym_used = LS;
+        {
+            long long binned = 0;
+            for (int q = 0; q < NB; q++) binned += h_sym->hist[q];
+            S.twin_rows = twin ? (int)(M - binned) : 0;
+            if (S.twin_rows > 0) {
+                hipLaunchKernelGGL(k_twin_copy, dim3(ceil_div(M, 256)), dim3(256), 0, s0, (const unsigned char *)twin, M,
+                                   row_nz, row_span_num, bm ? bm_off : (int *)nullptr);
+                NSP_LAUNCH_CHECK();
+            }
+        }
         c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
         scan_tmp = scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
     } else {
@@ -693,7 +707,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, (const int *)row_prod, M, num_thr,
                        d_num);
     hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, (const int *)row_prod, M,
-                       num_thr, d_num, row_perm);
+                       num_thr, d_num, row_perm, (const unsigned char *)nullptr);
     NSP_LAUNCH_CHECK();
     {
         const int seq = ++cx.seq;
@@ -747,6 +761,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     dev_free(scan_tmp);
     dev_free(bm);
     dev_free(bm_scan_tmp);
+    if (twin) dev_free(twin);
     dev_free(row_span_num);
     dev_free(bm_off);
     dev_free(bm_words);

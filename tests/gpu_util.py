@@ -115,6 +115,23 @@ def row_windows(A, B):
     return prod, span
 
 
+TWIN_RUN = 64  # kTwinRun in csrc/spgemm/common.h
+
+
+def twin_rows(A):
+    """Rows of A with the column pattern of the row before them (k_row_products): they are left out
+    of the symbolic bins and take that row's structure.  Every TWIN_RUN-th row is kept."""
+    rpt = np.asarray(A["rpt"], dtype=np.int64)
+    col = np.asarray(A["col"])
+    M = len(rpt) - 1
+    tw = np.zeros(M, dtype=bool)
+    ln = np.diff(rpt)
+    for r in range(1, M):
+        if r % TWIN_RUN and ln[r] > 0 and ln[r] == ln[r - 1]:
+            tw[r] = np.array_equal(col[rpt[r]:rpt[r + 1]], col[rpt[r - 1]:rpt[r]])
+    return tw
+
+
 def bins_of(n, span, ladder, work=None):
     """numpy twin of bin_of() in csrc/spgemm/common.h; ladder = 15 ints from nsparse_get_spgemm_bins.
     work = products of the row (numeric phase; the symbolic phase bins by the products themselves)."""

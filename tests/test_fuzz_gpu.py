@@ -42,4 +42,4 @@ def test_random_products(seed, lib_d, oracle_d):
     assert got["nnz"] == ref["nnz"]
     assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
     assert oracle_d.check_spgemm(got, ref) == 0
-    assert sum(st.sym_bin_size) == m and sum(st.num_bin_size) == m
+    assert sum(st.sym_bin_size) + st.twin_rows == m and sum(st.num_bin_size) == m
