@@ -350,3 +350,45 @@ def test_wide_windows_take_the_window_bins(lib_d, oracle_d):
     assert st.num_bin_size[7] + st.num_bin_size[8] > 0.8 * A["M"]
     np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-12)  # numeric-only re-run, MODE 2
     assert np.array_equal(got["col_again"], got["col"])
+
+
+@pytest.mark.parametrize("prec", ["d", "s"])
+def test_twin_rows_take_their_leaders_structure(prec, lib_d, lib_s, oracle_d, oracle_s):
+    """Rows of A that repeat the column pattern of the row before them (different values) are left out
+    of the symbolic bins.  Runs of every length (a run of 150 is cut by the kept rows at multiples of
+    64), patterns of 1 .. 1500 entries (tiny, hash and window bins, a deferred long row), a run that
+    starts at row 0, look-alikes that differ in one entry, empty rows, and NSPARSE_TWINS=0 for the
+    same answer; the numeric-only re-run must keep working on the shared structure."""
+    lib, orc = (lib_d, oracle_d) if prec == "d" else (lib_s, oracle_s)
+    rng = np.random.default_rng(2024)
+    k = 6000
+    pats = []
+    for run, ln in [(3, 30), (150, 12), (1, 7), (5, 1), (4, 400), (2, 1500), (3, 0), (70, 64), (6, 3)]:
+        cols = np.sort(rng.choice(k, size=ln, replace=False)).astype(np.int32)
+        pats += [cols] * run
+        if ln > 1:  # a look-alike: same length, last entry differs
+            alt = cols.copy()
+            alt[-1] = alt[-1] + 1 if alt[-1] + 1 < k and (ln < 2 or alt[-1] + 1 != alt[-2]) else alt[-1]
+            pats.append(alt)
+    m = len(pats)
+    rpt = np.zeros(m + 1, dtype=np.int32)
+    rpt[1:] = np.cumsum([len(p) for p in pats])
+    col = np.concatenate(pats).astype(np.int32)
+    val = rng.uniform(0.5, 1.5, size=len(col))
+    A = dict(M=m, N=k, rpt=rpt, col=col, val=val.astype(lib.real))
+    import scipy.sparse as sp
+    b = sp.random(k, 9000, density=8 / 9000, format="csr", random_state=rng, dtype=np.float64)
+    b.sort_indices()
+    B = dict(M=k, N=9000, rpt=b.indptr.astype(np.int32), col=b.indices.astype(np.int32),
+             val=(b.data + 0.5).astype(lib.real))
+    ref = orc.spgemm(A, B)
+    got, st = spgemm(lib, A, B, numeric_again=True)
+    tw = twin_rows(A)
+    assert st.twin_rows == int(tw.sum()) and st.twin_rows > 200
+    assert sum(st.sym_bin_size) + st.twin_rows == m and sum(st.num_bin_size) == m
+    assert_parity(orc, got, ref)
+    assert np.array_equal(got["col_again"], got["col"])
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9 if prec == "d" else 2e-5)
+    got0, st0 = spgemm_subprocess(A, {"NSPARSE_TWINS": "0"}, prec=prec, B=B)
+    assert sum(st0["sym"]) == m
+    assert np.array_equal(got0["rpt"], got["rpt"]) and np.array_equal(got0["col"], got["col"])
