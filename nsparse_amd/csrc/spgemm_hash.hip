@@ -172,13 +172,25 @@ struct BinLauncher {
     void *deferred[4] = {};  // scratch of kernels still in flight: returned to the cache by collect()
     int ndeferred = 0;
     void free_later(void *p) { deferred[ndeferred++] = p; }
-    BinLauncher(Context &c, int phase, const int *hist = nullptr)
+    int most_bin = -1;  // the bin with the most rows
+    // big_a, big_b: bins whose workgroups want a whole CU each (LDS).  When one of them has a few rows
+    // it takes the main stream and is launched first: on a side stream its launch waits for the fork
+    // event while the million small rows of the main bin already fill every CU, and the big
+    // workgroups then start only when that bin has drained (webbase class: symbolic phase 0.15 or
+    // 0.23 ms from one call to the next).
+    BinLauncher(Context &c, int phase, const int *hist = nullptr, int big_a = -1, int big_b = -1)
         : cx(&c), ev(c.ev_bin + phase * 2 * NB), serial(c.profiling), timed(c.profiling || c.bin_timing), main_bin(-1)
     {
+        static const bool big_main = !(getenv("NSPARSE_BIG_MAIN") && atoi(getenv("NSPARSE_BIG_MAIN")) == 0);
         if (hist) {
             int best = 0;
             for (int b = 0; b < NB; b++)
-                if (hist[b] > best) { best = hist[b]; main_bin = b; }
+                if (hist[b] > best) { best = hist[b]; most_bin = b; }
+            main_bin = most_bin;
+            // (a big bin with more rows than CUs keeps every CU for milliseconds anyway: R-MAT is 3 %
+            //  slower with it on the main stream)
+            if (big_main && big_a >= 0 && hist[big_a] > 0 && hist[big_a] <= 256) main_bin = big_a;
+            else if (big_main && big_b >= 0 && hist[big_b] > 0 && hist[big_b] <= 256) main_bin = big_b;
             for (int b = 0; b < NB; b++) side_bins |= hist[b] > 0 && b != main_bin;
         } else {
             side_bins = true;
@@ -281,7 +293,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
 {
     int hist[NB], off[NB + 1];
     fold_small_hash_bins(hist_in, hist, off);
-    BinLauncher L(cx, 0, hist);
+    BinLauncher L(cx, 0, hist, 10, 4);
     const int *arpt = a->d_rpt, *acol = a->d_col, *brpt = b->d_rpt, *bcol = b->d_col;
     *fail_rows = 0;
     int *fail_list = nullptr;
@@ -328,7 +340,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     for (int pass = 0; pass < 3; pass++) {
     auto now = [&](int bin) {
         const bool big = bin == 10 || bin == 4;
-        return bin == L.main_bin ? pass == 1 : (big ? pass == 0 : pass == 2);
+        return big ? pass == 0 : (bin == L.most_bin ? pass == 1 : pass == 2);
     };
     // bin 10 with windows wider than the 2^20-bit window and sorted rows of B: cursor kernel, every
     // product seen once (k_sym_bits would walk all products once per 2^20-column piece)
@@ -416,7 +428,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
 {
     int hist[NB], off[NB + 1];
     fold_small_hash_bins(hist_in, hist, off);
-    BinLauncher L(cx, 1, hist);
+    BinLauncher L(cx, 1, hist, kNumGlobalBin);
     const int *arpt = a->d_rpt, *acol = a->d_col, *brpt = b->d_rpt, *bcol = b->d_col;
     const real *aval = a->d_val, *bval = b->d_val;
     L.fork();
@@ -439,7 +451,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     for (int pass = 0; pass < 3; pass++) {
     auto now = [&](int bin) {
         const bool big = bin == kNumGlobalBin;  // persistent workgroups that own a CU's LDS
-        return bin == L.main_bin ? pass == 1 : (big ? pass == 0 : pass == 2);
+        return big ? pass == 0 : (bin == L.most_bin ? pass == 1 : pass == 2);
     };
     if (use_tiled && now(kNumGlobalBin)) {
         hipStream_t st = L.begin(kNumGlobalBin);
