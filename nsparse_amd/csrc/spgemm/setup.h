@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             // candidate twin: same length as the row before, which then ends where this one starts
             // (and the same first column: rows of equal length that are NOT twins -- a stencil -- then skip
             //  the comparison of the other entries)
-            const bool cand = twin && !todo && len > 0 && row % kTwinRun != 0 && arpt[row] - arpt[row - 1] == len &&
+            const bool cand = twin && len > 0 && row % kTwinRun != 0 && arpt[row] - arpt[row - 1] == len &&
                               acol[arpt[row]] == acol[arpt[row] - len];
             differs = cand ? 0 : 1;
             int j = arpt[row] + lane;
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             row_maxb[row] = mb;
             // words of the column bitmap the symbolic dense kernel hands to the numeric one
             const bool is_twin = differs == 0;
-            if (twin) twin[row] = is_twin ? 1 : 0;  // (deferred long rows: never twins)
+            if (twin) twin[row] = is_twin ? 1 : 0;
             const int bw = (span > 0 && span <= bm_span_max && !is_twin) ? (span + 31) >> 5 : 0;  // twins share
             bm_words[row] = bw;
             row_span_num[row] = 0;  // set by k_sym_dense when it hands a bitmap over
@@ -410,21 +410,28 @@ __global__ __launch_bounds__(1024) void k_hist(const int *__restrict__ n, const 
         s_sum = 0;
     }
     __syncthreads();
-    const int i = blockIdx.x * 1024 + threadIdx.x;  // 1024 rows per block: 4x fewer same-address
-    int bin = -1, v = 0;                             // global atomics at the end
-    if (i < M) {
-        v = n[i];
-        bin = bin_of(v, span[i], thr, work ? work[i] : v);
+    // grid-stride over the rows with a bounded grid: the global atomics at the end all go to a dozen
+    // addresses and serialise at ~20 ns each (a block per 1024 rows of a 1 M-row matrix: 26 us)
+    int v = 0;
+    unsigned long long sum = 0;
+    for (int i0 = blockIdx.x * 1024; i0 < M; i0 += gridDim.x * 1024) {
+        const int i = i0 + threadIdx.x;
+        int bin = -1;
+        if (i < M) {
+            const int vi = n[i];
+            bin = bin_of(vi, span[i], thr, work ? work[i] : vi);
+            v = vi > v ? vi : v;
+            sum += (unsigned long long)vi;
+        }
+        unsigned long long todo = __ballot(bin >= 0);
+        while (todo) {  // one LDS atomic per (wave, bin present in the wave)
+            const int leader = __ffsll((long long)todo) - 1;
+            const int b = __shfl(bin, leader);
+            const unsigned long long same = __ballot(bin == b);
+            if ((threadIdx.x & 63) == leader) atomicAdd(&s_hist[b], __popcll(same));
+            todo &= ~same;
+        }
     }
-    unsigned long long todo = __ballot(bin >= 0);
-    while (todo) {  // one LDS atomic per (wave, bin present in the wave)
-        const int leader = __ffsll((long long)todo) - 1;
-        const int b = __shfl(bin, leader);
-        const unsigned long long same = __ballot(bin == b);
-        if ((threadIdx.x & 63) == leader) atomicAdd(&s_hist[b], __popcll(same));
-        todo &= ~same;
-    }
-    unsigned long long sum = (unsigned long long)v;
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         const int m = __shfl_xor(v, o);

@@ -96,16 +96,22 @@ static inline int pick_w(long long nnz, int M)
 // would be deferred: a quarter of the average length, to the nearest power of two -- every lane then
 // runs the four-gathers-in-flight loop once or twice instead of one gather and a 6-step shuffle
 // reduction for one entry (k_row_products on the cant class: 52 -> 17 us with 16 lanes instead of
-// 64; 27-point stencil 8 instead of 32).  Skewed matrices keep a lane per average entry: their long
-// rows are what the width is for.
+// 64; 27-point stencil 8 instead of 32).
 static inline int pick_w_regular(long long nnz, int M, int nnz_max)
 {
-    const int w_avg = pick_w(nnz, M);
-    if (nnz_max <= 0 || M <= 0) return w_avg;
+    // long rows possible (or unknown): half the average, at least 2 lanes when rows average more than
+    // one entry -- the long rows go to the 64-lane pass anyway, and the short ones are bound by the
+    // dependent loads of a row, not by lanes (webbase class: k_row_products 75 -> 45 us with 2 lanes
+    // instead of 4)
+    const int w_full = pick_w(nnz, M), w_half = pick_w((nnz + 1) / 2, M);
+    const int w_two = w_full < 2 ? w_full : 2;
+    const int w_skew = w_half > w_two ? w_half : w_two;
+    if (nnz_max <= 0 || M <= 0) return w_skew;
+    // no row will be deferred: a quarter of the average, to the nearest power of two
     const double q = (double)nnz / M / 4.0;
     int w = 1;
     while (w < 64 && (double)w * 1.4142 < q) w <<= 1;
-    return nnz_max <= kLongFactor * w ? w : w_avg;
+    return nnz_max <= kLongFactor * w ? w : w_skew;
 }
 
 
@@ -753,8 +759,8 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
     const int *num_span = numeric_only ? row_span : row_span_num;
     if (!numeric_only && bm == nullptr) num_thr.dense_ratio = 0;
-    hipLaunchKernelGGL(k_hist, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, (const int *)row_prod, M, num_thr,
-                       d_num);
+    hipLaunchKernelGGL(k_hist, dim3(grid_m < 128 ? grid_m : 128), dim3(1024), 0, s0, row_nz, num_span,
+                       (const int *)row_prod, M, num_thr, d_num);
     hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, (const int *)row_prod, M,
                        num_thr, d_num, row_perm, (const unsigned char *)nullptr);
     NSP_LAUNCH_CHECK();
