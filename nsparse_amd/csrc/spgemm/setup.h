@@ -458,6 +458,10 @@ __global__ __launch_bounds__(256) void k_row_len(const int *__restrict__ rpt, in
 
 // rows grouped by bin (set_row_perm :125-154): one LDS pass ranks the rows of a block
 // inside their bin, one global atomic per (block, bin) reserves the range.
+// RPT rows per thread (1024 * RPT per workgroup): the cursor claims at the end are global atomics on
+// a dozen addresses, ~20 ns each one after the other -- a workgroup per 1024 rows of a 1 M-row matrix
+// spends 15 us there, a workgroup per 4096 rows 8.
+template <int RPT>
 __global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
                                                      const int *__restrict__ span,
                                                      const int *__restrict__ work, int M, Thr thr,
@@ -472,28 +476,34 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
         s_span[threadIdx.x] = 0;
     }
     __syncthreads();
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    int b = -1, r = 0;
-    const bool in = i < M && !(skip && skip[i]);  // skip: twin rows (symbolic phase)
-    if (in) {
-        const int ni = n[i];
-        b = bin_of(ni, span[i], thr, work ? work[i] : ni);
-        if (b >= kDenseBin0) atomicMax(&s_span[b], span[i]);  // window bins only
-    }
-    // rank inside the block: ballot + popcount inside the wave, one LDS atomic per (wave, bin)
-    unsigned long long todo = __ballot(b >= 0);
     const int lane = threadIdx.x & 63;
-    while (todo) {
-        const int leader = __ffsll((long long)todo) - 1;
-        const int bb = __shfl(b, leader);
-        const unsigned long long same = __ballot(b == bb);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&s_cnt[bb], __popcll(same));
-        base = __shfl(base, leader);
-        if (b == bb) r = base + __popcll(same & ((1ull << lane) - 1ull));
-        todo &= ~same;
+    int b[RPT], r[RPT];
+    bool in[RPT];
+#pragma unroll
+    for (int k = 0; k < RPT; k++) {
+        const int i = (blockIdx.x * RPT + k) * 1024 + threadIdx.x;
+        b[k] = -1;
+        r[k] = 0;
+        in[k] = i < M && !(skip && skip[i]);  // skip: twin rows (symbolic phase)
+        if (in[k]) {
+            const int ni = n[i];
+            b[k] = bin_of(ni, span[i], thr, work ? work[i] : ni);
+            if (b[k] >= kDenseBin0) atomicMax(&s_span[b[k]], span[i]);  // window bins only
+        }
+        // rank inside the block: ballot + popcount inside the wave, one LDS atomic per (wave, bin)
+        unsigned long long todo = __ballot(b[k] >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int bb = __shfl(b[k], leader);
+            const unsigned long long same = __ballot(b[k] == bb);
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&s_cnt[bb], __popcll(same));
+            base = __shfl(base, leader);
+            if (b[k] == bb) r[k] = base + __popcll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
+        }
+        if (b[k] < 0) b[k] = 0;
     }
-    if (b < 0) b = 0;
     __syncthreads();
     if (threadIdx.x < NB) {
         int off = 0;
@@ -503,7 +513,9 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
         if (s_span[threadIdx.x]) atomicMax(&bs->max_span[threadIdx.x], s_span[threadIdx.x]);
     }
     __syncthreads();
-    if (in) perm[s_base[b] + r] = i;
+#pragma unroll
+    for (int k = 0; k < RPT; k++)
+        if (in[k]) perm[s_base[b[k]] + r[k]] = (blockIdx.x * RPT + k) * 1024 + threadIdx.x;
 }
 
 }  // namespace spgemm

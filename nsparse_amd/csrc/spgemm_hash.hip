@@ -705,8 +705,12 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
     const int grid_m = ceil_div(M, 1024);
     if (!numeric_only) {
-        hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_prod, row_span, (const int *)nullptr, M,
-                           sym_thr, d_sym, row_perm, (const unsigned char *)twin);
+        if (M >= (1 << 18))
+            hipLaunchKernelGGL(k_bin_scatter<4>, dim3(ceil_div(M, 4096)), dim3(1024), 0, s0, row_prod, row_span,
+                               (const int *)nullptr, M, sym_thr, d_sym, row_perm, (const unsigned char *)twin);
+        else
+            hipLaunchKernelGGL(k_bin_scatter<1>, dim3(grid_m), dim3(1024), 0, s0, row_prod, row_span,
+                               (const int *)nullptr, M, sym_thr, d_sym, row_perm, (const unsigned char *)twin);
         NSP_LAUNCH_CHECK();
     }
     {
@@ -761,8 +765,12 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     if (!numeric_only && bm == nullptr) num_thr.dense_ratio = 0;
     hipLaunchKernelGGL(k_hist, dim3(grid_m < 128 ? grid_m : 128), dim3(1024), 0, s0, row_nz, num_span,
                        (const int *)row_prod, M, num_thr, d_num);
-    hipLaunchKernelGGL(k_bin_scatter, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span, (const int *)row_prod, M,
-                       num_thr, d_num, row_perm, (const unsigned char *)nullptr);
+    if (M >= (1 << 18))
+        hipLaunchKernelGGL(k_bin_scatter<4>, dim3(ceil_div(M, 4096)), dim3(1024), 0, s0, row_nz, num_span,
+                           (const int *)row_prod, M, num_thr, d_num, row_perm, (const unsigned char *)nullptr);
+    else
+        hipLaunchKernelGGL(k_bin_scatter<1>, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span,
+                           (const int *)row_prod, M, num_thr, d_num, row_perm, (const unsigned char *)nullptr);
     NSP_LAUNCH_CHECK();
     {
         const int seq = ++cx.seq;
