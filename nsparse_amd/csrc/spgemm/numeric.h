@@ -30,11 +30,17 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
     // values in `real` here (not acc_t): a row has a handful of products, so the slow fp32 LDS atomic
     // does not show, while 4 bytes less per slot is two more workgroups per CU in the float build
     __shared__ real vals[RPB * TROW];
-    for (int i = threadIdx.x; i < RPB * TROW; i += BS) {
-        keys[i] = -1;
-        vals[i] = 0;
+    // every wavefront clears and uses only the slots of its own 64 / LPR rows: no workgroup barrier,
+    // so a wavefront does not wait for the slowest row of the other three
+    {
+        constexpr int WSLOTS = 64 / LPR * TROW;
+        const int w0 = (threadIdx.x >> 6) * WSLOTS;
+        for (int i = threadIdx.x & 63; i < WSLOTS; i += 64) {
+            keys[w0 + i] = -1;
+            vals[w0 + i] = 0;
+        }
     }
-    __syncthreads();
+    wave_lds_sync();
     const int lrow = threadIdx.x / LPR;
     const int sub = threadIdx.x % LPR;
     const int q = blockIdx.x * RPB + lrow;
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
             }
         }
     }
-    __syncthreads();  // uniform: every thread reaches it
+    wave_lds_sync();
     if (active) {
         const int off = crpt[rid];
         for (int s = sub; s < TROW; s += LPR) {

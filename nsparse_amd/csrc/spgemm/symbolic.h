@@ -21,8 +21,12 @@ __global__ __launch_bounds__(BS) void k_sym_small(const int *__restrict__ arpt,
 {
     constexpr int RPB = BS / LPR;
     __shared__ int tab[RPB * TROW];
-    for (int i = threadIdx.x; i < RPB * TROW; i += BS) tab[i] = -1;
-    __syncthreads();
+    {  // every wavefront clears only the slots of its own rows: no workgroup barrier
+        constexpr int WSLOTS = 64 / LPR * TROW;
+        const int w0 = (threadIdx.x >> 6) * WSLOTS;
+        for (int i = threadIdx.x & 63; i < WSLOTS; i += 64) tab[w0 + i] = -1;
+    }
+    wave_lds_sync();
     const int lrow = threadIdx.x / LPR;
     const int sub = threadIdx.x % LPR;
     const int q = blockIdx.x * RPB + lrow;
