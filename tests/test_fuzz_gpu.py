@@ -2,6 +2,8 @@
 density and row-length distribution against the CPU oracle -- structure exact, values to the
 reference tolerance.  Catches the corners the targeted tests do not name (empty rows / columns,
 1 x N, N x 1, hub rows next to empty ones, every mix of bins in one call)."""
+import os
+
 import numpy as np
 import pytest
 import scipy.sparse as sp
@@ -21,6 +23,12 @@ def _rand_csr(rng, m, n, kind):
         cols = np.minimum((rng.pareto(0.8, rows.size) * 3).astype(np.int64), n - 1)
         a = sp.csr_matrix((rng.random(rows.size) + 0.1, (rows, cols)), shape=(m, n))
         a.sum_duplicates()
+    elif kind == 3:    # runs of rows with one column pattern (twin rows), different values
+        base = sp.random(max(m // 3, 1), n, density=rng.choice([0.003, 0.02, 0.2]), format="csr",
+                         random_state=rng, dtype=np.float64)
+        pick = np.sort(rng.integers(0, base.shape[0], size=m))
+        a = base[pick].tocsr()
+        a.data = rng.random(a.data.size) + 0.1
     else:              # banded
         bw = int(rng.integers(1, 40))
         offs = [o for o in range(-bw, bw + 1) if -m < o < n]
@@ -31,12 +39,13 @@ def _rand_csr(rng, m, n, kind):
                 val=a.data.astype(np.float64))
 
 
-@pytest.mark.parametrize("seed", range(40))
+# NSPARSE_FUZZ_SEEDS / NSPARSE_FUZZ_BASE: a longer soak from other seeds (default: 40 cases from 1000)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NSPARSE_FUZZ_SEEDS", "40"))))
 def test_random_products(seed, lib_d, oracle_d):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(int(os.environ.get("NSPARSE_FUZZ_BASE", "1000")) + seed)
     m, k, n = (int(rng.choice([1, 2, 7, 63, 64, 65, 300, 1500, 4000, 20000])) for _ in range(3))
-    A = _rand_csr(rng, m, k, int(rng.integers(0, 3)))
-    B = _rand_csr(rng, k, n, int(rng.integers(0, 3)))
+    A = _rand_csr(rng, m, k, int(rng.integers(0, 4)))
+    B = _rand_csr(rng, k, n, int(rng.integers(0, 4)))
     ref = oracle_d.spgemm(A, B)
     got, st = spgemm(lib_d, A, B)
     assert got["nnz"] == ref["nnz"]
