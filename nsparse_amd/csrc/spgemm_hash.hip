@@ -652,8 +652,10 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     Thr sym_thr = kSymThr, num_thr = kNumThr;
     if (!g_dense_enabled) sym_thr.dense_ratio = num_thr.dense_ratio = sym_thr.bits_ratio = 0;
     NSP_CHECK(hipStreamSynchronize(0));  // inputs queued on the null stream by the caller
-    NSP_CHECK(hipMemsetAsync(d_sym, 0, 2 * sizeof(BinState), s0));
-    NSP_CHECK(hipMemsetAsync(long_cnt, 0, 4 * sizeof(int), s0));  // + the two words of k_col_range
+    // one fill for both counter blocks and the four words at long_cnt (the two list counters and the
+    // two words of k_col_range); the ints in between belong to calls that reset them themselves
+    static_assert(2 * sizeof(BinState) <= 240 * sizeof(int), "counter blocks end before long_cnt");
+    NSP_CHECK(hipMemsetAsync(cx.d_scratch, 0, 244 * sizeof(int), s0));
 
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
     {
