@@ -96,7 +96,17 @@ SIGNATURES = {
                                  C.c_ulonglong, C.c_longlong, C.c_longlong]),
 }
 
+# every entry point declared in include/nsparse_vendor.h (libnsparse_vendor_{d,s}.so: rocSPARSE baseline)
+VENDOR_SIGNATURES = {
+    "nsparse_vendor_spgemm": (None, [_P(sfCSR), _P(sfCSR), _P(sfCSR), _P(C.c_float)]),
+    "nsparse_vendor_release_csr": (None, [sfCSR]),
+    "spgemm_cu_csr": (None, [_P(sfCSR), _P(sfCSR), _P(sfCSR)]),
+    "nsparse_vendor_spmv_csr": (C.c_float, [C.c_void_p, _P(sfCSR), C.c_void_p, C.c_int]),
+    "nsparse_vendor_last_error": (C.c_int, []),
+}
+
 _libs = {}
+_vendor = {}
 
 
 class Lib:
@@ -191,6 +201,31 @@ class Lib:
             write_permutation=self.d2h(a.d_write_permutation, (cs * ch,), np.int32),
             c_size=cs, chunk=ch, block_size=bs, nnz=n, pad_M=a.pad_M, seg_size=a.seg_size,
             seg_num=a.seg_num, M=a.M, N=a.N)
+
+
+class VendorLib:
+    """libnsparse_vendor_{d,s}.so: the reference's cuSPARSE comparison path on rocSPARSE (baseline and
+    third oracle; the product library does not depend on it)."""
+
+    def __init__(self, precision):
+        assert precision in ("d", "s")
+        path = os.path.join(LIB_DIR, f"libnsparse_vendor_{precision}.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C nsparse_amd/csrc vendor`")
+        self.precision = precision
+        self.path = path
+        self.dll = C.CDLL(path, mode=C.RTLD_LOCAL)
+        for name, (res, args) in VENDOR_SIGNATURES.items():
+            fn = getattr(self.dll, name)
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+
+def load_vendor(precision="d"):
+    if precision not in _vendor:
+        _vendor[precision] = VendorLib(precision)
+    return _vendor[precision]
 
 
 def load(precision="d"):

@@ -535,10 +535,43 @@ static float tune_thread_block(sfAMB *mat, real *d_x, real *d_y, sfPlan *plan, i
     return best;
 }
 
-static void convert(sfAMB *mat, sfCSR *csr, real *d_x, sfPlan *plan)
+static void convert(sfAMB *mat, sfCSR *csr_in, real *d_x, sfPlan *plan)
 {
+    ApiLock api_lock;
     clear_error();
     Context &cx = ctx();
+    // nnz_max sizes the sort keys: a value outside (0, N] (a caller-built sfCSR) means unknown
+    sfCSR csr_chk = *csr_in;
+    if (!(csr_chk.nnz_max > 0 && csr_chk.nnz_max <= csr_chk.N)) csr_chk.nnz_max = 0;
+    sfCSR *csr = &csr_chk;
+    if (csr->M <= 0) {
+        // no rows (the empty block of a row-sharded run): an AMB with no chunks; sf_spmv_amb on it
+        // writes nothing.  Every d_* array still exists, so release_amb works as usual.
+        memset(mat, 0, sizeof(*mat));
+        mat->N = csr->N;
+        mat->chunk = g_chunk;
+        mat->block_size = 1;
+        mat->SIGMA = SHORT_MAX;
+        mat->seg_size = USHORT_MAX;
+        mat->seg_num = (size_t)(csr->N > 0 ? ceil_div(csr->N, USHORT_MAX) : 1);
+        mat->group_num_col = (int)mat->seg_num;
+        mat->matrix_name = csr->matrix_name;
+        mat->d_cs = (int *)dev_alloc(sizeof(int));
+        mat->d_cl = (unsigned int *)dev_alloc(sizeof(unsigned int));
+        mat->d_sellcs_col = (unsigned short *)dev_alloc(sizeof(unsigned short));
+        mat->d_sellcs_val = (real *)dev_alloc(sizeof(real));
+        mat->d_write_permutation = (int *)dev_alloc(sizeof(int));
+        mat->d_s_write_permutation = (unsigned short *)dev_alloc(sizeof(unsigned short));
+        mat->d_s_write_permutation_offset = (unsigned short *)dev_alloc(sizeof(unsigned short));
+        plan->isPlan = TRUE;
+        plan->seg_size = mat->seg_size;
+        plan->seg_num = mat->seg_num;
+        plan->block_size = 1;
+        plan->SIGMA = mat->SIGMA;
+        plan->thread_block = 256;
+        plan->thread_grid = 0;
+        return;
+    }
     NSP_CHECK(hipDeviceSynchronize());  // inputs may have been produced on any stream
     hipStream_t st = cx.stream[0];
     const int C = g_chunk;

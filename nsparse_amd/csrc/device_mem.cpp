@@ -7,6 +7,7 @@
 #include <chrono>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <unordered_map>
 
 #include "internal.h"
@@ -14,16 +15,36 @@
 namespace nsp {
 
 namespace {
+constexpr int kMaxDevices = 16;
+// One cache for the process, one idle list per device: a block goes back to the list of the device
+// it was allocated on, whatever device is current when it is released.  Guarded by its own mutex
+// (csr_memcpy / release_* may be called from any thread).
 struct Cache {
     bool enabled = true;
-    std::unordered_map<void *, size_t> live;  // blocks handed out
-    std::multimap<size_t, void *> idle;       // blocks waiting for reuse
+    struct Live { size_t bytes; int dev; };
+    std::unordered_map<void *, Live> live;               // blocks handed out
+    std::multimap<size_t, void *> idle[kMaxDevices];     // blocks waiting for reuse
     size_t idle_bytes = 0;
+    std::mutex mu;
 };
 Cache &cache()
 {
     static Cache c;
     return c;
+}
+int current_device()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) d = 0;
+    return d >= 0 && d < kMaxDevices ? d : 0;
+}
+void trim_locked(Cache &c)
+{
+    for (auto &lst : c.idle) {
+        for (auto &kv : lst) (void)hipFree(kv.second);
+        lst.clear();
+    }
+    c.idle_bytes = 0;
 }
 // Round so that near-equal requests of consecutive calls hit the same idle block.
 inline size_t round_size(size_t b)
@@ -38,26 +59,29 @@ void *dev_alloc(size_t bytes)
 {
     Cache &c = cache();
     const size_t want = round_size(bytes);
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(c.mu);
     if (c.enabled) {
-        auto it = c.idle.lower_bound(want);
+        auto &idle = c.idle[dev];
+        auto it = idle.lower_bound(want);
         // accept an idle block up to 25 % (+1 MiB) larger than the request
-        if (it != c.idle.end() && it->first <= want + want / 4 + (1u << 20)) {
+        if (it != idle.end() && it->first <= want + want / 4 + (1u << 20)) {
             void *p = it->second;
-            c.live[p] = it->first;
+            c.live[p] = {it->first, dev};
             c.idle_bytes -= it->first;
-            c.idle.erase(it);
+            idle.erase(it);
             return p;
         }
     }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, want);
-    if (e != hipSuccess && c.enabled && !c.idle.empty()) {
+    if (e != hipSuccess && c.enabled && c.idle_bytes > 0) {
         (void)hipGetLastError();
-        dev_cache_trim();  // give the idle blocks back and retry once
+        trim_locked(c);  // give the idle blocks back and retry once
         e = hipMalloc(&p, want);
     }
     NSP_CHECK(e);
-    if (c.enabled) c.live[p] = want;
+    if (c.enabled) c.live[p] = {want, dev};
     return p;
 }
 
@@ -65,31 +89,41 @@ void dev_free(void *p)
 {
     if (!p) return;
     Cache &c = cache();
-    auto it = c.live.find(p);
-    if (it != c.live.end()) {
-        if (c.enabled) {
-            c.idle.emplace(it->second, p);
-            c.idle_bytes += it->second;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        auto it = c.live.find(p);
+        if (it != c.live.end()) {
+            if (c.enabled) {
+                c.idle[it->second.dev].emplace(it->second.bytes, p);
+                c.idle_bytes += it->second.bytes;
+                c.live.erase(it);
+                return;
+            }
             c.live.erase(it);
-            return;
         }
-        c.live.erase(it);
     }
     NSP_CHECK(hipFree(p));
 }
 
 void dev_cache_enable(bool on)
 {
-    if (!on) dev_cache_trim();
-    cache().enabled = on;
+    Cache &c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    if (!on) trim_locked(c);
+    c.enabled = on;
 }
 
 void dev_cache_trim()
 {
     Cache &c = cache();
-    for (auto &kv : c.idle) (void)hipFree(kv.second);
-    c.idle.clear();
-    c.idle_bytes = 0;
+    std::lock_guard<std::mutex> lk(c.mu);
+    trim_locked(c);
+}
+
+std::recursive_mutex &api_mutex()
+{
+    static std::recursive_mutex m;
+    return m;
 }
 
 void wait_published(int slot, int seq, hipStream_t st)
@@ -108,9 +142,15 @@ void wait_published(int slot, int seq, hipStream_t st)
     }
 }
 
+// One context per device, created on first use with that device current: streams, events and the
+// counter / flag blocks belong to the device the caller selected with hipSetDevice (the reference
+// builds its sfBIN and streams inside every call, so it follows the current device as well).
 Context &ctx()
 {
-    static Context c;
+    static Context per_dev[kMaxDevices];
+    static std::mutex mu;
+    Context &c = per_dev[current_device()];
+    std::lock_guard<std::mutex> lk(mu);
     if (!c.ready) {
         for (int i = 0; i < kMaxBins; i++) {
             NSP_CHECK(hipStreamCreateWithFlags(&c.stream[i], hipStreamNonBlocking));
@@ -135,9 +175,14 @@ extern "C" {
 
 void nsparse_set_workspace_cache(int on) { nsp::dev_cache_enable(on != 0); }
 void nsparse_trim_workspace(void) { nsp::dev_cache_trim(); }
-void nsparse_set_profiling(int on) { nsp::ctx().profiling = (on != 0); }
+void nsparse_set_profiling(int on)
+{
+    nsp::ApiLock lk;
+    nsp::ctx().profiling = (on != 0);
+}
 int nsparse_set_bin_timing(int on)
 {
+    nsp::ApiLock lk;
     const int old = nsp::ctx().bin_timing;
     nsp::ctx().bin_timing = (on != 0);
     return old;

@@ -4,6 +4,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 
@@ -36,7 +37,18 @@ void dev_free(void *p);
 void dev_cache_enable(bool on);
 void dev_cache_trim();
 
-// ---- per-process context ---------------------------------------------------------
+// ---- threading ---------------------------------------------------------------------
+// The reference is not thread-safe (global `memory_access`, default stream).  Here every
+// public entry point that touches a Context takes one process-wide lock, so concurrent callers
+// serialise instead of sharing the device-side counters of a call in flight; the block cache has
+// its own lock.  nsparse_spmv_amb_async touches no shared state and takes no lock.
+std::recursive_mutex &api_mutex();
+struct ApiLock {
+    std::lock_guard<std::recursive_mutex> lk;
+    ApiLock() : lk(api_mutex()) {}
+};
+
+// ---- per-device context ------------------------------------------------------------
 constexpr int kMaxBins = 12;
 
 struct Context {

@@ -613,10 +613,39 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     return L;
 }
 
-static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
+// nnz_max is a HINT here (it selects lane counts and whether long rows are deferred); upstream only
+// ever prints it.  A caller-built sfCSR may leave it unset: anything outside (0, N] means unknown.
+static inline sfCSR with_checked_hint(const sfCSR *m)
 {
+    sfCSR r = *m;
+    if (!(r.nnz_max > 0 && r.nnz_max <= r.N)) r.nnz_max = 0;
+    return r;
+}
+
+static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
+{
+    ApiLock api_lock;
     clear_error();
     Context &cx = ctx();
+    sfCSR a_chk = with_checked_hint(a_in), b_chk = with_checked_hint(b_in);
+    const sfCSR *a = &a_chk, *b = &b_chk;
+    if (a->M <= 0 || a->nnz <= 0 || b->nnz <= 0 || b->M <= 0) {
+        // nothing to multiply: C has a->M empty rows (zero-size grids are not launchable)
+        memset(&g_stats.s, 0, sizeof(g_stats.s));
+        if (!numeric_only) {
+            const int M0 = a->M > 0 ? a->M : 0;
+            c->M = M0;
+            c->N = b->N;
+            c->nnz = 0;
+            c->nnz_max = 0;
+            c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M0 + 1));
+            c->d_col = (int *)dev_alloc(sizeof(int));
+            c->d_val = (real *)dev_alloc(sizeof(real));
+            NSP_CHECK(hipMemsetAsync(c->d_rpt, 0, sizeof(int) * (size_t)(M0 + 1), cx.stream[0]));
+            NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
+        }
+        return;
+    }
     Timer tm(cx);
     hipStream_t s0 = cx.stream[0];
     const int M = a->M;
@@ -789,6 +818,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     }
     if (!numeric_only && !too_big) {
         c->nnz = h_num->nnz;
+        c->nnz_max = h_num->maxv;  // longest row of C: the hint a chained product or sf_csr2amb reads
         c->d_col = (int *)dev_alloc(sizeof(int) * (size_t)(c->nnz > 0 ? c->nnz : 1));
         c->d_val = (real *)dev_alloc(sizeof(real) * (size_t)(c->nnz > 0 ? c->nnz : 1));
     }
@@ -816,6 +846,7 @@ static void run(sfCSR *a, sfCSR *b, sfCSR *c, bool numeric_only)
     S.ms_total = tm.ms(0, 3);
     } else {
         NSP_CHECK(hipStreamSynchronize(s0));
+        sym_used.collect(S.ms_sym_bin);  // returns the scratch the symbolic kernels deferred
         dev_free(c->d_rpt);
         c->d_rpt = nullptr;
         c->d_col = nullptr;
@@ -868,7 +899,11 @@ void spgemm_kernel_hash(sfCSR *a, sfCSR *b, sfCSR *c) { nsp::spgemm::run(a, b, c
 
 void nsparse_spgemm_hash_numeric(sfCSR *a, sfCSR *b, sfCSR *c) { nsp::spgemm::run(a, b, c, true); }
 
-void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out) { *out = nsp::spgemm::g_stats.s; }
+void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out)
+{
+    nsp::ApiLock lk;
+    *out = nsp::spgemm::g_stats.s;
+}
 
 int nsparse_spgemm_set_sorted(int on)
 {
@@ -903,7 +938,10 @@ void nsparse_get_spgemm_bins(int *sym, int *num)
 
 void get_spgemm_flop(sfCSR *a, sfCSR *b, int M, long long int *flop)
 {
+    nsp::ApiLock lk;
     nsp::clear_error();
+    *flop = 0;
+    if (M <= 0) return;
     nsp::Context &cx = nsp::ctx();
     unsigned long long *d_total = reinterpret_cast<unsigned long long *>(cx.d_scratch + 192);
     NSP_CHECK(hipMemsetAsync(d_total, 0, sizeof(unsigned long long), cx.stream[0]));

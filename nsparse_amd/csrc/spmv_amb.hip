@@ -106,7 +106,7 @@ static void launch(real *d_y, const sfAMB *mat, const real *d_x, const sfPlan *p
     // chunk present each row is stored exactly once, and the memset -- a third of the time of a
     // cache-resident SpMV -- is skipped.
     const bool every_row_stored = mat->seg_num == 1 && (long long)mat->c_size * mat->chunk >= (long long)mat->pad_M;
-    if (!every_row_stored) NSP_CHECK(hipMemsetAsync(d_y, 0, sizeof(real) * (size_t)mat->M, st));
+    if (!every_row_stored && mat->M > 0) NSP_CHECK(hipMemsetAsync(d_y, 0, sizeof(real) * (size_t)mat->M, st));
     if (mat->c_size <= 0) return;
     int tb = (int)plan->thread_block;
     if (tb < 64 || tb > 1024 || (tb & 63)) tb = 256;
@@ -135,6 +135,7 @@ void nsparse_spmv_amb_async(real *d_y, sfAMB *mat, real *d_x, sfPlan *plan, void
 // (the reference launches on the default stream and ends with cudaThreadSynchronize).
 void sf_spmv_amb(real *d_y, sfAMB *mat, real *d_x, sfPlan *plan)
 {
+    nsp::ApiLock lk;
     nsp::clear_error();
     nsp::Context &cx = nsp::ctx();
     if (cx.profiling) NSP_CHECK(hipEventRecord(cx.ev_t[4], 0));

@@ -148,6 +148,188 @@ void gen_powerlaw(sfCSR *mat, long long n, long long target_nnz, unsigned long l
     b.finish(mat, M, n);
 }
 
+// "cant class, irregular" (kind 5): the same nx*ny*nz brick of 3-dof nodes as kind 0, but
+//   * the unknowns are renumbered by a pseudo-random permutation inside consecutive blocks of
+//     `blk` unknowns (symmetric: P A P^T), so the rows of one node are no longer neighbours, the
+//     column window of a C row is no longer the 5 planes a natural ordering gives, and rows with
+//     the same column pattern are not adjacent;
+//   * node couplings are dropped (symmetrically, all 3 x 3 dof at once) with probability `drop`,
+//     which brings nnz and the product count down to the SuiteSparse statistics of cant
+//     (62,451 rows, 4.0 M nnz, ~0.27 G products for 9 x 9 x 257 with drop = 0.074).
+// Values as in kind 0 (symmetric in the ORIGINAL numbering, so the matrix stays symmetric).
+void gen_brick_shuffled(sfCSR *mat, long long nx, long long ny, long long nz, unsigned long long seed,
+                        long long rb, long long re)
+{
+    const int dof = 3;
+    const long long nodes = nx * ny * nz, Mfull = nodes * dof;
+    if (re <= 0 || re > Mfull) re = Mfull;
+    if (rb < 0) rb = 0;
+    const long long blk = 2 * dof * nx * ny;  // two planes of unknowns
+    const unsigned long long drop_thr = (unsigned long long)(0.074 * 18446744073709551615.0);
+    // new_of[old] / old_of[new]: permutation inside each block, by sorting hash keys
+    std::vector<int> new_of((size_t)Mfull), old_of((size_t)Mfull);
+    {
+        std::vector<std::pair<unsigned long long, int>> keys;
+        for (long long b0 = 0; b0 < Mfull; b0 += blk) {
+            const long long b1 = b0 + blk < Mfull ? b0 + blk : Mfull;
+            keys.clear();
+            for (long long i = b0; i < b1; i++) keys.emplace_back(mix64(seed ^ mix64(0xB10Cull + (unsigned long long)i)), (int)i);
+            std::sort(keys.begin(), keys.end());
+            for (long long i = b0; i < b1; i++) {
+                old_of[(size_t)i] = keys[(size_t)(i - b0)].second;
+                new_of[(size_t)keys[(size_t)(i - b0)].second] = (int)i;
+            }
+        }
+    }
+    Builder b;
+    const long long M = re - rb;
+    b.rpt.resize((size_t)M + 1);
+    b.col.reserve((size_t)M * 27 * dof);
+    b.val.reserve((size_t)M * 27 * dof);
+    std::vector<std::pair<int, real>> row;
+    for (long long rn = rb; rn < re; rn++) {
+        b.rpt[(size_t)(rn - rb)] = (int)b.col.size();
+        const long long r = old_of[(size_t)rn];
+        const long long node = r / dof;
+        const long long x = node % nx, y = (node / nx) % ny, z = node / (nx * ny);
+        row.clear();
+        for (long long dz = -1; dz <= 1; dz++) {
+            const long long zz = z + dz;
+            if (zz < 0 || zz >= nz) continue;
+            for (long long dy = -1; dy <= 1; dy++) {
+                const long long yy = y + dy;
+                if (yy < 0 || yy >= ny) continue;
+                for (long long dx = -1; dx <= 1; dx++) {
+                    const long long xx = x + dx;
+                    if (xx < 0 || xx >= nx) continue;
+                    const long long nb = (zz * ny + yy) * nx + xx;
+                    if (nb != node) {
+                        const long long lo = nb < node ? nb : node, hi = nb < node ? node : nb;
+                        if (mix64(seed ^ mix64(0xD40Full + (unsigned long long)lo * 0x100000001B3ull + (unsigned long long)hi)) < drop_thr)
+                            continue;
+                    }
+                    for (int d = 0; d < dof; d++) {
+                        const long long c = nb * dof + d;
+                        row.emplace_back(new_of[(size_t)c], pair_value(seed, r, c));
+                    }
+                }
+            }
+        }
+        std::sort(row.begin(), row.end());
+        for (auto &e : row) {
+            b.col.push_back(e.first);
+            b.val.push_back(e.second);
+        }
+        if ((int)row.size() > b.nnz_max) b.nnz_max = (int)row.size();
+    }
+    b.rpt[(size_t)M] = (int)b.col.size();
+    b.finish(mat, M, Mfull);
+}
+
+// Web graph with the SuiteSparse statistics of webbase-1M (kind 4; BASELINE config 3):
+// 1,000,005 pages, 3.1 M links, ~70 M intermediate products and ~51 M non-zeros in A^2, longest
+// row ~4.7 K.  Kind 2 has the row-length distribution only: its products are 11x fewer than the
+// real matrix's because its long rows are not the popular ones.  Here pages come in sites of
+// kSite consecutive ids; the first page of a site is its index page with a heavy-tailed number
+// of links (directories), index pages of popular sites are long AND linked from everywhere, so
+// the popular columns select long rows of B -- which is what makes n_prod / nnz = 22 in
+// webbase-1M.  Every row depends on its own id and the seed only (row blocks can be generated
+// independently).
+constexpr long long kSite = 32;
+inline long long web_index_degree(unsigned long long seed, long long site, long long n_sites, long long cap)
+{
+    // popularity rank of a site = its id (low ids popular); degree: Pareto tail, longer for popular sites
+    const double u = u01(mix64(seed ^ mix64(0x51DEull + (unsigned long long)site)));
+    const double pop = 1.0 - (double)site / (double)n_sites;  // 1 = most popular
+    double d = (5.0 + 36.0 * pop * pop * pop) / std::pow(1.0 - u, 1.0 / 1.5);
+    if (d > (double)cap) d = (double)cap;
+    return (long long)d;
+}
+void gen_webgraph(sfCSR *mat, long long n, long long target_nnz, unsigned long long seed, long long rb,
+                  long long re)
+{
+    if (re <= 0 || re > n) re = n;
+    if (rb < 0) rb = 0;
+    const long long n_sites = (n + kSite - 1) / kSite;
+    const long long cap = 4700;
+    // ordinary pages: 1 + geometric, mean = the share `ofr` of target_nnz (index pages and template
+    // sites carry the rest)
+    // constants tuned (tools: the statistics line of tests/test_configs_gpu.py) until nnz, the product
+    // count and nnz(A^2) land within 2 % of webbase-1M's 3,105,536 / 69.5 M / 51.1 M
+    constexpr double ofr = 0.47, skp = 3.4, i_loc = 0.70, i_dir = 0.90, o_home = 0.30, o_loc = 0.55, o_dir = 0.75,
+                     wmul = 2.0, tpl = 0.03;
+    const double ord_mean = ((double)target_nnz * ofr) / (double)(n - n_sites);
+    const double pgeo = ord_mean > 1.0 ? 1.0 - 1.0 / ord_mean : 0.0;
+    Builder b;
+    const long long M = re - rb;
+    b.rpt.resize((size_t)M + 1);
+    std::vector<int> tmp;
+    auto skew_site = [&](double t) {  // popular sites (low ids) drawn far more often
+        long long s = (long long)((double)n_sites * std::pow(t, skp));
+        return s >= n_sites ? n_sites - 1 : s;
+    };
+    for (long long r = rb; r < re; r++) {
+        b.rpt[(size_t)(r - rb)] = (int)b.col.size();
+        unsigned long long s = mix64(seed ^ mix64((unsigned long long)r));
+        const long long site = r / kSite;
+        const bool is_index = r % kSite == 0;
+        long long deg;
+        const unsigned long long sh = mix64(seed ^ mix64(0x7E3Full + (unsigned long long)site));
+        if (u01(sh) < tpl && (site + 1) * kSite <= n) {
+            // template site: every page carries the same navigation bar of K same-site links
+            const long long K = 16 + (long long)((sh >> 7) % 17);
+            for (long long k = 0; k < K; k++) {
+                const long long c = site * kSite + k;
+                b.col.push_back((int)c);
+                b.val.push_back((real)(0.1 + u01(mix64(seed ^ mix64((unsigned long long)r * 0x9E3779B1ull + (unsigned long long)c)))));
+            }
+            if ((int)K > b.nnz_max) b.nnz_max = (int)K;
+            continue;
+        }
+        if (is_index) {
+            deg = web_index_degree(seed, site, n_sites, cap);
+        } else {
+            deg = 1;
+            while (deg < 40 && u01(s = mix64(s)) < pgeo) deg++;
+        }
+        tmp.clear();
+        for (long long k = 0; k < deg; k++) {
+            s = mix64(s);
+            const double a = u01(s);
+            s = mix64(s);
+            const double t = u01(s);
+            long long c;
+            if (is_index) {
+                if (a < i_loc) {  // the pages of the site and of the sites next to it
+                    const long long w = deg < kSite ? kSite : (long long)(wmul * deg);
+                    c = site * kSite + (long long)(t * (double)w) - (w - kSite) / 2;
+                } else if (a < i_dir) {  // other directories
+                    c = skew_site(t) * kSite;
+                } else {
+                    c = (long long)(t * (double)n);
+                }
+            } else {
+                if (a < o_home) c = site * kSite;                               // home
+                else if (a < o_loc) c = site * kSite + (long long)(t * kSite); // a page of the site
+                else if (a < o_dir) c = skew_site(t) * kSite;                  // a popular directory
+                else c = (long long)(t * (double)n);
+            }
+            if (c < 0) c = 0;
+            if (c >= n) c = n - 1;
+            tmp.push_back((int)c);
+        }
+        std::sort(tmp.begin(), tmp.end());
+        tmp.erase(std::unique(tmp.begin(), tmp.end()), tmp.end());
+        for (int c : tmp) {
+            b.col.push_back(c);
+            b.val.push_back((real)(0.1 + u01(mix64(seed ^ mix64((unsigned long long)r * 0x9E3779B1ull + (unsigned long long)c)))));
+        }
+        if ((int)tmp.size() > b.nnz_max) b.nnz_max = (int)tmp.size();
+    }
+    b.rpt[(size_t)M] = (int)b.col.size();
+    b.finish(mat, M, n);
+}
+
 // R-MAT (a,b,c,d) = (0.57,0.19,0.19,0.05), no vertex permutation, duplicates merged with
 // summed values.
 void gen_rmat(sfCSR *mat, int scale, long long ef, long long edges, unsigned long long seed, long long rb,
@@ -204,6 +386,8 @@ extern "C" void nsparse_synth_csr(sfCSR *mat, int kind, long long p0, long long 
         case 1: gen_stencil(mat, 1, p0, p1, p2, seed, row_begin, row_end); break;
         case 2: gen_powerlaw(mat, p0, p1, seed, row_begin, row_end); break;
         case 3: gen_rmat(mat, (int)p0, p1, p2, seed, row_begin, row_end); break;
+        case 4: gen_webgraph(mat, p0, p1, seed, row_begin, row_end); break;
+        case 5: gen_brick_shuffled(mat, p0, p1, p2, seed, row_begin, row_end); break;
         default:
             fprintf(stderr, "nsparse_synth_csr: unknown kind %d\n", kind);
             memset(mat, 0, sizeof(*mat));
