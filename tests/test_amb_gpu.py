@@ -120,3 +120,48 @@ def test_full_size_cant_class(lib_d, oracle_d):
     # linearity: A(2x) == 2 A(x) exactly (power-of-two scaling commutes with rounding)
     assert np.array_equal(d.spmv(2 * x), 2 * y)
     d.close()
+
+
+def test_timed_plan_search(lib_d, oracle_d):
+    """NSPARSE_AMB_TUNE=timed: the reference's default plan search (convert_amb.cu:18 `#define AT`,
+    :556-600 evaluate_spmv, :878-925) -- every (segment size, block size) candidate is built and
+    timed.  Which candidate wins depends on the clock; what must hold: the plan written back is one
+    of the candidates, the arrays are bit-exact for THAT plan, and y is right."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, json, ctypes as C, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r);"
+        "import nsparse_amd as ns; from gpu_util import DeviceAMB; from conftest import load_golden;"
+        "lib = ns.load('d'); g = load_golden('banded2k'); d = DeviceAMB(lib, g);"
+        "y = d.spmv(g['x']); arr = d.arrays();"
+        "np.savez(sys.argv[1], y=y, **{k: arr[k] for k in ('cs','cl','sellcs_col','sellcs_val','s_write_permutation','s_write_permutation_offset','write_permutation')});"
+        "print(json.dumps(dict(seg=int(d.plan.seg_size), bs=int(d.plan.block_size), isplan=int(d.plan.isPlan),"
+        " tb=int(d.plan.thread_block), nnz=int(d.amb.nnz), c_size=int(d.amb.c_size))))"
+    ) % (root, os.path.join(root, "tests"))
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = os.path.join(td, "amb.npz")
+        r = subprocess.run([sys.executable, "-c", code, out], cwd=root, capture_output=True, text=True,
+                           env=dict(os.environ, NSPARSE_AMB_TUNE="timed"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        z = np.load(out)
+        g = load_golden("banded2k")
+        assert info["isplan"] == 1 and 1 <= info["bs"] <= 20 and info["tb"] in (64, 128, 256, 512, 1024)
+        assert info["seg"] in (65536, 1024, 2048, 3072, 4096)  # sf_csr2amb's candidates for N < 128 K
+        ora = oracle_d.csr2amb(g, info["seg"], info["bs"], 64)
+        assert info["nnz"] == ora.nnz and info["c_size"] == ora.c_size
+        for k in ARRAYS:
+            assert np.array_equal(z[k], getattr(ora, k)), f"AMB array {k} differs for the timed plan"
+        assert oracle_d.ans_check(g["y"], z["y"]) == 0
+
+
+def test_no_rows(lib_d):
+    """M = 0: an AMB with no chunks; conversion, SpMV and release are all no-ops that do not fail."""
+    A = dict(M=0, N=500, rpt=np.zeros(1, np.int32), col=np.zeros(0, np.int32), val=np.zeros(0))
+    d = DeviceAMB(lib_d, A)
+    assert d.amb.c_size == 0 and d.plan.isPlan == 1 and lib_d.nsparse_last_error() == 0
+    assert d.spmv(np.ones(500)).shape == (0,)
+    d.close()
