@@ -1,0 +1,301 @@
+// spgemm/block.h -- numeric window kernel that works on NODE BLOCKS (bins 6-8, default path).
+// Part of the spgemm_hash.hip translation unit (kernels are launched from its host code).
+//
+// What measurements of the first numeric window kernel (window.h: k_num_dense) showed on the
+// cant-class brick (ablations): without its LDS atomics the kernel takes the SAME time;
+// without the loads of B it drops from 0.46 to 0.33 ms; without both, still 0.32 ms -- 0.18 ms of pure
+// instruction stream of the product walk and 0.13 ms of per-row latency (clear, A-entry parking,
+// emission).  It is bound by instructions per product and by bytes through the 64 B/clk L1, not by
+// ds_add_f64 (tools/lds_atomic: 5-20 lane-operations per clock per CU; the kernel needed 1.3).
+//
+// So this kernel cuts the instructions and the bytes per product, by the structure finite-element
+// matrices have: the degrees of freedom of one mesh node are consecutive rows with ONE column
+// pattern ("twin rows", already detected for the symbolic phase).
+//   * up to 3 twin rows of A are one workgroup: the A entries are parked once, every element of B is
+//     loaded once and used for all of them (3 windows in LDS);
+//   * consecutive A entries whose rows of B are twins (the 3 dof of the node the entry points to)
+//     are one RUN: the lane that holds column p of the run loads the column id once and the values of
+//     the (up to 3) rows, forms  sum_d a[r][d] * b[d][p]  in registers and issues ONE ds_add_f64 per
+//     C row -- a 3 x 3 node block costs 4 loads, 9 multiply-adds and 3 atomics for 9 products,
+//     where the generic walk needed 9 x (load share + 6 slot instructions + multiply + atomic);
+//   * one lane per COLUMN of the B row (a group of G lanes reads G consecutive entries), so an atomic
+//     instruction sees consecutive columns: the window is indexed plainly, a partial chunk is one
+//     exec mask.
+// Matrices without twin rows run the same code with runs and groups of one (the lean scalar walk).
+// Structure and values are the reference's (kernel_spgemm_hash_d.cu:829-927 accumulates the same
+// products with shared-memory atomics); only the order of the floating-point additions differs, as it
+// already does between two runs of the reference.
+#pragma once
+#include "common.h"
+#include "window.h"
+
+namespace nsp {
+namespace spgemm {
+
+constexpr int kBlkRows = 3;        // twin rows of A per workgroup
+constexpr int kBlkRun = 3;         // twin rows of B per run
+constexpr int kBlkAccElems = 4608;  // LDS budget of the accumulator rows of one workgroup (36 KiB)
+
+// grp[r]: bits 0-1 = position of row r inside its group (0: head), bits 2-3 = rows in the group (heads).
+// A group = up to `cap` consecutive rows of one twin chain, cap = how many accumulator rows of this
+// row's nnz fit the LDS budget.  One wavefront per 64-row segment (twin chains never cross multiples
+// of kTwinRun = 64 rows).  Only rows the numeric window bins take form groups.
+__global__ __launch_bounds__(256) void k_twin_groups(const unsigned char *__restrict__ twin,
+                                                     const int *__restrict__ row_span_num,
+                                                     const int *__restrict__ row_nz,
+                                                     const int *__restrict__ row_prod, Thr num_thr, int M,
+                                                     unsigned char *__restrict__ grp)
+{
+    static_assert(kTwinRun == 64, "one wavefront per chain segment");
+    const int lane = threadIdx.x & 63;
+    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
+    const bool valid = r < M;
+    const bool t = valid && twin[r] != 0;
+    const unsigned long long heads = __ballot(valid && !t);
+    const unsigned long long vm = __ballot(valid);
+    if (!valid) return;
+    const int nvalid = __popcll(vm);
+    const unsigned long long below = heads & ((2ull << lane) - 1ull);
+    const int h = below ? 63 - __clzll((long long)below) : lane;  // lane of the chain head (lane 0 is one)
+    const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
+    const int end = above ? lane + 1 + (__ffsll((long long)above) - 1) : nvalid;
+    const int span = row_span_num[r];  // twins carry their head's numbers (k_twin_copy)
+    const int nzs = ((row_nz[r] + 7) >> 3) << 3;
+    // only rows the numeric binning will put into a window bin (the same rule, bin_of): the followers
+    // of a group are left out of the bin lists, which only the node-block kernel understands
+    const bool windowed = span > 0 && nzs > 0 && bin_of(row_nz[r], span, num_thr, row_prod[r]) >= kDenseBin0;
+    int cap = windowed ? kBlkAccElems / nzs : 1;
+    cap = cap < 1 ? 1 : (cap > kBlkRows ? kBlkRows : cap);
+    const int pos = lane - h;
+    const int gpos = pos % cap;
+    int gsize = end - (lane - gpos);
+    gsize = gsize > cap ? cap : gsize;
+    grp[r] = (unsigned char)(gpos | (gsize << 2));
+}
+
+template <int BS, int SPAN_MAX, int MODE, int U>
+__global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                  const real *__restrict__ aval,
+                                                  const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                  const real *__restrict__ bval,
+                                                  const int *__restrict__ crpt, int *__restrict__ ccol,
+                                                  real *__restrict__ cval,
+                                                  const int *__restrict__ row_perm,
+                                                  const int *__restrict__ row_maxb,
+                                                  const int *__restrict__ row_lo,
+                                                  const int *__restrict__ row_span, int bin_off,
+                                                  int bin_size, int bnnz,
+                                                  const int *__restrict__ bm_off,
+                                                  const unsigned int *__restrict__ bm,
+                                                  const unsigned char *__restrict__ grp,
+                                                  const unsigned char *__restrict__ btwin,
+                                                  unsigned long long *__restrict__ prof)
+{
+    // MODE 1: full call (structure = the column bitmap k_sym_dense wrote); MODE 2: numeric-only re-run
+    // (structure = C.col, the bitmap is rebuilt from it).
+    // prof != nullptr (NSPARSE_BLK_PROF=1): thread 0 of every group head adds the shader-clock cycles of
+    // its phases to its slots prof[8 * block + 0..4] (meta, park loads, run building, walk, emission;
+    // [6] = 1 per group, [7] = rows)
+    unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0;
+    auto stamp = [&](int phase) {
+        if (prof && threadIdx.x == 0) {
+            const unsigned long long t = __builtin_readcyclecounter();
+            prof[8ull * blockIdx.x + phase] += t - t_prev;
+            t_prev = t;
+        }
+    };
+    constexpr int NW = BS / 64;
+    constexpr int PARK = BS < 256 ? BS : 256;  // A entries parked per batch
+    constexpr int NWORDS = SPAN_MAX / 32 + 2;
+    // The accumulators are COMPACT: the value of column c lives at rank(c) = number of columns of the
+    // row below c, read off the bitmap (prefix of the word + popcount inside it).  A row of a
+    // finite-element matrix fills a third of its window (375 of 1215 columns on the cant class), and
+    // the LDS per workgroup is what bounds the rows in flight per CU -- the kernel is bound by the
+    // latency of its dependent loads, i.e. by how many rows are in flight.  Values leave in rank order,
+    // which is the output order: the emission is a straight copy.
+    acc_t *acc = reinterpret_cast<acc_t *>(nsp_dyn_lds);  // RA rows of nzs accumulators
+    __shared__ unsigned int s_bits[NWORDS];
+    __shared__ int s_pre[NWORDS];
+    // run records: x, y, z = first entry of the (up to 3) rows of B, w = length | rows << 21 | leader entry << 23
+    __shared__ int4 s_rec[PARK];
+    __shared__ real s_a[kBlkRows][PARK + 2];  // A values of the parked entries, per row of the group
+    __shared__ int s_wcnt[NW];
+    const int slot = xcd_row_slot(bin_size);
+    if (slot < 0) return;
+    const int rid = row_perm[bin_off + slot];
+    const int gcode = grp ? (int)grp[rid] : (1 << 2);
+    if (gcode & 3) return;  // a follower: its group head computes this row
+    const int RA = gcode >> 2;
+    if (prof && threadIdx.x == 0) {
+        prof[8ull * blockIdx.x + 6] = 1;
+        prof[8ull * blockIdx.x + 7] = (unsigned long long)RA;
+    }
+    const int lo = row_lo[rid];
+    const int span = row_span[rid];
+    int off[kBlkRows], a_beg[kBlkRows];
+#pragma unroll
+    for (int r = 0; r < kBlkRows; r++) {
+        off[r] = r < RA ? crpt[rid + r] : 0;
+        a_beg[r] = r < RA ? arpt[rid + r] : 0;
+    }
+    const int nz = crpt[rid + 1] - off[0];
+    const int nzs = ((nz + 7) >> 3) << 3;  // the number k_twin_groups sized the group with
+    const int alen = arpt[rid + 1] - a_beg[0];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nw = (span + 31) >> 5;
+    const int maxb = row_maxb[rid];
+    if (MODE == 1) {
+        const unsigned int *bits = bm + bm_off[rid];
+        for (int i = threadIdx.x; i < nw; i += BS) s_bits[i] = bits[i];
+    } else {
+        for (int i = threadIdx.x; i < nw; i += BS) s_bits[i] = 0;
+        __syncthreads();
+        for (int p = threadIdx.x; p < nz; p += BS) {
+            const int idx = ccol[off[0] + p] - lo;
+            atomicOr(&s_bits[idx >> 5], 1u << (idx & 31));
+        }
+    }
+    for (int i = threadIdx.x; i < RA * nzs; i += BS) acc[i] = 0;
+    const int G = lean_group(maxb, 3);
+    const int lg = 31 - __clz(G);
+    const int gid = (int)threadIdx.x >> lg, gl = (int)threadIdx.x & (G - 1);
+    const int NG = BS >> lg;
+    if (prof) { __syncthreads(); stamp(0); }
+
+    for (int a0 = 0; a0 < alen; a0 += PARK) {
+        // ---- park up to PARK entries of A and cut them into runs ---------------------------------
+        const int j = a0 + (int)threadIdx.x;
+        const bool valid = j < alen && (int)threadIdx.x < PARK;
+        int c = -2, kb = 0, ke = 0;
+        bool tw = false;
+        if (valid) {
+            c = __builtin_nontemporal_load(acol + a_beg[0] + j);
+            struct __attribute__((aligned(4))) I2 {
+                int b, e;
+            };
+            const I2 rr = *reinterpret_cast<const I2 *>(brpt + c);
+            kb = rr.b, ke = rr.e;
+            tw = btwin != nullptr && btwin[c] != 0;
+        }
+#pragma unroll
+        for (int r = 0; r < kBlkRows; r++)
+            if (r < RA && (int)threadIdx.x < PARK)
+                s_a[r][threadIdx.x] = valid ? __builtin_nontemporal_load(aval + a_beg[r] + j) : (real)0;
+        const int cprev = __shfl_up(c, 1);
+        // entry j continues the run of entry j - 1 when its row of B is the twin of that one's (same
+        // columns, hence same length) and directly follows it; runs never cross a wavefront
+        const bool head = !(lane > 0 && tw && c == cprev + 1);
+        const unsigned long long hm = __ballot(head || !valid);
+        const unsigned long long vm = __ballot(valid);
+        const int nvalid = __popcll(vm);  // valid lanes are a prefix
+        const unsigned long long below = hm & ((2ull << lane) - 1ull);
+        const int h = 63 - __clzll((long long)below);  // lane 0 is always a head
+        const int pos = lane - h;
+        const int d = pos % kBlkRun;
+        const bool leader = valid && d == 0;
+        const unsigned long long lm = __ballot(leader);
+        const unsigned long long above = lane < 63 ? hm >> (lane + 1) : 0ull;
+        int end = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+        end = end < nvalid ? end : nvalid;
+        int nB = end - lane;
+        nB = nB > kBlkRun ? kBlkRun : nB;
+        if (lane == 0) s_wcnt[wv] = __popcll(lm);
+        __syncthreads();  // also: bitmap in LDS, accumulators cleared, s_a written
+        stamp(1);
+        if (a0 == 0 && wv == NW - 1) {
+            // exclusive prefix of the word popcounts: the last wavefront (it parks the fewest entries)
+            int carry = 0;
+            for (int b0 = 0; b0 < nw; b0 += 64) {
+                const int v = b0 + lane < nw ? __popc(s_bits[b0 + lane]) : 0;
+                const int inc = wave_incl_scan(v);
+                if (b0 + lane < nw) s_pre[b0 + lane] = carry + inc - v;
+                carry += __shfl(inc, 63);
+            }
+        }
+        int wbase = 0, nruns = 0;
+#pragma unroll
+        for (int u = 0; u < NW; u++) {
+            wbase += u < wv ? s_wcnt[u] : 0;
+            nruns += s_wcnt[u];
+        }
+        if (valid) {
+            const int my_run = wbase + __popcll(lm & ((2ull << lane) - 1ull)) - 1;
+            reinterpret_cast<int *>(&s_rec[my_run])[d] = kb;
+            if (leader) s_rec[my_run].w = (ke - kb) | (nB << 21) | ((int)threadIdx.x << 23);
+        }
+        __syncthreads();
+        stamp(2);
+
+        // ---- walk: the (run, chunk) pairs of the batch are one flat task list; group q takes a
+        // contiguous stretch of it, U tasks in flight (their loads issued before the first is added) ----
+        const int nch = (maxb + G - 1) >> lg;  // chunks per run, by the longest row of B this C row meets
+        const int ntask = nruns * nch;
+        const int per = (ntask + NG - 1) / NG;
+        const int t0 = gid * per;
+        const int t1 = t0 + per < ntask ? t0 + per : ntask;
+        int u = t0 / nch, ch = t0 - u * nch;
+        for (int tb = t0; tb < t1; tb += U) {
+            int col[U], meta[U];
+            real v[kBlkRun][U];
+            bool ok[U];
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                const bool live = tb + i < t1;
+                const int4 rec = s_rec[live ? u : 0];
+                const int len = rec.w & 0x1fffff;
+                const int nb = (rec.w >> 21) & 3;
+                const int p = gl + (ch << lg);
+                ok[i] = live && p < len;
+                meta[i] = rec.w;
+                const unsigned idx = ok[i] ? (unsigned)p : 0u;  // masked lanes re-read entry 0 of the run
+                const unsigned k0 = len > 0 ? (unsigned)rec.x : 0u;  // an empty row may start at the very end
+                col[i] = bcol[k0 + idx];
+                v[0][i] = bval[k0 + idx];
+                v[1][i] = nb > 1 ? bval[(unsigned)rec.y + idx] : (real)0;
+                v[2][i] = nb > 2 ? bval[(unsigned)rec.z + idx] : (real)0;
+                ch++;
+                if (ch == nch) {
+                    ch = 0;
+                    u++;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < U; i++) {
+                if (ok[i]) {
+                    const int nb = (meta[i] >> 21) & 3;
+                    const int j0 = (int)((unsigned)meta[i] >> 23);
+                    const int idx = col[i] - lo;
+                    const int rank = s_pre[idx >> 5] + __popc(s_bits[idx >> 5] & ((1u << (idx & 31)) - 1u));
+#pragma unroll
+                    for (int r = 0; r < kBlkRows; r++) {
+                        if (r < RA) {
+                            acc_t sum = (acc_t)(s_a[r][j0] * v[0][i]);
+                            if (nb > 1) sum += (acc_t)(s_a[r][j0 + 1] * v[1][i]);
+                            if (nb > 2) sum += (acc_t)(s_a[r][j0 + 2] * v[2][i]);
+                            unsafeAtomicAdd(acc + r * nzs + rank, sum);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        stamp(3);
+    }
+
+    // ---- emission: values are in output order already; columns are read off the bitmap ------------
+    for (int r = 0; r < RA; r++)
+        for (int k = threadIdx.x; k < nz; k += BS) cval[off[r] + k] = (real)acc[r * nzs + k];
+    if (MODE == 1) {
+        for (int idx = threadIdx.x; idx < span; idx += BS) {
+            const unsigned int wbits = s_bits[idx >> 5];
+            if ((wbits >> (idx & 31)) & 1u) {
+                const int rank = s_pre[idx >> 5] + __popc(wbits & ((1u << (idx & 31)) - 1u));
+                for (int r = 0; r < RA; r++) ccol[off[r] + rank] = lo + idx;
+            }
+        }
+    }
+    if (prof) { __syncthreads(); stamp(4); }
+}
+
+}  // namespace spgemm
+}  // namespace nsp

@@ -102,8 +102,12 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
                                                 int K, BInfo *__restrict__ info, BinState *bs,
                                                 int *__restrict__ long_list, int *long_cnt, int long_len,
                                                 const int *__restrict__ todo,
-                                                const unsigned int *__restrict__ range)
+                                                const unsigned int *__restrict__ range,
+                                                unsigned char *__restrict__ btwin)
 {
+    // btwin != nullptr: btwin[r] = 1 when row r of B has exactly the column pattern of row r - 1 (the
+    // degrees of freedom of one mesh node): the numeric window kernel then treats consecutive A entries
+    // that point at such rows as one run (block.h).  Long rows (second pass) are never marked.
     // W lanes per row of B (W from the average row length, so the column loads coalesce).
     // todo == nullptr: bulk pass over all rows (over the rows k_col_range found when range is
     // given); rows longer than long_len are deferred to long_list.  todo != nullptr: pass over
@@ -133,10 +137,16 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
             if (ok) long_list[idx] = r;
         }
         const bool defer = __shfl(ok, 0, W) != 0;
+        int differs = 1;
         if (r >= 0 && !defer) {
+            const int len = e - b;
+            // candidate twin of the row before: same length (that row ends where this one starts)
+            const bool cand = btwin && !todo && r > 0 && len > 0 && b - brpt[r - 1] == len;
+            differs = cand ? 0 : 1;
             for (int k = b + lane; k < e; k += W) {
                 const int c = bcol[k];
                 if (k > b) bad |= c <= bcol[k - 1];  // strictly ascending?  (neighbour is in cache)
+                if (cand) differs |= bcol[k - len] != c;
                 lo = c < lo ? c : lo;
                 hi = c > hi ? c : hi;
             }
@@ -144,11 +154,13 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
 #pragma unroll
         for (int o = W / 2; o >= 1; o >>= 1) {
             const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o);
+            differs |= __shfl_xor(differs, o);
             lo = l < lo ? l : lo;
             hi = h > hi ? h : hi;
         }
         if (bad) atomicOr(&bs->b_unsorted, 1);
         if (r >= 0 && !defer && lane == 0) {
+            if (btwin) btwin[r] = differs == 0 ? 1 : 0;
             BInfo o;
             o.start = b;
             o.len = e - b;
@@ -466,8 +478,11 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
                                                      const int *__restrict__ span,
                                                      const int *__restrict__ work, int M, Thr thr,
                                                      BinState *bs, int *__restrict__ perm,
-                                                     const unsigned char *__restrict__ skip)
+                                                     const unsigned char *__restrict__ skip, int skip_mask)
 {
+    // skip: rows left out of the lists -- twin rows in the symbolic phase (mask 0xff), rows that follow
+    // a group head in the numeric phase (grp, mask 3).  hist counts every row; cursor[bin] ends as the
+    // number of rows actually listed.
     __shared__ int s_cnt[NB];
     __shared__ int s_base[NB];
     __shared__ int s_span[NB];
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(const int *__restrict__ n,
         const int i = (blockIdx.x * RPT + k) * 1024 + threadIdx.x;
         b[k] = -1;
         r[k] = 0;
-        in[k] = i < M && !(skip && skip[i]);  // skip: twin rows (symbolic phase)
+        in[k] = i < M && !(skip && (skip[i] & skip_mask));
         if (in[k]) {
             const int ni = n[i];
             b[k] = bin_of(ni, span[i], thr, work ? work[i] : ni);

@@ -44,6 +44,7 @@
 //   spgemm/symbolic.h      k_sym_small, k_sym_tb, k_sym_global            (bins 0-5)
 //   spgemm/numeric.h       k_num_small, k_num_tb, k_num_global            (bins 0-4, fallback)
 //   spgemm/window.h        k_sym_dense, k_sym_bits, k_num_dense           (bins 6-10)
+//   spgemm/block.h         k_num_block, k_twin_groups                     (numeric bins 6-8: node blocks)
 //   spgemm/heavy_tiled.h   k_num_tiled                                    (bin 5, dense tiles)
 //   spgemm/heavy_ranked.h  k_num_ranked                                   (bin 5, thin rows)
 //
@@ -56,6 +57,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "internal.h"
 #include "spgemm/common.h"
@@ -63,6 +65,7 @@
 #include "spgemm/symbolic.h"
 #include "spgemm/numeric.h"
 #include "spgemm/window.h"
+#include "spgemm/block.h"
 #include "spgemm/heavy_tiled.h"
 #include "spgemm/heavy_ranked.h"
 
@@ -430,7 +433,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                                  const int *hist_in, int max_nz, BinState *d_bs, Context &cx,
                                  float *ms_bin, int write_col, const int *bm_off,
                                  const unsigned int *bm, int max_alen, bool b_sorted,
-                                 const int *max_span)
+                                 const int *max_span, const unsigned char *grp, const unsigned char *btwin,
+                                 const int *listed)
 {
     int hist[NB], off[NB + 1];
     fold_small_hash_bins(hist_in, hist, off);
@@ -452,6 +456,14 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // taking the wide rows there is no limit
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
                            (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
+    constexpr int kBlkU = 6;  // tasks in flight per lane in the node-block kernel
+    static const int blk_prof_on = getenv("NSPARSE_BLK_PROF") ? atoi(getenv("NSPARSE_BLK_PROF")) : 0;
+    unsigned long long *blk_prof = nullptr;
+    if (blk_prof_on) {
+        blk_prof = (unsigned long long *)dev_alloc(8 * sizeof(unsigned long long) * (size_t)(a->M + 8));
+        NSP_CHECK(hipMemsetAsync(blk_prof, 0, 8 * sizeof(unsigned long long) * (size_t)(a->M + 8), cx.stream[0]));
+        NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
+    }
     // launch order: the heavy bin, then the bin with the most rows (main stream), then the rest
     // biggest rows first (see symbolic_phase)
     for (int pass = 0; pass < 3; pass++) {
@@ -525,27 +537,55 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
+#define NSP_NUM_DENSE_GO(BS, SPAN, MODEX)                                                       \
+    {                                                                                          \
+        static bool big_ok = false;                                                            \
+        allow_big_lds(k_num_dense<BS, SPAN, MODEX, false>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
+        hipLaunchKernelGGL((k_num_dense<BS, SPAN, MODEX, false>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), \
+                           lds, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,      \
+                           c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[bin_],  \
+                           hist[bin_], b->nnz, bm_off, bm, 0);                                 \
+    }
+#define NSP_NUM_BLOCK_GO(BS, SPAN, MODEX)                                                       \
+    {                                                                                          \
+        static bool big_ok = false;                                                            \
+        allow_big_lds(k_num_block<BS, SPAN, MODEX, kBlkU>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
+        /* followers of a group head are not listed (k_bin_scatter): listed[bin] heads */        \
+        const int heads = grp ? listed[bin_] : hist[bin_];                                     \
+        hipLaunchKernelGGL((k_num_block<BS, SPAN, MODEX, kBlkU>), dim3(8 * ceil_div(heads, 8)), dim3(BS), \
+                           lds_blk, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
+                           c->d_val, row_perm, row_maxb, row_lo, row_span, off[bin_],            \
+                           heads, b->nnz, bm_off, bm, grp, btwin, blk_prof);                   \
+    }
 #define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
-    if (hist[BIN] > 0 && now(BIN)) {                                                                       \
+    if (hist[BIN] > 0 && now(BIN)) {                                                           \
+        constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        static bool big_ok1 = false, big_ok2 = false;                                          \
-        allow_big_lds(k_num_dense<BS, SPAN, 1>, big_ok1, (int)sizeof(acc_t) * (SPAN + 64));     \
-        allow_big_lds(k_num_dense<BS, SPAN, 2>, big_ok2, (int)sizeof(acc_t) * (SPAN + 64));     \
         const int span_b = max_span[BIN] < SPAN ? max_span[BIN] : SPAN;                        \
-        const size_t lds = sizeof(acc_t) * (size_t)((span_b + 63) / 64 * 64 + 8);               \
-        if (write_col & 1)                                                                     \
-            hipLaunchKernelGGL((k_num_dense<BS, SPAN, 1>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
-                               lds, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
-                               c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[BIN],       \
-                               hist[BIN], b->nnz, bm_off, bm);                                 \
-        else                                                                                   \
-            hipLaunchKernelGGL((k_num_dense<BS, SPAN, 2>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), \
-                               lds, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
-                               c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[BIN],       \
-                               hist[BIN], b->nnz, bm_off, bm);                                 \
+        const int stride_b = (span_b + 63) / 64 * 64 + 8;                                      \
+        const size_t lds = sizeof(acc_t) * (size_t)stride_b;                                   \
+        /* node-block kernel (block.h): compact accumulators, nnz of the row each, up to kBlkRows rows */ \
+        const int nz1 = ((max_nz < span_b ? max_nz : span_b) + 7) / 8 * 8 + 8;                 \
+        int blk_elems = nz1;  /* any group satisfies rows * own nnz <= min(budget, 3 * longest row) */ \
+        if (grp) {                                                                             \
+            const int want = kBlkRows * nz1 < kBlkAccElems ? kBlkRows * nz1 : kBlkAccElems;    \
+            blk_elems = want > nz1 ? want : nz1;                                               \
+        }                                                                                      \
+        const size_t lds_blk = sizeof(acc_t) * (size_t)blk_elems;                              \
+        if (lean_on && (grp || blk_all)) {                                                     \
+            if (write_col & 1) NSP_NUM_BLOCK_GO(BS, SPAN, 1) else NSP_NUM_BLOCK_GO(BS, SPAN, 2) \
+        } else {                                                                               \
+            if (write_col & 1) NSP_NUM_DENSE_GO(BS, SPAN, 1) else NSP_NUM_DENSE_GO(BS, SPAN, 2) \
+        }                                                                                      \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
+    // node-block numeric window kernel (block.h) for matrices with twin rows (grp != nullptr); rows of
+    // matrices without that structure are one-row groups with one-entry runs, which the first kernel
+    // (window.h: four entries per lane and step) walks in fewer instructions: cant-class irregular
+    // stand-in 0.42 ms against 0.63.  NSPARSE_LEAN=0: always the first kernel; =2: always the block one.
+    static const bool lean_on = !(getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0);
+    static const bool blk_all = getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 2;
     static const int tune_nd6 = getenv("NSPARSE_NUMD6_BS") ? atoi(getenv("NSPARSE_NUMD6_BS")) : 256;
     static const int tune_nd8 = getenv("NSPARSE_NUMD8_BS") ? atoi(getenv("NSPARSE_NUMD8_BS")) : 512;
     if (tune_nd8 == 256) { NSP_NUM_DENSE(8, 256, 12288) } else { NSP_NUM_DENSE(8, 512, 12288) }
@@ -568,6 +608,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     }
     }  // pass
 #undef NSP_NUM_DENSE
+#undef NSP_NUM_DENSE_GO
+#undef NSP_NUM_BLOCK_GO
 #undef NSP_NUM_TB
     // rows beyond the LDS tables without the tile kernels (unsorted B, or switched off): global
     // table + segmented sort; synchronises on the host (scratch freed here), hence last
@@ -610,6 +652,17 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         dev_free(kslab);
     }
     L.join();
+    if (blk_prof) {
+        NSP_CHECK(hipDeviceSynchronize());
+        std::vector<unsigned long long> hb(8 * (size_t)(a->M + 8));
+        NSP_CHECK(hipMemcpy(hb.data(), blk_prof, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        unsigned long long h[8] = {};
+        for (size_t i = 0; i < hb.size(); i++) h[i & 7] += hb[i];
+        const double g = h[6] ? (double)h[6] : 1.0;
+        fprintf(stderr, "[blk] groups %llu rows %llu | cycles per group: meta %.0f clear+park-loads %.0f runs %.0f walk %.0f emit %.0f\n",
+                h[6], h[7], h[0] / g, h[1] / g, h[2] / g, h[3] / g, h[4] / g);
+        dev_free(blk_prof);
+    }
     return L;
 }
 
@@ -632,6 +685,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     if (a->M <= 0 || a->nnz <= 0 || b->nnz <= 0 || b->M <= 0) {
         // nothing to multiply: C has a->M empty rows (zero-size grids are not launchable)
         memset(&g_stats.s, 0, sizeof(g_stats.s));
+        g_stats.s.sym_bin_size[0] = g_stats.s.num_bin_size[0] = a->M > 0 ? a->M : 0;  // every row: nothing to do
         if (!numeric_only) {
             const int M0 = a->M > 0 ? a->M : 0;
             c->M = M0;
@@ -663,6 +717,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 
     void *scan_tmp = nullptr;
     unsigned int *bm = nullptr;
+    unsigned char *grp = nullptr;
     BinLauncher sym_used(cx, 0);
     int *row_prod = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_nz = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
@@ -686,6 +741,11 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     static_assert(2 * sizeof(BinState) <= 240 * sizeof(int), "counter blocks end before long_cnt");
     NSP_CHECK(hipMemsetAsync(cx.d_scratch, 0, 244 * sizeof(int), s0));
 
+    // rows of B with the column pattern of the row before them (k_b_info): runs of the numeric
+    // window kernel (block.h).  NSPARSE_TWINS=0 switches the whole twin machinery off.
+    static const bool twins_on = !(getenv("NSPARSE_TWINS") && atoi(getenv("NSPARSE_TWINS")) == 0);
+    static const bool lean_on = !(getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0);
+    unsigned char *btwin = (twins_on && lean_on && K > 1) ? (unsigned char *)dev_alloc((size_t)K) : nullptr;
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
     {
         const int wb = pick_w_regular(b->nnz, K, b->nnz_max);
@@ -709,7 +769,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 #define NSP_BI(W)                                                                              \
     case W:                                                                                    \
         hipLaunchKernelGGL(k_b_info<W>, dim3(gb), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym, \
-                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range);     \
+                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range, btwin); \
         break;
         switch (wb) {
             NSP_BI(1) NSP_BI(2) NSP_BI(4) NSP_BI(8) NSP_BI(16) NSP_BI(32) NSP_BI(64)
@@ -717,7 +777,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 #undef NSP_BI
         if (blist)
             hipLaunchKernelGGL(k_b_info<64>, dim3(256), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym,
-                               (int *)nullptr, long_cnt, 0, (const int *)long_list, (const unsigned int *)nullptr);
+                               (int *)nullptr, long_cnt, 0, (const int *)long_list, (const unsigned int *)nullptr, btwin);
         if (range_part) dev_free(range_part);  // stream-ordered reuse, see scan_exclusive
     }
     long long *partial = (long long *)dev_alloc(sizeof(long long) * kPartialStride * kSetupMaxGrid);
@@ -728,7 +788,6 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
     // rows that repeat the column pattern of the row before them are not run through the symbolic
     // phase: they take that row's result (k_twin_copy).  NSPARSE_TWINS=0 switches the detection off.
-    static const bool twins_on = !(getenv("NSPARSE_TWINS") && atoi(getenv("NSPARSE_TWINS")) == 0);
     unsigned char *twin = (!numeric_only && twins_on && M > 1) ? (unsigned char *)dev_alloc((size_t)M) : nullptr;
     launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
                         use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, twin, s0);
@@ -738,10 +797,10 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     if (!numeric_only) {
         if (M >= (1 << 18))
             hipLaunchKernelGGL(k_bin_scatter<4>, dim3(ceil_div(M, 4096)), dim3(1024), 0, s0, row_prod, row_span,
-                               (const int *)nullptr, M, sym_thr, d_sym, row_perm, (const unsigned char *)twin);
+                               (const int *)nullptr, M, sym_thr, d_sym, row_perm, (const unsigned char *)twin, 0xff);
         else
             hipLaunchKernelGGL(k_bin_scatter<1>, dim3(grid_m), dim3(1024), 0, s0, row_prod, row_span,
-                               (const int *)nullptr, M, sym_thr, d_sym, row_perm, (const unsigned char *)twin);
+                               (const int *)nullptr, M, sym_thr, d_sym, row_perm, (const unsigned char *)twin, 0xff);
         NSP_LAUNCH_CHECK();
     }
     {
@@ -779,6 +838,14 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                                    row_nz, row_span_num, bm ? bm_off : (int *)nullptr);
                 NSP_LAUNCH_CHECK();
             }
+            // groups of twin rows for the numeric window kernel: worth their LDS only when a good share
+            // of the rows has a twin (a finite-element matrix), not for a few chance repeats
+            if (lean_on && bm && (long long)S.twin_rows * 8 >= M) {
+                grp = (unsigned char *)dev_alloc((size_t)M);
+                hipLaunchKernelGGL(k_twin_groups, dim3(ceil_div(M, 256)), dim3(256), 0, s0, (const unsigned char *)twin,
+                                   (const int *)row_span_num, (const int *)row_nz, (const int *)row_prod, num_thr, M, grp);
+                NSP_LAUNCH_CHECK();
+            }
         }
         c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
         scan_tmp = scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
@@ -798,10 +865,10 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                        (const int *)row_prod, M, num_thr, d_num);
     if (M >= (1 << 18))
         hipLaunchKernelGGL(k_bin_scatter<4>, dim3(ceil_div(M, 4096)), dim3(1024), 0, s0, row_nz, num_span,
-                           (const int *)row_prod, M, num_thr, d_num, row_perm, (const unsigned char *)nullptr);
+                           (const int *)row_prod, M, num_thr, d_num, row_perm, (const unsigned char *)grp, 3);
     else
         hipLaunchKernelGGL(k_bin_scatter<1>, dim3(grid_m), dim3(1024), 0, s0, row_nz, num_span,
-                           (const int *)row_prod, M, num_thr, d_num, row_perm, (const unsigned char *)nullptr);
+                           (const int *)row_prod, M, num_thr, d_num, row_perm, (const unsigned char *)grp, 3);
     NSP_LAUNCH_CHECK();
     {
         const int seq = ++cx.seq;
@@ -829,7 +896,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_maxb, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
-                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span);
+                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor);
     tm.mark(3, s0);
     {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
         const int seq = ++cx.seq;
@@ -858,6 +925,8 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     dev_free(bm);
     dev_free(bm_scan_tmp);
     if (twin) dev_free(twin);
+    if (grp) dev_free(grp);
+    if (btwin) dev_free(btwin);
     dev_free(row_span_num);
     dev_free(bm_off);
     dev_free(bm_words);

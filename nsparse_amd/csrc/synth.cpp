@@ -150,7 +150,7 @@ void gen_powerlaw(sfCSR *mat, long long n, long long target_nnz, unsigned long l
 
 // "cant class, irregular" (kind 5): the same nx*ny*nz brick of 3-dof nodes as kind 0, but
 //   * the unknowns are renumbered by a pseudo-random permutation inside consecutive blocks of
-//     `blk` unknowns (symmetric: P A P^T), so the rows of one node are no longer neighbours, the
+//     `blk` unknowns = three mesh planes (symmetric: P A P^T), so the rows of one node are no longer neighbours, the
 //     column window of a C row is no longer the 5 planes a natural ordering gives, and rows with
 //     the same column pattern are not adjacent;
 //   * node couplings are dropped (symmetrically, all 3 x 3 dof at once) with probability `drop`,
@@ -164,7 +164,7 @@ void gen_brick_shuffled(sfCSR *mat, long long nx, long long ny, long long nz, un
     const long long nodes = nx * ny * nz, Mfull = nodes * dof;
     if (re <= 0 || re > Mfull) re = Mfull;
     if (rb < 0) rb = 0;
-    const long long blk = 2 * dof * nx * ny;  // two planes of unknowns
+    const long long blk = 3 * dof * nx * ny;  // three planes of unknowns
     const unsigned long long drop_thr = (unsigned long long)(0.074 * 18446744073709551615.0);
     // new_of[old] / old_of[new]: permutation inside each block, by sorting hash keys
     std::vector<int> new_of((size_t)Mfull), old_of((size_t)Mfull);

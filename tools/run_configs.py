@@ -30,6 +30,8 @@ CASES = {
     "rmat22_2": ("d", 3, (22, 2, 0)),
     "rmat22_16": ("d", 3, (22, 16, 0)),
     "cant": ("d", 0, (9, 9, 257)),
+    "cant_irr": ("d", 5, (9, 9, 257)),   # irregular cant class: renumbered inside bands, couplings dropped
+    "webbase1m": ("s", 4, (1000005, 3105536, 0)),  # webbase-1M statistics (config 3)
     "cant_s": ("s", 0, (9, 9, 257)),
     "stencil": ("d", 1, (100, 100, 100)),
     "brick20": ("d", 0, (20, 20, 60)),    # wider cross-section: numeric window 2.4 K columns (bin 7)
