@@ -118,7 +118,9 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
     __shared__ int s_pre[NWORDS];
     // run records: x, y, z = first entry of the (up to 3) rows of B, w = length | rows << 21 | leader entry << 23
     __shared__ int4 s_rec[PARK];
-    __shared__ real s_a[kBlkRows][PARK + 2];  // A values of the parked entries, per row of the group
+    // A values of the parked entries, [entry][row of the group]: the 3 x 3 values of a run are 9 consecutive
+    // words, read back to back without conditions (the values of B are zero for the rows a run lacks)
+    __shared__ real s_a[(PARK + 2) * kBlkRows];
     __shared__ int s_wcnt[NW];
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
@@ -179,8 +181,9 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
         }
 #pragma unroll
         for (int r = 0; r < kBlkRows; r++)
-            if (r < RA && (int)threadIdx.x < PARK)
-                s_a[r][threadIdx.x] = valid ? __builtin_nontemporal_load(aval + a_beg[r] + j) : (real)0;
+            if ((int)threadIdx.x < PARK)
+                s_a[threadIdx.x * kBlkRows + r] = (valid && r < RA) ? __builtin_nontemporal_load(aval + a_beg[r] + j) : (real)0;
+        if (threadIdx.x < 2 * kBlkRows) s_a[PARK * kBlkRows + threadIdx.x] = 0;  // what a run at the very end reads past
         const int cprev = __shfl_up(c, 1);
         // entry j continues the run of entry j - 1 when its row of B is the twin of that one's (same
         // columns, hence same length) and directly follows it; runs never cross a wavefront
@@ -262,16 +265,20 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
 #pragma unroll
             for (int i = 0; i < U; i++) {
                 if (ok[i]) {
-                    const int nb = (meta[i] >> 21) & 3;
                     const int j0 = (int)((unsigned)meta[i] >> 23);
                     const int idx = col[i] - lo;
                     const int rank = s_pre[idx >> 5] + __popc(s_bits[idx >> 5] & ((1u << (idx & 31)) - 1u));
+                    real a[kBlkRun][kBlkRows];
+#pragma unroll
+                    for (int dd = 0; dd < kBlkRun; dd++)
+#pragma unroll
+                        for (int r = 0; r < kBlkRows; r++) a[dd][r] = s_a[(j0 + dd) * kBlkRows + r];
 #pragma unroll
                     for (int r = 0; r < kBlkRows; r++) {
                         if (r < RA) {
-                            acc_t sum = (acc_t)(s_a[r][j0] * v[0][i]);
-                            if (nb > 1) sum += (acc_t)(s_a[r][j0 + 1] * v[1][i]);
-                            if (nb > 2) sum += (acc_t)(s_a[r][j0 + 2] * v[2][i]);
+                            acc_t sum = (acc_t)(a[0][r] * v[0][i]);
+                            sum += (acc_t)(a[1][r] * v[1][i]);  // v is zero for the rows the run lacks
+                            sum += (acc_t)(a[2][r] * v[2][i]);
                             unsafeAtomicAdd(acc + r * nzs + rank, sum);
                         }
                     }

@@ -456,7 +456,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // taking the wide rows there is no limit
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
                            (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
-    constexpr int kBlkU = 6;  // tasks in flight per lane in the node-block kernel
+    constexpr int kBlkU = 4;  // tasks in flight per lane in the node-block kernel
     static const int blk_prof_on = getenv("NSPARSE_BLK_PROF") ? atoi(getenv("NSPARSE_BLK_PROF")) : 0;
     unsigned long long *blk_prof = nullptr;
     if (blk_prof_on) {
@@ -539,9 +539,11 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     }
 #define NSP_NUM_DENSE_GO(BS, SPAN, MODEX)                                                       \
     {                                                                                          \
+        /* the first kernel keeps at most two bitmap words per lane: widest windows need 512 threads */ \
+        constexpr int BSO = (SPAN / (BS / 64) + 2047) / 2048 <= 2 ? BS : 512;                  \
         static bool big_ok = false;                                                            \
-        allow_big_lds(k_num_dense<BS, SPAN, MODEX, false>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
-        hipLaunchKernelGGL((k_num_dense<BS, SPAN, MODEX, false>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), \
+        allow_big_lds(k_num_dense<BSO, SPAN, MODEX, false>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
+        hipLaunchKernelGGL((k_num_dense<BSO, SPAN, MODEX, false>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BSO), \
                            lds, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,      \
                            c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[bin_],  \
                            hist[bin_], b->nnz, bm_off, bm, 0);                                 \
@@ -586,11 +588,19 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // stand-in 0.42 ms against 0.63.  NSPARSE_LEAN=0: always the first kernel; =2: always the block one.
     static const bool lean_on = !(getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0);
     static const bool blk_all = getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 2;
-    static const int tune_nd6 = getenv("NSPARSE_NUMD6_BS") ? atoi(getenv("NSPARSE_NUMD6_BS")) : 256;
-    static const int tune_nd8 = getenv("NSPARSE_NUMD8_BS") ? atoi(getenv("NSPARSE_NUMD8_BS")) : 512;
-    if (tune_nd8 == 256) { NSP_NUM_DENSE(8, 256, 12288) } else { NSP_NUM_DENSE(8, 512, 12288) }
-    NSP_NUM_DENSE(7, 256, 4096)
-    if (tune_nd6 == 128) { NSP_NUM_DENSE(6, 128, 1536) } else if (tune_nd6 == 512) { NSP_NUM_DENSE(6, 512, 1536) } else { NSP_NUM_DENSE(6, 256, 1536) }
+    // workgroup sizes of the window bins: the node-block kernel is bound by the latency of its dependent
+    // loads, i.e. by the groups in flight per CU, and does best with 128 threads per group (cant class:
+    // 64 / 128 / 256 / 512 threads -> 0.240 / 0.197 / 0.216 / 0.41 ms); the first kernel keeps 256 / 256 / 512
+    const bool blk = lean_on && (grp || blk_all);
+    static const int env_nd6 = getenv("NSPARSE_NUMD6_BS") ? atoi(getenv("NSPARSE_NUMD6_BS")) : 0;
+    static const int env_nd7 = getenv("NSPARSE_NUMD7_BS") ? atoi(getenv("NSPARSE_NUMD7_BS")) : 0;
+    static const int env_nd8 = getenv("NSPARSE_NUMD8_BS") ? atoi(getenv("NSPARSE_NUMD8_BS")) : 0;
+    const int tune_nd6 = env_nd6 ? env_nd6 : (blk ? 128 : 256);
+    const int tune_nd7 = env_nd7 ? env_nd7 : (blk ? 128 : 256);
+    const int tune_nd8 = env_nd8 ? env_nd8 : (blk ? 128 : 512);
+    if (tune_nd8 == 128) { NSP_NUM_DENSE(8, 128, 12288) } else if (tune_nd8 == 256) { NSP_NUM_DENSE(8, 256, 12288) } else { NSP_NUM_DENSE(8, 512, 12288) }
+    if (tune_nd7 == 128) { NSP_NUM_DENSE(7, 128, 4096) } else { NSP_NUM_DENSE(7, 256, 4096) }
+    if (tune_nd6 == 128) { NSP_NUM_DENSE(6, 128, 1536) } else if (tune_nd6 == 64) { NSP_NUM_DENSE(6, 64, 1536) } else if (tune_nd6 == 512) { NSP_NUM_DENSE(6, 512, 1536) } else { NSP_NUM_DENSE(6, 256, 1536) }
     static const int tune_n2 = getenv("NSPARSE_NUM2_BS") ? atoi(getenv("NSPARSE_NUM2_BS")) : 256;
     static const int tune_n1 = getenv("NSPARSE_NUM1_BS") ? atoi(getenv("NSPARSE_NUM1_BS")) : 64;
     NSP_NUM_TB(4, 1024, 8192, 8192)
