@@ -439,6 +439,88 @@ __device__ __forceinline__ void ht_insert_vec(int *tab, int mask, const IVecT<V>
 }
 
 
+// ---- wave-cooperative probing (BASELINE north_star: "wavefront-wide linear probing using ds_bpermute /
+// ballot") ---------------------------------------------------------------------------------------
+// One key at a time, all the lanes that are active inspect consecutive slots of its probe sequence:
+// lane with rank q among the active lanes reads slot h + q; a ballot finds the key or the first empty slot
+// in probe order, the lane that saw the empty slot claims it with one CAS.  NSPARSE_COOP=1: every lane
+// first tries its own keys with one CAS each (as ht_insert_vec) and only the keys that collided are
+// resolved cooperatively, one after the other; NSPARSE_COOP=2: every key is inserted cooperatively.
+// Kept as a measured alternative: with tables at load factor <= 2/3 a probe sequence is two
+// slots long on average, and the cooperative form spends a whole wavefront instruction stream per key.
+__device__ __forceinline__ int ht_coop_one(int *tab, int mask, int key, int h0, int *fresh)
+{
+    const unsigned long long active = __ballot(1);
+    const int nact = __popcll(active);
+    const int lane = (int)(threadIdx.x & 63);
+    const int q = __popcll(active & ((1ull << lane) - 1ull));
+    int base = h0;
+    while (true) {
+        const int s = (base + q) & mask;
+        const int v = lds_load(tab + s);
+        const unsigned long long hit = __ballot(v == key);
+        if (hit) {
+            *fresh = 0;
+            return __builtin_amdgcn_readlane(s, __ffsll((long long)hit) - 1);
+        }
+        const unsigned long long emp = __ballot(v == -1);
+        if (emp) {
+            const int w = __ffsll((long long)emp) - 1;  // active lanes are ranked in lane order: first in probe order
+            int old = -2;
+            if (lane == w) old = atomicCAS(tab + s, -1, key);
+            old = __builtin_amdgcn_readlane(old, w);
+            if (old == -1 || old == key) {
+                *fresh = old == -1;
+                return __builtin_amdgcn_readlane(s, w);
+            }
+            continue;  // another wavefront took that slot meanwhile: look at the same window again
+        }
+        base += nact;
+    }
+}
+
+template <int V>
+__device__ __forceinline__ void ht_insert_vec_coop(int *tab, int mask, const IVecT<V> &k, int n, int (&h)[V],
+                                                   int &fresh, int mode)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    bool pend[V];
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+        h[i] = hash_slot(k.v[i], mask);
+        pend[i] = i < n;
+        if (mode == 1 && i < n) {
+            const int old = atomicCAS(tab + h[i], -1, k.v[i]);
+            fresh += old == -1;
+            pend[i] = old != -1 && old != k.v[i];
+            h[i] = (h[i] + 1) & mask;  // where the cooperative search of a collided key starts
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; i++) {
+        unsigned long long m = __ballot(pend[i]);
+        while (m) {
+            const int L = __ffsll((long long)m) - 1;
+            const int key = __builtin_amdgcn_readlane(k.v[i], L);
+            const int hs = __builtin_amdgcn_readlane(h[i], L);
+            int f;
+            const int slot = ht_coop_one(tab, mask, key, hs, &f);
+            if (lane == L) {
+                h[i] = slot;
+                fresh += f;
+            }
+            m &= m - 1;
+        }
+    }
+    if (mode == 1) {
+        // lanes whose first CAS decided keep h at the slot they used
+#pragma unroll
+        for (int i = 0; i < V; i++)
+            if (i < n && !pend[i]) h[i] = (h[i] - 1) & mask;
+    }
+}
+
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
 // waits for the acknowledgement of every global store issued before it; the tiled kernel
 // emits a tile with global stores nobody in the workgroup reads back, so waiting for them

@@ -263,7 +263,7 @@ __device__ __forceinline__ void bitonic_sort_lds(int *s, int P)
 }
 
 // bins 1..4: one workgroup per row (calculate_value_col_bin_each_tb :829-927).
-template <int BS, int TMAX, int PMAX>
+template <int BS, int TMAX, int PMAX, int COOP = 0>
 __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
                                                const int *__restrict__ acol,
                                                const real *__restrict__ aval,
@@ -308,7 +308,8 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
                                   s_ext, s_av, &s_defer,
                                   [&](const IVec &k, const RVec &v, int n, real sc) {
                                       int h[VW], fresh = 0;
-                                      ht_insert_vec(keys, mask, k, n, h, fresh);
+                                      if (COOP) ht_insert_vec_coop(keys, mask, k, n, h, fresh, COOP);
+                                      else ht_insert_vec(keys, mask, k, n, h, fresh);
 #pragma unroll
                                       for (int i = 0; i < VW; i++)
                                           if (i < n) unsafeAtomicAdd(vals + h[i], (acc_t)(sc * v.v[i]));

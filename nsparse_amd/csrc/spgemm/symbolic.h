@@ -84,7 +84,7 @@ __global__ __launch_bounds__(BS) void k_sym_small(const int *__restrict__ arpt,
 
 // bins 1..5: one workgroup per row (set_row_nz_bin_each_tb :399-472; LARGE = the try-in-LDS
 // kernel with a fail list, set_row_nz_bin_each_tb_large :474-554).
-template <int BS, int TMAX, bool LARGE>
+template <int BS, int TMAX, bool LARGE, int COOP = 0>
 __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                                const int *__restrict__ acol,
                                                const int *__restrict__ brpt,
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                        a_beg, a_end, np, row_maxb[rid], s_ext, (real *)nullptr, &s_defer,
                                        [&](const IVec &k, const RVecT<1> &, int n, real) {
                                            int h[VW];
-                                           ht_insert_vec(tab, mask, k, n, h, cnt);
+                                           if (COOP) ht_insert_vec_coop(tab, mask, k, n, h, cnt, COOP);
+                                           else ht_insert_vec(tab, mask, k, n, h, cnt);
                                        });
     } else {
         // try-in-LDS: plain walk with early exit once the table holds kSymLargeLimit keys

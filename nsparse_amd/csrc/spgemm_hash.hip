@@ -76,6 +76,27 @@ namespace spgemm {
 //  host orchestration
 // ===================================================================================
 
+// Numeric ladder in force.  NSPARSE_NUM_HEAVY_MIN=<n> (experiments): rows with more than n non-zeros go
+// to the heavy bin (cursor kernels, no sort) instead of the LDS hash bins above that size.
+static const Thr &num_ladder()
+{
+    static Thr t = [] {
+        Thr v = kNumThr;
+        const char *e = getenv("NSPARSE_NUM_HEAVY_MIN");
+        if (e && atoi(e) > 0) {
+            const int n = atoi(e);
+            for (int q = 0; q < 4; q++)
+                if (v.hash_t[q] > n) v.hash_t[q] = n;
+        }
+        return v;
+    }();
+    return t;
+}
+
+// NSPARSE_COOP=1 / 2: wave-cooperative probing in the LDS hash bins (common.h: ht_insert_vec_coop), the
+// alternative BASELINE's north_star names; 0 (default): one lane per key.  Measured in DESIGN 4.1.
+static const int g_coop = getenv("NSPARSE_COOP") ? atoi(getenv("NSPARSE_COOP")) : 0;
+
 static void *scan_exclusive(const int *in, int *out, int n, hipStream_t st)
 {
     size_t tmp_bytes = 0;
@@ -307,13 +328,17 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     *fail_rows = 0;
     int *fail_list = nullptr;
     L.fork();
+#define NSP_SYM_TB_GO(BS, TMAX, COOPX)                                                          \
+    hipLaunchKernelGGL((k_sym_tb<BS, TMAX, false, COOPX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, \
+                       st, arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], \
+                       hist[bin_], b->nnz, d_bs, (int *)nullptr)
 #define NSP_SYM_TB(BIN, BS, TMAX)                                                              \
-    if (hist[BIN] > 0 && now(BIN)) {                                                                       \
+    if (hist[BIN] > 0 && now(BIN)) {                                                           \
+        constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        hipLaunchKernelGGL((k_sym_tb<BS, TMAX, false>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, \
-                           st, arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[BIN],   \
-                           hist[BIN], b->nnz, d_bs,                                            \
-                           (int *)nullptr);                                                    \
+        if (g_coop == 1) NSP_SYM_TB_GO(BS, TMAX, 1);                                           \
+        else if (g_coop == 2) NSP_SYM_TB_GO(BS, TMAX, 2);                                      \
+        else NSP_SYM_TB_GO(BS, TMAX, 0);                                                       \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -396,6 +421,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
 #undef NSP_SYM_BITS
 #undef NSP_SYM_DENSE
 #undef NSP_SYM_TB
+#undef NSP_SYM_TB_GO
     // the overflow bin needs a host round trip (fail count), so it is issued last: by then
     // every other bin is already queued on its own stream.
     if (hist[5] > 0) {
@@ -528,12 +554,17 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         }
         L.free_later(slab);
     }
+#define NSP_NUM_TB_GO(BS, TMAX, PMAX, COOPX)                                                    \
+    hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX, COOPX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, arpt, \
+                       acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm,    \
+                       row_prod, row_maxb, off[bin_], hist[bin_], b->nnz, write_col)
 #define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
-    if (hist[BIN] > 0 && now(BIN)) {                                                                       \
+    if (hist[BIN] > 0 && now(BIN)) {                                                           \
+        constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, arpt,  \
-                           acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, \
-                           row_prod, row_maxb, off[BIN], hist[BIN], b->nnz, write_col);                                     \
+        if (g_coop == 1) NSP_NUM_TB_GO(BS, TMAX, PMAX, 1);                                     \
+        else if (g_coop == 2) NSP_NUM_TB_GO(BS, TMAX, PMAX, 2);                                \
+        else NSP_NUM_TB_GO(BS, TMAX, PMAX, 0);                                                 \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -621,6 +652,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
 #undef NSP_NUM_DENSE_GO
 #undef NSP_NUM_BLOCK_GO
 #undef NSP_NUM_TB
+#undef NSP_NUM_TB_GO
     // rows beyond the LDS tables without the tile kernels (unsorted B, or switched off): global
     // table + segmented sort; synchronises on the host (scratch freed here), hence last
     if (!use_tiled && hist[kNumGlobalBin] > 0) {
@@ -743,7 +775,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         const char *e = getenv("NSPARSE_DENSE");
         g_dense_enabled = !(e && e[0] == '0');
     }
-    Thr sym_thr = kSymThr, num_thr = kNumThr;
+    Thr sym_thr = kSymThr, num_thr = num_ladder();
     if (!g_dense_enabled) sym_thr.dense_ratio = num_thr.dense_ratio = sym_thr.bits_ratio = 0;
     NSP_CHECK(hipStreamSynchronize(0));  // inputs queued on the null stream by the caller
     // one fill for both counter blocks and the four words at long_cnt (the two list counters and the
@@ -995,7 +1027,7 @@ void nsparse_get_spgemm_bins(int *sym, int *num)
 {
     // 15 ints each: tiny, hash_t[4], dense_span[3], dense_ratio, bits_span[2], bits_ratio,
     // bits_min, bits_wide_min, bits_wide_span (ratios are 0 when NSPARSE_DENSE=0)
-    const nsp::spgemm::Thr *t[2] = {&nsp::spgemm::kSymThr, &nsp::spgemm::kNumThr};
+    const nsp::spgemm::Thr *t[2] = {&nsp::spgemm::kSymThr, &nsp::spgemm::num_ladder()};
     int *out[2] = {sym, num};
     if (nsp::spgemm::g_dense_enabled < 0) {
         const char *e = getenv("NSPARSE_DENSE");

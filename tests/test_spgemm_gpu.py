@@ -482,3 +482,17 @@ def test_concurrent_callers_serialise(lib_d, oracle_d):
     for t in th:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("coop", ["1", "2"])
+def test_wave_cooperative_probe_variants(coop, lib_d, oracle_d):
+    """NSPARSE_COOP=1 / 2: the wave-cooperative probe of BASELINE's north_star (ballot over the slots
+    h .. h+63 of one key, the lane that sees the first empty slot claims it) in every LDS hash bin, with
+    the window bins off so that all rows hash.  A measured alternative, not the default (DESIGN 4.1:
+    1.2-1.8x slower as collision fallback, 4-15x as the only probe) -- but it ships, so it must be right."""
+    for kind, p in ((1, (20, 20, 20)), (3, (12, 8, 0)), (4, (30000, 95000, 0))):
+        A = synth(lib_d, kind, *p, seed=0x5EED0022)
+        ref = oracle_d.spgemm(A, A)
+        got, st = spgemm_subprocess(A, {"NSPARSE_COOP": coop, "NSPARSE_DENSE": "0"})
+        assert sum(st["sym"][6:]) == 0 and sum(st["num"][6:]) == 0
+        assert_parity(oracle_d, got, ref)
