@@ -64,10 +64,13 @@ L2_PEAK_GBS = 34500.0   # MI355X_MICROARCH.md: aggregate L2, 8 XCDs
 FETCH_UNIT, WRITE_UNIT = 2048, 1024  # bytes per PMC unit, profiles/r01_pmc_calibration.txt
 
 # numeric bin -> kernel the library launches for it (csrc/spgemm_hash.hip: numeric_phase)
-NUM_KERNEL = {0: "k_num_small<256, 4, 32>", 1: "k_num_tb<64, 256, 256>", 2: "k_num_tb<256, 1024, 1024>",
-              3: "k_num_tb<512, 4096, 4096>", 4: "k_num_tb<1024, 8192, 8192>",
-              5: "k_num_tiled<1024, 12288> + k_num_ranked", 6: "k_num_dense<256, 1536, 1>",
-              7: "k_num_dense<256, 4096, 1>", 8: "k_num_dense<512, 12288, 1>"}
+# (the window bins 6-8 run k_num_block<128, span, ...> on matrices with twin rows, else k_num_dense<BS, span, ...>)
+NUM_KERNEL = {0: ["k_num_small<256, 4, 32"], 1: ["k_num_tb<64, 256, 256"], 2: ["k_num_tb<256, 1024, 1024"],
+              3: ["k_num_tb<512, 4096, 4096"], 4: ["k_num_tb<1024, 8192, 8192"],
+              5: ["k_num_tiled<1024, 12288", "k_num_ranked"],
+              6: ["k_num_block<128, 1536, 1", "k_num_dense<256, 1536, 1"],
+              7: ["k_num_block<128, 4096, 1", "k_num_dense<256, 4096, 1"],
+              8: ["k_num_block<128, 12288, 1", "k_num_dense<512, 12288, 1"]}
 
 STANDINS = {  # name -> (kind, params, seed)
     "cant": (0, (9, 9, 257), 0x5EED0022),
@@ -194,14 +197,17 @@ def pmc_traffic(workload):
                 "hbm_bytes": f[k] * FETCH_UNIT + wr.get(k, 0.0) * WRITE_UNIT} for k in f}
 
 
-def find_kernel(traffic, pattern):
+def find_kernel(traffic, patterns):
+    """First kernel of the PMC pass whose name contains one of the patterns -> (name, counters)."""
     if not traffic:
-        return None
-    pat = pattern.replace(" ", "")
-    for k, v in traffic.items():
-        if pat in k.replace(" ", ""):
-            return v
-    return None
+        return None, None
+    for pattern in ([patterns] if isinstance(patterns, str) else patterns):
+        pat = pattern.replace(" ", "")
+        for k, v in traffic.items():
+            if pat in k.replace(" ", ""):
+                short = k.split("(")[0].replace("void ", "").replace("nsp::spgemm::", "").replace("nsp::spmv::", "")
+                return short, v
+    return None, None
 
 
 def relaunch_under_torchrun(args):
@@ -338,8 +344,10 @@ def main():
         t0 = time.time()
         traffic_all = pmc_traffic("bench")
         log(f"[pmc] two passes in {time.time() - t0:.0f}s: {'ok' if traffic_all else 'unavailable'}")
-    dom_kernel = NUM_KERNEL.get(dom, f"numeric bin {dom}")
-    tr = find_kernel(traffic_all, dom_kernel.split(" + ")[0]) if traffic_all else None
+    pats = NUM_KERNEL.get(dom, [f"numeric bin {dom}"])
+    kname, tr = find_kernel(traffic_all, pats)
+    # without a PMC pass the name is the first candidate: the node-block kernel when the matrix has twin rows
+    dom_kernel = kname if kname else (pats[0] if st.twin_rows * 8 >= a.M or dom < 6 else pats[-1]) + ", ...>"
 
     lds = None
     lds_path = os.path.join(ROOT, "profiles", "r02_lds_atomic.json")
@@ -347,7 +355,7 @@ def main():
         try:
             rowsj = json.load(open(lds_path))["rows"]
             best = max(r["lanes_per_clk_per_cu"] for r in rowsj if r["type"] == "ds_add_f64" and r["pattern"] == "consecutive")
-            fem = [r for r in rowsj if r["type"] == "ds_add_f64" and r["pattern"] == "random_1536" and r["active_lanes"] == 24]
+            fem = [r for r in rowsj if r["type"] == "ds_add_f64" and r["pattern"] == "random_1536" and r["active_lanes"] == 32]
             clk = 2.4e9
             lds = {"source": "profiles/r02_lds_atomic.json (tools/lds_atomic/lds_atomic_bench.hip on this GPU model)",
                    "ds_add_f64_lanes_per_clk_per_cu_peak": best,
@@ -355,8 +363,9 @@ def main():
                    "frac_of_peak": round(mdl["products"] / (best * 256 * clk) / t_dom, 4)}
             if fem:
                 r24 = fem[0]["lanes_per_clk_per_cu"]
-                lds.update({"lanes_per_clk_per_cu_24_lanes_random_window": r24,
-                            "floor_ms_at_24_lanes_random": round(mdl["products"] / (r24 * 256 * clk) * 1e3, 4)})
+                lds.update({"lanes_per_clk_per_cu_32_lanes_random_window": r24,
+                            "floor_ms_at_32_lanes_random": round(mdl["products"] / (r24 * 256 * clk) * 1e3, 4),
+                            "needed_lanes_per_clk_per_cu": round(mdl["products"] / (t_dom * 256 * clk), 3)})
         except Exception as e:
             lds = {"error": repr(e)[:120]}
 
@@ -384,8 +393,9 @@ def main():
         "whole_call": {"bytes_requested_model": int(b_spgemm), "ms": round(ms_per_step, 4),
                        "l2_frac": round(gbs(b_spgemm, ms_per_step * 1e-3) / L2_PEAK_GBS, 4),
                        "compulsory_hbm_frac": round(gbs((4 + w) * (nnz_a + nnz_b + nnz_c) + 8 * a.M, ms_per_step * 1e-3) / HBM_PEAK_GBS, 4)},
-        "note": "the window kernels are bound by one LDS fp64 atomic per product, not by HBM (DESIGN 4.1); "
-                "frac is the physical HBM fraction",
+        "note": "frac is the physical HBM fraction.  The numeric window kernels are bound by the latency of the "
+                "dependent loads of a row group (row list -> row words -> A entries -> B extents -> B entries) and by "
+                "instruction issue, not by HBM and not by the LDS atomics (ablations in DESIGN 4.1)",
     }
 
     # ------------------------------------------------ irregular cant-class stand-in ----
@@ -409,7 +419,7 @@ def main():
         ms_i = el_i * 1e3 / args.steps
         irregular = {
             "workload": "synthetic cant-class, irregular: 9x9x257 brick of 3-dof nodes, unknowns renumbered inside "
-                        "486-unknown bands, 7.4 % of node couplings dropped (nsparse_synth_csr kind 5)",
+                        "729-unknown bands (three mesh planes), 7.4 % of node couplings dropped (nsparse_synth_csr kind 5)",
             "M": int(Ai["M"]), "nnz_A": int(Ai["rpt"][-1]), "n_prod": int(fl_i.value // 2), "nnz_C": int(st_i.nnz_c),
             "suitesparse_cant": {"M": 62451, "nnz_A": 4007383, "n_prod": "~269.5 M", "nnz_C": "~17.4 M"},
             "value": round(fl_i.value / (ms_i * 1e6), 2), "unit": "GFLOPS", "ms_per_step": round(ms_i, 4),
@@ -451,8 +461,9 @@ def main():
         ms_c, ms_c_ev = time_spmv(op, x, args.spmv_steps, gather=False)
         ms_g = time_spmv(op, x, args.spmv_steps, gather=True)[0] if world > 1 else ms_c
         b_csr = nnz_global * (w + 4) + 4 * (M_global + 1) + N_cols * w + M_global * w
-        kname = f"k_spmv_amb<{int(op.plan.block_size)}, {int(op.amb.chunk)}, {'true' if op.amb.seg_num > 1 else 'false'}"
-        tr_s = find_kernel(traffic, kname) if traffic else None
+        atom = "true" if op.amb.seg_num > 1 else "false"
+        _, tr_s = find_kernel(traffic, [f"k_spmv_amb_pipe<{int(op.plan.block_size)}, {atom}",
+                                        f"k_spmv_amb<{int(op.plan.block_size)}, {int(op.amb.chunk)}, {atom}"])
         rep = {
             "workload": label, "M": M_global, "nnz": int(nnz_global),
             "plan": {"seg_size": int(op.plan.seg_size), "block_size": int(op.plan.block_size),

@@ -304,8 +304,12 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
                                               const int *__restrict__ brpt, const int *__restrict__ bcol,
                                               const real *__restrict__ bval, int bnnz, int a_beg,
                                               int a_end, int g, int2 *s_ext, real *s_av, F &&consume,
-                                              DeferList<WITH_VAL> *dl = nullptr, int defer_len = 0x7fffffff)
+                                              DeferList<WITH_VAL> *dl = nullptr, int defer_len = 0x7fffffff,
+                                              const unsigned char *skip_twin = nullptr)
 {
+    // skip_twin (symbolic walks only): rows of B flagged as twins of the row before them have that row's
+    // columns; an A entry that points at such a row right after an entry that points at the row before it
+    // adds no column and is not walked (the 3 dof of a mesh node: a third of the products remains).
     const int ngroups = BS / g;
     const int gid = threadIdx.x / g, gl = threadIdx.x % g;
     const int first = a_beg + gid;
@@ -328,6 +332,7 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
             const I2 r = *reinterpret_cast<const I2 *>(brpt + c);  // one 8-byte gather
             e.x = r.b;
             e.y = r.e;
+            if (!WITH_VAL && skip_twin && j > a_beg && skip_twin[c] && acol[j - 1] == c - 1) e = make_int2(0, 0);
             if (dl && e.y - e.x > defer_len) {  // far longer than the rows g was chosen for
                 const int i = atomicAdd(&dl->n, 1);
                 if (i < DeferList<WITH_VAL>::CAP) {

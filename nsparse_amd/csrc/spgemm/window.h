@@ -31,7 +31,8 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
                                                   int *__restrict__ row_nz, int bin_off, int bin_size,
                                                   int bnnz, const int *__restrict__ bm_off,
                                                   unsigned int *__restrict__ bm,
-                                                  int *__restrict__ row_span_num)
+                                                  int *__restrict__ row_span_num,
+                                                  const unsigned char *__restrict__ btwin)
 {
     // flags: dynamic LDS sized by the widest window actually in the bin, (span/4 + 8) words -- a
     // bin spans a 4x range of windows and a static array for its upper end would cost occupancy
@@ -62,7 +63,8 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
                              [&](const IVecS &k, const RVecS &, int n, real) {
 #pragma unroll
                                  for (int i = 0; i < VWS; i++) flag[i < n ? k.v[i] - lo : dummy] = 1;
-                             });
+                             },
+                             nullptr, 0x7fffffff, btwin);
     __syncthreads();
     int cnt = 0;
     for (int i = threadIdx.x; i < words; i += BS) cnt += __popc(flag4[i] & 0x01010101u);

@@ -319,7 +319,8 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
                                   const int *row_span, int *row_nz, int *row_perm, const int *hist_in,
                                   int max_prod, BinState *d_bs, Context &cx, float *ms_bin,
                                   int *fail_rows, const int *bm_off, unsigned int *bm,
-                                  int *row_span_num, const int *max_span, int max_alen, bool b_sorted)
+                                  int *row_span_num, const int *max_span, int max_alen, bool b_sorted,
+                                  const unsigned char *btwin)
 {
     int hist[NB], off[NB + 1];
     fold_small_hash_bins(hist_in, hist, off);
@@ -351,7 +352,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         const size_t lds = sizeof(int) * (size_t)((span_b + 63) / 64 * 16 + 16);               \
         hipLaunchKernelGGL((k_sym_dense<BS, SPAN>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), lds, st, \
                            arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_lo, row_span, row_nz, \
-                           off[BIN], hist[BIN], b->nnz, bm_off, bm, row_span_num);             \
+                           off[BIN], hist[BIN], b->nnz, bm_off, bm, row_span_num, btwin);      \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -482,7 +483,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // taking the wide rows there is no limit
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
                            (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
-    constexpr int kBlkU = 4;  // tasks in flight per lane in the node-block kernel
+    constexpr int kBlkU = 8;  // tasks in flight per lane in the node-block kernel
     static const int blk_prof_on = getenv("NSPARSE_BLK_PROF") ? atoi(getenv("NSPARSE_BLK_PROF")) : 0;
     unsigned long long *blk_prof = nullptr;
     if (blk_prof_on) {
@@ -869,7 +870,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         BinLauncher LS = symbolic_phase(a, b, row_prod, row_maxb, row_lo, row_span, row_nz, row_perm, h_sym->hist,
                                         h_sym->maxv, d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows,
                                         bm_off, bm, row_span_num, h_sym->max_span, (int)h_sym->max_alen,
-                                        h_sym->b_unsorted == 0);
+                                        h_sym->b_unsorted == 0, btwin);
         sym_used = LS;
         {
             long long binned = 0;
