@@ -304,5 +304,6 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
     if (prof) { __syncthreads(); stamp(4); }
 }
 
+
 }  // namespace spgemm
 }  // namespace nsp

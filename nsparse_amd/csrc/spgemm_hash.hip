@@ -483,7 +483,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // taking the wide rows there is no limit
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
                            (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
-    constexpr int kBlkU = 8;  // tasks in flight per lane in the node-block kernel
+    constexpr int kBlkU = 4;  // tasks in flight per lane in the node-block kernel
     static const int blk_prof_on = getenv("NSPARSE_BLK_PROF") ? atoi(getenv("NSPARSE_BLK_PROF")) : 0;
     unsigned long long *blk_prof = nullptr;
     if (blk_prof_on) {
