@@ -1,7 +1,6 @@
 #!/bin/bash
-# quick A/B of tuning knobs on the GPU box: prints GFLOPS / ms / phase times per setting
-run() { echo "== $*"; env "$@" timeout 300 python bench.py --no-cpu --no-large 2>/dev/null | python -c "
+# usage: bash tools/quick_bench.sh case [case ...]   (env passes through; per-bin events on)
+for c in "$@"; do NSPARSE_BIN_TIMING=${NSPARSE_BIN_TIMING:-1} timeout 120 python tools/run_configs.py $c 2>/dev/null | grep "^{" | python -c "
 import json,sys
-d=json.loads(sys.stdin.read()); p=d['phase_ms']
-print(d['value'], 'GFLOPS', d['ms_per_step'], 'ms | setup', p['setup'], 'sym', p['symbolic'], p['symbolic_bins'], 'num', p['numeric'], p['numeric_bins'], '| spmv', d['spmv']['ms_per_spmv'], d['spmv']['value'])"; }
-for cfg in "$@"; do run $cfg; done
+for ln in sys.stdin:
+    d=json.loads(ln); print(d['case'], d['ms'], d['gflops'], d['phase'], 'sym', [x for x in d['sym_ms'] if x>0], 'num', [x for x in d['num_ms'] if x>0], d.get('rpt_ok'), d.get('col_ok'), d.get('val_fails'))"; done
