@@ -291,20 +291,24 @@ __device__ __forceinline__ int fetch_chunk(const int *__restrict__ bcol, const r
 }
 
 // B rows parked by the group walk for a pass by the whole workgroup (walk_products_mixed)
-template <bool WITH_VAL>
+// CAPX: a row whose products fit the bin's table cannot have more than table / 32 B rows of more than
+// 32 entries, so the kernels size the list by their table (a fixed 32 was the whole duration of the
+// webbase-1M-class symbolic phase: index pages that link to hundreds of directories left all but 32 of
+// those long rows to single lanes, ~1000 dependent steps each)
+template <bool WITH_VAL, int CAPX = 32>
 struct DeferList {
-    static constexpr int CAP = 32;  // small on purpose: LDS per workgroup decides the occupancy of
-    int n;                          // the one-wavefront-per-row kernels
+    static constexpr int CAP = CAPX;
+    int n;
     int2 ext[CAP];
     real av[WITH_VAL ? CAP : 1];
 };
 
-template <int BS, bool WITH_VAL, int V = VW, typename F>
+template <int BS, bool WITH_VAL, int V = VW, typename F, int DCAP = 32>
 __device__ __forceinline__ void walk_products(const int *__restrict__ acol, const real *__restrict__ aval,
                                               const int *__restrict__ brpt, const int *__restrict__ bcol,
                                               const real *__restrict__ bval, int bnnz, int a_beg,
                                               int a_end, int g, int2 *s_ext, real *s_av, F &&consume,
-                                              DeferList<WITH_VAL> *dl = nullptr, int defer_len = 0x7fffffff,
+                                              DeferList<WITH_VAL, DCAP> *dl = nullptr, int defer_len = 0x7fffffff,
                                               const unsigned char *skip_twin = nullptr)
 {
     // skip_twin (symbolic walks only): rows of B flagged as twins of the row before them have that row's
@@ -335,7 +339,7 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
             if (!WITH_VAL && skip_twin && j > a_beg && skip_twin[c] && acol[j - 1] == c - 1) e = make_int2(0, 0);
             if (dl && e.y - e.x > defer_len) {  // far longer than the rows g was chosen for
                 const int i = atomicAdd(&dl->n, 1);
-                if (i < DeferList<WITH_VAL>::CAP) {
+                if (i < DCAP) {
                     dl->ext[i] = e;
                     if (WITH_VAL) dl->av[i] = av;
                     e = make_int2(0, 0);
@@ -381,23 +385,23 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
 // B rows more than 8 steps long are parked in LDS, and after the group walk the whole workgroup
 // strides over each parked row.  Must be called by every thread of the workgroup; dl->n zeroed and
 // visible (barrier) beforehand.
-template <int BS, bool WITH_VAL, typename F>
+template <int BS, bool WITH_VAL, typename F, int DCAP>
 __device__ __forceinline__ void walk_products_mixed(const int *__restrict__ acol, const real *__restrict__ aval,
                                                     const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                     const real *__restrict__ bval, int bnnz, int a_beg,
                                                     int a_end, int np, int maxb, int2 *s_ext, real *s_av,
-                                                    DeferList<WITH_VAL> *dl, F &&consume)
+                                                    DeferList<WITH_VAL, DCAP> *dl, F &&consume)
 {
     const int alen = a_end - a_beg;
     // longest row > 8 x the average (workgroup-uniform): width for the others, the long ones parked
     const bool mixed = alen > 1 && (long long)maxb * alen > 8LL * np;
     constexpr int V = VW;
     const int g = group_width(mixed ? np - maxb : np, mixed ? alen - 1 : alen, BS, mixed ? 0 : maxb, V);  // once
-    walk_products<BS, WITH_VAL, V>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av, consume,
-                                   mixed ? dl : nullptr, 8 * g * V);
+    walk_products<BS, WITH_VAL, V, F &, DCAP>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av, consume,
+                                              mixed ? dl : (DeferList<WITH_VAL, DCAP> *)nullptr, 8 * g * V);
     if (!mixed) return;
     __syncthreads();
-    const int nd = dl->n < DeferList<WITH_VAL>::CAP ? dl->n : DeferList<WITH_VAL>::CAP;
+    const int nd = dl->n < DCAP ? dl->n : DCAP;
     for (int d = 0; d < nd; d++) {
         const int2 e = dl->ext[d];
         const real av = WITH_VAL ? dl->av[d] : (real)0;

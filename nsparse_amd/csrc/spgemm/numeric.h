@@ -282,7 +282,7 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     __shared__ __attribute__((aligned(16))) int srt[PMAX];
     __shared__ int2 s_ext[BS];
     __shared__ real s_av[BS];
-    __shared__ DeferList<true> s_defer;
+    __shared__ DeferList<true, (PMAX / 16 > 32 ? PMAX / 16 : 32)> s_defer;
     __shared__ int s_cnt;
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
 {
     __shared__ __attribute__((aligned(16))) int tab[TMAX];
     __shared__ int2 s_ext[LARGE ? 1 : BS];
-    __shared__ DeferList<false> s_defer;
+    __shared__ DeferList<false, (LARGE ? 32 : (TMAX / 32 > 32 ? TMAX / 32 : 32))> s_defer;
     __shared__ int s_nz;
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;

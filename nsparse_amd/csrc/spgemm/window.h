@@ -64,7 +64,7 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
 #pragma unroll
                                  for (int i = 0; i < VWS; i++) flag[i < n ? k.v[i] - lo : dummy] = 1;
                              },
-                             nullptr, 0x7fffffff, btwin);
+                             (DeferList<false, 32> *)nullptr, 0x7fffffff, btwin);
     __syncthreads();
     int cnt = 0;
     for (int i = threadIdx.x; i < words; i += BS) cnt += __popc(flag4[i] & 0x01010101u);
