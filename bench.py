@@ -70,7 +70,8 @@ NUM_KERNEL = {0: ["k_num_small<256, 4, 32"], 1: ["k_num_tb<64, 256, 256"], 2: ["
               5: ["k_num_tiled<1024, 12288", "k_num_ranked"],
               6: ["k_num_block<128, 1536, 1", "k_num_dense<256, 1536, 1"],
               7: ["k_num_block<128, 4096, 1", "k_num_dense<256, 4096, 1"],
-              8: ["k_num_block<128, 12288, 1", "k_num_dense<512, 12288, 1"]}
+              8: ["k_num_block<128, 12288, 1", "k_num_dense<512, 12288, 1"],
+              9: ["k_num_block<128, 65536, 1"]}
 
 STANDINS = {  # name -> (kind, params, seed)
     "cant": (0, (9, 9, 257), 0x5EED0022),
@@ -322,8 +323,8 @@ def main():
     crpt = lib.d2h(c.d_rpt, (c.M + 1,), np.int32)
     nnz_c = c.nnz
     lib.release_csr(c)
-    sym_thr = (C.c_int * 15)()
-    num_thr = (C.c_int * 15)()
+    sym_thr = (C.c_int * 18)()
+    num_thr = (C.c_int * 18)()
     lib.nsparse_get_spgemm_bins(sym_thr, num_thr)
     models = numeric_bin_models(A_loc, A_full, crpt, list(sym_thr), list(num_thr), w)
     dom = int(np.argmax(bin_ms))

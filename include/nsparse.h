@@ -245,14 +245,17 @@ typedef struct {
 } nsparse_spgemm_stats;
 void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out);
 
-/* Bin ladder of the symbolic / numeric phase, 15 ints each: tiny, hash_t[4], dense_span[3],
- * dense_ratio, bits_span[2], bits_ratio, bits_min, bits_wide_min, bits_wide_span.
+/* Bin ladder of the symbolic / numeric phase, 18 ints each: tiny, hash_t[4], dense_span[3],
+ * dense_ratio, bits_span[2], bits_ratio, bits_min, bits_wide_min, bits_wide_span, rank_span, rank_ratio,
+ * rank_max_nz.
  * Row (n, span) -> bin: n <= tiny: 0;
  * span <= dense_span[2] and (span <= dense_ratio * n or 4 * span <= dense_ratio * products of the
  * row -- the numeric phase bins by nnz, n, but a window also pays off by its products):
  * 6 + #(dense_span < span);
  * n > bits_min and span <= bits_span[1] and span <= bits_ratio * n: 9 + (span > bits_span[0]);
  * bits_wide_min > 0 and n > bits_wide_min and span <= bits_wide_span: 10 (window in pieces);
+ * rank_span > 0 (numeric ladder) and span <= rank_span and n <= rank_max_nz and (span <= rank_ratio * n or
+ * span <= 4 * products): 9 (ranked window: accumulators addressed by bitmap rank);
  * else 1 + #(hash_t < n).                                                               */
 void nsparse_get_spgemm_bins(int *sym_thresholds, int *num_thresholds);
 

@@ -50,10 +50,17 @@ struct Thr {
     int bits_wide_min;   // rows with n > bits_wide_min (they would fill the two largest hash tables to
     int bits_wide_span;  // the brim, or overflow them) and span <= bits_wide_span -> bin 10, which
                          // then covers the window in pieces of bits_span[1] columns; 0 disables
+    // numeric only: RANKED WINDOW rows (bin 9 of the numeric ladder).  The node-block kernel keeps nnz
+    // accumulators addressed by bitmap rank, not one per column, so the width of the window only costs
+    // bitmap words: rows with span <= rank_span, at most rank_max_nz non-zeros and a window that is not
+    // absurdly sparse (span <= rank_ratio * n or span <= 4 * products) take it instead of hashing and
+    // sorting.  0 disables.
+    int rank_span, rank_ratio, rank_max_nz;
 };
 constexpr Thr kSymThr = {32,   {435, 1740, 6963, 27852}, {4096, 16384, 65536}, 8, {262144, 1048576}, 64, 2048,
-                         8192, 16 * 1048576};
-constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8, {0, 0}, 0, 0, 0, 0};
+                         8192, 16 * 1048576, 0, 0, 0};
+constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8, {0, 0}, 0, 0, 0, 0, 65536, 64, 4096};
+constexpr int kRankBin = 9;  // numeric ladder only (the symbolic ladder's bins 9 / 10 are the bit windows)
 constexpr int kSymLargeBin = 5;
 constexpr int kNumGlobalBin = 5;
 // Setup kernels: rows longer than kLongFactor * W entries are not walked by their W-lane group
@@ -103,6 +110,9 @@ __host__ __device__ __forceinline__ int bin_of(int n, int span, const Thr &thr, 
         ((long long)span <= (long long)thr.dense_ratio * n ||
          (long long)span * 4 <= (long long)thr.dense_ratio * work))
         return kDenseBin0 + (span > thr.dense_span[0]) + (span > thr.dense_span[1]);
+    if (thr.rank_span > 0 && span > 0 && span <= thr.rank_span && n <= thr.rank_max_nz &&
+        ((long long)span <= (long long)thr.rank_ratio * n || (long long)span <= 4LL * work))
+        return kRankBin;
     if (thr.bits_ratio > 0 && n > thr.bits_min && span > 0 && span <= thr.bits_span[1] &&
         (long long)span <= (long long)thr.bits_ratio * n)
         return kBitsBin0 + (span > thr.bits_span[0]);

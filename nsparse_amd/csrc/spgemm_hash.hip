@@ -82,6 +82,7 @@ static const Thr &num_ladder()
 {
     static Thr t = [] {
         Thr v = kNumThr;
+        if (getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0) v.rank_span = 0;  // needs the block kernel
         const char *e = getenv("NSPARSE_NUM_HEAVY_MIN");
         if (e && atoi(e) > 0) {
             const int n = atoi(e);
@@ -630,6 +631,30 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     const int tune_nd6 = env_nd6 ? env_nd6 : (blk ? 128 : 256);
     const int tune_nd7 = env_nd7 ? env_nd7 : (blk ? 128 : 256);
     const int tune_nd8 = env_nd8 ? env_nd8 : (blk ? 128 : 512);
+    // ranked-window rows (numeric bin 9): always the node-block kernel, windows up to 65536 columns
+    if (hist[kRankBin] > 0 && now(kRankBin)) {
+        constexpr int bin_ = kRankBin;
+        hipStream_t st = L.begin(kRankBin);
+        const int span_b = max_span[kRankBin] < 65536 ? max_span[kRankBin] : 65536;
+        const int nzcap = num_ladder().rank_max_nz;
+        const int nz1 = ((max_nz < nzcap ? max_nz : nzcap) + 7) / 8 * 8 + 8;
+        int blk_elems = nz1;
+        if (grp) {
+            const int want = kBlkRows * nz1 < kBlkAccElems ? kBlkRows * nz1 : kBlkAccElems;
+            blk_elems = want > nz1 ? want : nz1;
+        }
+        (void)span_b;
+        const size_t lds_blk = sizeof(acc_t) * (size_t)blk_elems;
+        const int heads = grp ? listed[bin_] : hist[bin_];
+#define NSP_RANKWIN(MODEX)                                                                      \
+    hipLaunchKernelGGL((k_num_block<128, 65536, MODEX, kBlkU>), dim3(8 * ceil_div(heads, 8)), dim3(128), lds_blk, st, \
+                       arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_maxb, \
+                       row_lo, row_span, off[bin_], heads, b->nnz, bm_off, bm, grp, btwin, blk_prof)
+        if (write_col & 1) NSP_RANKWIN(1); else NSP_RANKWIN(2);
+#undef NSP_RANKWIN
+        NSP_LAUNCH_CHECK();
+        L.end(kRankBin);
+    }
     if (tune_nd8 == 128) { NSP_NUM_DENSE(8, 128, 12288) } else if (tune_nd8 == 256) { NSP_NUM_DENSE(8, 256, 12288) } else { NSP_NUM_DENSE(8, 512, 12288) }
     if (tune_nd7 == 128) { NSP_NUM_DENSE(7, 128, 4096) } else { NSP_NUM_DENSE(7, 256, 4096) }
     if (tune_nd6 == 128) { NSP_NUM_DENSE(6, 128, 1536) } else if (tune_nd6 == 64) { NSP_NUM_DENSE(6, 64, 1536) } else if (tune_nd6 == 512) { NSP_NUM_DENSE(6, 512, 1536) } else { NSP_NUM_DENSE(6, 256, 1536) }
@@ -777,7 +802,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         g_dense_enabled = !(e && e[0] == '0');
     }
     Thr sym_thr = kSymThr, num_thr = num_ladder();
-    if (!g_dense_enabled) sym_thr.dense_ratio = num_thr.dense_ratio = sym_thr.bits_ratio = 0;
+    if (!g_dense_enabled) sym_thr.dense_ratio = num_thr.dense_ratio = sym_thr.bits_ratio = num_thr.rank_span = 0;
     NSP_CHECK(hipStreamSynchronize(0));  // inputs queued on the null stream by the caller
     // one fill for both counter blocks and the four words at long_cnt (the two list counters and the
     // two words of k_col_range); the ints in between belong to calls that reset them themselves
@@ -833,7 +858,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // phase: they take that row's result (k_twin_copy).  NSPARSE_TWINS=0 switches the detection off.
     unsigned char *twin = (!numeric_only && twins_on && M > 1) ? (unsigned char *)dev_alloc((size_t)M) : nullptr;
     launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
-                        use_bm ? num_thr.dense_span[2] : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, twin, s0);
+                        use_bm ? (num_thr.rank_span > num_thr.dense_span[2] ? num_thr.rank_span : num_thr.dense_span[2]) : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, twin, s0);
     void *bm_scan_tmp = nullptr;
     if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
     const int grid_m = ceil_div(M, 1024);
@@ -903,7 +928,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // ---- numeric binning ------------------------------------------------------------
     // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
     const int *num_span = numeric_only ? row_span : row_span_num;
-    if (!numeric_only && bm == nullptr) num_thr.dense_ratio = 0;
+    if (!numeric_only && bm == nullptr) num_thr.dense_ratio = num_thr.rank_span = 0;
     hipLaunchKernelGGL(k_hist, dim3(grid_m < 128 ? grid_m : 128), dim3(1024), 0, s0, row_nz, num_span,
                        (const int *)row_prod, M, num_thr, d_num);
     if (M >= (1 << 18))
@@ -1026,8 +1051,8 @@ int nsparse_spgemm_set_sorted(int on)
 
 void nsparse_get_spgemm_bins(int *sym, int *num)
 {
-    // 15 ints each: tiny, hash_t[4], dense_span[3], dense_ratio, bits_span[2], bits_ratio,
-    // bits_min, bits_wide_min, bits_wide_span (ratios are 0 when NSPARSE_DENSE=0)
+    // 18 ints each: tiny, hash_t[4], dense_span[3], dense_ratio, bits_span[2], bits_ratio,
+    // bits_min, bits_wide_min, bits_wide_span, rank_span, rank_ratio, rank_max_nz (ratios / rank_span are 0 when NSPARSE_DENSE=0)
     const nsp::spgemm::Thr *t[2] = {&nsp::spgemm::kSymThr, &nsp::spgemm::num_ladder()};
     int *out[2] = {sym, num};
     if (nsp::spgemm::g_dense_enabled < 0) {
@@ -1045,6 +1070,9 @@ void nsparse_get_spgemm_bins(int *sym, int *num)
         out[p][12] = t[p]->bits_min;
         out[p][13] = t[p]->bits_wide_min;
         out[p][14] = t[p]->bits_wide_span;
+        out[p][15] = nsp::spgemm::g_dense_enabled ? t[p]->rank_span : 0;
+        out[p][16] = t[p]->rank_ratio;
+        out[p][17] = t[p]->rank_max_nz;
     }
 }
 

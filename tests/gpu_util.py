@@ -158,6 +158,9 @@ def bins_of(n, span, ladder, work=None):
             b = np.where((n > ladder[13]) & (span > 0) & (span <= ladder[14]), 10, b)
         bits = (n > bmin) & (span > 0) & (span <= bspan[1]) & (span <= bratio * n)
         b = np.where(bits, 9 + (span > bspan[0]), b)
+    if len(ladder) > 15 and ladder[15] > 0:  # ranked window (numeric ladder): after the dense rule, before the rest
+        rank = (span > 0) & (span <= ladder[15]) & (n <= ladder[17]) & ((span <= ladder[16] * n) | (span <= 4 * work))
+        b = np.where(rank, 9, b)
     if ratio > 0:
         dense = (span > 0) & (span <= dspan[2]) & ((span <= ratio * n) | (4 * span <= ratio * work))
         b = np.where(dense, 6 + (span > dspan[0]) + (span > dspan[1]), b)
@@ -169,13 +172,15 @@ def numeric_bins(row_nz, row_prod, span, sym, num):
     window only if the symbolic dense kernel wrote its column bitmap (symbolic bin >= 6) and the
     window fits the numeric ladder; everything else is binned by nnz alone."""
     span = np.asarray(span, dtype=np.int64)
-    has_bm = (bins_of(row_prod, span, sym) >= 6) & (span <= num[7])
+    sb = bins_of(row_prod, span, sym)
+    limit = max(num[7], num[15] if len(num) > 15 else 0)  # widest window a bitmap is handed over for
+    has_bm = (sb >= 6) & (sb <= 8) & (span <= limit)
     return bins_of(row_nz, np.where(has_bm, span, 0), num, work=row_prod)
 
 
 def ladders(lib):
-    sym = (C.c_int * 15)()
-    num = (C.c_int * 15)()
+    sym = (C.c_int * 18)()
+    num = (C.c_int * 18)()
     lib.nsparse_get_spgemm_bins(sym, num)
     return list(sym), list(num)
 

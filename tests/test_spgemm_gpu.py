@@ -66,7 +66,7 @@ def _bins_match(orc, st, row_prod, row_nz, lib, A, B=None):
     tw = twin_rows(A)  # not binned in the symbolic phase
     assert st.twin_rows == int(tw.sum())
     assert list(st.sym_bin_size)[:11] == np.bincount(bins_of(row_prod, span, sym)[~tw], minlength=11).tolist()
-    assert list(st.num_bin_size)[:9] == np.bincount(numeric_bins(row_nz, row_prod, span, sym, num), minlength=9).tolist()
+    assert list(st.num_bin_size)[:10] == np.bincount(numeric_bins(row_nz, row_prod, span, sym, num), minlength=10).tolist()
 
 
 @pytest.mark.parametrize("kind,p,prec", [
