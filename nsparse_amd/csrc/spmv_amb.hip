@@ -14,9 +14,10 @@
 //     lane, so the result is stored, not atomically added, and is bit-reproducible; with
 //     several segments the native fp64/fp32 global atomic add is used (the reference spins
 //     on a 64-bit CAS, kernel_spmv_amb.cu:70-76);
-//   * workgroup b runs on XCD b % 8 (observed dispatch order); the block index is remapped so
-//     that each XCD walks one contiguous eighth of the chunks and its private L2 sees one
-//     contiguous window of x instead of eight interleaved ones;
+//   * workgroup b runs on XCD b % 8 (observed dispatch order); for matrices that fit the Infinity
+//     Cache the block index is remapped so that each XCD walks one contiguous eighth of the chunks
+//     and its private L2 sees one contiguous window of x instead of eight interleaved ones; matrices
+//     that stream from HBM keep the natural order (see launch_bs);
 //   * reads of x are clamped to N-1 and rows >= M are not written, so neither the
 //     N + MAX_BLOCK_SIZE / M + WARP over-allocation of the reference's callers
 //     (spmv_amb.cu:32-33) nor the uninitialised tail of x can influence the result.
@@ -103,14 +104,14 @@ __global__ __launch_bounds__(1024) void k_spmv_amb_pipe(real *__restrict__ y, co
     const unsigned int length = cl[cu];
     const int nblk = (int)(length & SCL_BIT) + 1;
     const int c_off = (int)(length >> SCL_BORDER) * seg_size;
-    const int row = (int)__builtin_nontemporal_load(perm + i) + (int)perm_off[cu] * USHORT_MAX;
+    const int row = (abl & 16) ? (int)(i & 0xfffff) : (int)__builtin_nontemporal_load(perm + i) + (int)perm_off[cu] * USHORT_MAX;
     const real *v = val + cs0 + lane;
     const unsigned short *cp = col + cs0 / BSZ + lane;
     const int nmax = N - 1;
     real acc = 0;
     int ccur[UB], cnxt[UB];
 #pragma unroll
-    for (int u = 0; u < UB; u++) ccur[u] = u < nblk ? (int)__builtin_nontemporal_load(cp + u * C) : 0;
+    for (int u = 0; u < UB; u++) ccur[u] = (u < nblk && !(abl & 8)) ? (int)__builtin_nontemporal_load(cp + u * C) : 0;
     for (int h0 = 0; h0 < nblk; h0 += UB) {
         real vv[UB][BSZ];
 #pragma unroll
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(1024) void k_spmv_amb_pipe(real *__restrict__ y, co
             }
 #pragma unroll
         for (int u = 0; u < UB; u++)
-            cnxt[u] = h0 + UB + u < nblk ? (int)__builtin_nontemporal_load(cp + (UB + u) * C) : 0;
+            cnxt[u] = (h0 + UB + u < nblk && !(abl & 8)) ? (int)__builtin_nontemporal_load(cp + (UB + u) * C) : 0;
         real xx[UB][BSZ];
 #pragma unroll
         for (int u = 0; u < UB; u++)
@@ -155,7 +156,15 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
     const int nb = ceil_div(rows, tb);
     const int nb8 = ceil_div(nb, 8);
     const bool atomic = mat->seg_num > 1;
-    static const int no_remap = getenv("NSPARSE_SPMV_NOREMAP") ? 1 : 0;
+    // XCD-aware block remap (each XCD walks one contiguous eighth of the chunks, so its private L2 sees one
+    // window of x): pays only while the matrix lives in the 256 MiB Infinity Cache (cant class: 3 %).  A
+    // matrix that streams from HBM reads eight far-apart regions at once under the remap and loses DRAM
+    // locality: nlpkkt class 0.196 -> 0.178 ms without it (the bare value stream 0.164 -> 0.150).
+    // NSPARSE_SPMV_NOREMAP=1 / NSPARSE_SPMV_REMAP=1 force either.
+    static const int env_noremap = getenv("NSPARSE_SPMV_NOREMAP") ? 1 : 0;
+    static const int env_remap = getenv("NSPARSE_SPMV_REMAP") ? 1 : 0;
+    const long long stream_bytes = (long long)mat->nnz * (long long)sizeof(real) + (long long)mat->nnz / mat->block_size * 2;
+    const int no_remap = env_noremap || (!env_remap && stream_bytes > (128LL << 20));
     static const int plain = getenv("NSPARSE_SPMV_PLAIN") ? 1 : 0;
     const dim3 grid(no_remap ? nb : nb8 * 8), block(tb);
     const int nb8_arg = no_remap ? 0 : nb8;
