@@ -463,7 +463,7 @@ def main():
         ms_g = time_spmv(op, x, args.spmv_steps, gather=True)[0] if world > 1 else ms_c
         b_csr = nnz_global * (w + 4) + 4 * (M_global + 1) + N_cols * w + M_global * w
         atom = "true" if op.amb.seg_num > 1 else "false"
-        _, tr_s = find_kernel(traffic, [f"k_spmv_amb_pipe<{int(op.plan.block_size)}, {atom}",
+        _, tr_s = find_kernel(traffic, [f"k_spmv_amb_row<{int(op.plan.block_size)}, {atom}", f"k_spmv_amb_pipe<{int(op.plan.block_size)}, {atom}",
                                         f"k_spmv_amb<{int(op.plan.block_size)}, {int(op.amb.chunk)}, {atom}"])
         rep = {
             "workload": label, "M": M_global, "nnz": int(nnz_global),
