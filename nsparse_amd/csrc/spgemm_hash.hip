@@ -485,6 +485,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
                            (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
     constexpr int kBlkU = 4;  // tasks in flight per lane in the node-block kernel
+    // diagnostics: extra dynamic LDS per workgroup = fewer groups in flight per CU (what bounds the kernel?)
+    static const int blk_pad = getenv("NSPARSE_BLK_PAD") ? atoi(getenv("NSPARSE_BLK_PAD")) : 0;
     static const int blk_prof_on = getenv("NSPARSE_BLK_PROF") ? atoi(getenv("NSPARSE_BLK_PROF")) : 0;
     unsigned long long *blk_prof = nullptr;
     if (blk_prof_on) {
@@ -606,7 +608,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
             const int want = kBlkRows * nz1 < kBlkAccElems ? kBlkRows * nz1 : kBlkAccElems;    \
             blk_elems = want > nz1 ? want : nz1;                                               \
         }                                                                                      \
-        const size_t lds_blk = sizeof(acc_t) * (size_t)blk_elems;                              \
+        const size_t lds_blk = sizeof(acc_t) * (size_t)blk_elems + (size_t)blk_pad;            \
         if (lean_on && (grp || blk_all)) {                                                     \
             if (write_col & 1) NSP_NUM_BLOCK_GO(BS, SPAN, 1) else NSP_NUM_BLOCK_GO(BS, SPAN, 2) \
         } else {                                                                               \
