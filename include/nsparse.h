@@ -203,6 +203,10 @@ const char *nsparse_last_error_string(void);
 int nsparse_ans_check_count(const real *csr_ans, const real *ans_vec, int N);
 int nsparse_check_spgemm_count(const sfCSR *c, const sfCSR *ans);
 
+/* "gfx950 <double|float> <hash>": target, precision and the content hash of the library's sources at
+ * build time (csrc/Makefile); tests recompute the hash from the tree to catch a stale prebuilt .so.   */
+const char *nsparse_build_info(void);
+
 /* Deterministic replacement for init_vector: splitmix64 stream, U[0,1).       */
 void nsparse_init_vector_seeded(real *x, int row, unsigned long long seed);
 

@@ -73,6 +73,7 @@ SIGNATURES = {
     "spgemm_kernel_hash": (None, [_P(sfCSR), _P(sfCSR), _P(sfCSR)]),
     "nsparse_last_error": (C.c_int, []),
     "nsparse_last_error_string": (C.c_char_p, []),
+    "nsparse_build_info": (C.c_char_p, []),
     "nsparse_ans_check_count": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     "nsparse_check_spgemm_count": (C.c_int, [_P(sfCSR), _P(sfCSR)]),
     "nsparse_init_vector_seeded": (None, [C.c_void_p, C.c_int, C.c_ulonglong]),

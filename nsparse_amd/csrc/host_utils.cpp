@@ -438,4 +438,15 @@ void check_spgemm_answer(sfCSR c, sfCSR ans)
     printf(shown ? "Calculation Result is Incorrect\n" : "Calculation Result is Correct\n");
 }
 
+
+#ifndef NSPARSE_SRC_HASH
+#define NSPARSE_SRC_HASH "unknown"
+#endif
+// "gfx950 <precision> <content hash of csrc + headers at build time>": lets a harness check that the
+// shared object it loaded was built from the sources beside it.
+const char *nsparse_build_info(void)
+{
+    return NSPARSE_REAL_IS_FLOAT ? "gfx950 float " NSPARSE_SRC_HASH : "gfx950 double " NSPARSE_SRC_HASH;
+}
+
 }  // extern "C"

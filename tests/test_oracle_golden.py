@@ -116,3 +116,38 @@ def test_amb_plan_model(oracle_d):
     assert a.footprint == by
     for s2, b2 in ((65536, 1), (1024, 3), (4096, 20)):
         assert oracle_d.csr2amb(g, s2, b2, 32).footprint >= by
+
+
+@pytest.mark.parametrize("chunk", [32, 64])
+@pytest.mark.parametrize("name,seg,bs,sigma", [
+    ("banded2k", 65536, 1, 32768), ("banded2k", 1024, 3, 32768), ("banded2k", 300, 20, 32768),
+    ("banded2k", 65536, 2, 512), ("rmat_s10", 65536, 1, 32768), ("rmat_s10", 256, 4, 32768),
+    ("wide_seg", 4096, 5, 32768), ("wide_seg", 65536, 2, 1024), ("banded_signed1k", 65536, 2, 32768),
+])
+def test_amb_oracle_against_second_implementation(name, seg, bs, sigma, chunk, oracle_d):
+    """The C oracle's CSR -> AMB conversion against tests/amb_numpy.py, an independent numpy restatement
+    written from the reference's kernels: all seven arrays, the scalars, and the traversal."""
+    import amb_numpy
+    g = load_golden(name)
+    ora = oracle_d.csr2amb(g, seg, bs, chunk, sigma)
+    ref = amb_numpy.csr2amb(g, seg, bs, chunk, sigma)
+    for k in ("c_size", "nnz", "pad_M", "seg_num"):
+        assert ref[k] == getattr(ora, k), k
+    for k in ("cs", "cl", "sellcs_col", "sellcs_val", "s_write_permutation", "s_write_permutation_offset",
+              "write_permutation"):
+        assert np.array_equal(ref[k], getattr(ora, k)), f"AMB array {k}: oracle and numpy restatement differ"
+    y = amb_numpy.spmv(ref, g["x"])
+    np.testing.assert_allclose(y, g["y"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(ora.spmv(g["x"]), y, rtol=1e-13, atol=1e-13)
+
+
+def test_amb_second_implementation_on_test_mtx():
+    """tests/amb_numpy.py on the reference's fixture: the hand-derived layout of SURVEY 8c."""
+    import amb_numpy
+    A = dict(M=5, N=5, rpt=np.array(TEST_MTX["rpt"]), col=np.array(TEST_MTX["col"]),
+             val=np.array(TEST_MTX["val"], dtype=float))
+    a = amb_numpy.csr2amb(A, 65536, 1, 32)
+    assert a["c_size"] == 1 and a["nnz"] == 96 and a["cs"].tolist() == [0] and a["cl"].tolist() == [2]
+    assert a["s_write_permutation"].tolist() == [2, 0, 4, 1, 3] + list(range(5, 32))
+    assert a["sellcs_col"][:5].tolist() == [0, 0, 2, 1, 3] and a["sellcs_val"][:5].tolist() == [1, 10, 2, 20, 40]
+    assert amb_numpy.spmv(a, np.array(TEST_MTX["x"], float)).tolist() == TEST_MTX["y"]
