@@ -27,9 +27,11 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
 {
     constexpr int RPB = BS / LPR;
     __shared__ int keys[RPB * TROW];
-    // values in `real` here (not acc_t): a row has a handful of products, so the slow fp32 LDS atomic
-    // does not show, while 4 bytes less per slot is two more workgroups per CU in the float build
-    __shared__ real vals[RPB * TROW];
+    // values in acc_t (double in both builds) like every other accumulator: a row of this bin has at most
+    // 16 non-zeros but may have thousands of products (a C with one column), and float sums of those
+    // miss the reference's 1e-6 (fuzz seed 9047, float build: 8 of 63 entries); besides, ds_add_f32 is
+    // the slow LDS atomic on gfx950
+    __shared__ acc_t vals[RPB * TROW];
     // every wavefront clears and uses only the slots of its own 64 / LPR rows: no workgroup barrier,
     // so a wavefront does not wait for the slowest row of the other three
     {
@@ -47,14 +49,14 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
     const bool active = q < bin_size;
     int rid = 0;
     int *kt = keys + lrow * TROW;
-    real *vt = vals + lrow * TROW;
+    acc_t *vt = vals + lrow * TROW;
     if (active) {
         rid = row_perm[bin_off + q];
         const int e = arpt[rid + 1];
         auto add = [&](int key, real x) {
             int fresh;
             const int h = ht_find_or_insert(kt, TROW - 1, key, &fresh);
-            unsafeAtomicAdd(vt + h, x);
+            unsafeAtomicAdd(vt + h, (acc_t)x);
         };
         // EB of the lane's A entries at a time, their loads requested level by level (see
         // k_sym_small): ~3 memory round trips per row instead of 3 per entry
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
                 rank += (o != -1 && o < key) ? 1 : 0;
             }
             if (write_col & 1) ccol[off + rank] = key;
-            cval[off + rank] = vt[s];
+            cval[off + rank] = (real)vt[s];
         }
     }
 }
