@@ -149,113 +149,9 @@ __global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, c
     if (threadIdx.x == 0) row_nz[rid] = s_nz;
 }
 
-// ---- lean product walk for the numeric window kernels -----------------------------------------
-// rocprofv3 / ISA of the first k_num_dense: ~120 instructions per step of 4 products per lane -- the
-// generic walk's state machine, four exec-mask regions (one per vector element), six instructions
-// of slot arithmetic per product and two dozen register moves of its double buffer -- against an
-// LDS atomic rate (tools/lds_atomic) that would allow 4-15x more products per clock.  The kernel was
-// VALU-issue-bound.  Here every lane takes ONE entry of a B row per chunk: a group of G lanes reads
-// G consecutive entries (coalesced dword / qword loads), so one atomic instruction sees consecutive
-// columns -- consecutive 8-byte slots of a plainly indexed window, no slot swizzle -- and a partial
-// chunk is one exec mask, not one per element.  The A entries of the row are parked in LDS as
-// 16-byte records {first, end, value}; group q walks a CONTIGUOUS range of them (the rows of B that
-// belong to one mesh node have the same columns: interleaved, neighbouring groups would add to the
-// same slots in the same instruction), up to CH chunks of an entry in flight, the next entry's
-// loads issued before the current one is accumulated (two register sets, unrolled by hand: no moves).
-struct __attribute__((aligned(16))) LeanEnt {
-    int kb, ke;
-    acc_t av;  // aval as acc_t: 16 bytes in both builds
-};
-
-template <int BS, int CH>
-__device__ __forceinline__ void lean_accumulate(const int *__restrict__ acol, const real *__restrict__ aval,
-                                                const int *__restrict__ brpt, const int *__restrict__ bcol,
-                                                const real *__restrict__ bval, int bnnz, int a_beg, int a_end,
-                                                int lo, acc_t *dense, LeanEnt *s_ent, int G, int abl = 0)
-{
-    const int lg = 31 - __clz(G);
-    const int gid = (int)threadIdx.x >> lg, gl = (int)threadIdx.x & (G - 1);
-    const int NG = BS >> lg;
-    const unsigned last = (unsigned)(bnnz - 1);
-    acc_t *win = dense - lo;
-    struct Buf {
-        int c[CH];
-        real v[CH];
-    };
-    auto issue = [&](const LeanEnt &E, Buf &b) {
-#pragma unroll
-        for (int q = 0; q < CH; q++) {
-            const unsigned k = (unsigned)(E.kb + gl + q * G);
-            const unsigned kk = k < last ? k : last;  // past the row: a valid address, masked at the add
-            if (abl & 2) {  // ablation: no loads of B
-                b.c[q] = lo + (int)(kk & 1023);
-                b.v[q] = (real)kk;
-            } else {
-                b.c[q] = bcol[kk];
-                b.v[q] = bval[kk];
-            }
-        }
-    };
-    acc_t abl_sum = 0;
-    auto consume = [&](const LeanEnt &E, const Buf &b) {
-#pragma unroll
-        for (int q = 0; q < CH; q++)
-            if (E.kb + gl + q * G < E.ke) {
-                if (abl & 1) abl_sum += (acc_t)((real)E.av * b.v[q]) + (acc_t)b.c[q];  // ablation: no LDS atomics
-                else unsafeAtomicAdd(win + b.c[q], (acc_t)((real)E.av * b.v[q]));
-            }
-        // B rows longer than CH chunks (rare: G is chosen from the longest row): plain loop
-        for (int k = E.kb + gl + CH * G; k < E.ke; k += G) unsafeAtomicAdd(win + bcol[k], (acc_t)((real)E.av * bval[k]));
-    };
-    for (int a0 = a_beg; a0 < a_end; a0 += BS) {
-        LeanEnt me;
-        me.kb = 0, me.ke = 0, me.av = 0;
-        const int j = a0 + (int)threadIdx.x;
-        if (j < a_end) {
-            const int c = __builtin_nontemporal_load(acol + j);
-            me.av = (acc_t)__builtin_nontemporal_load(aval + j);
-            struct __attribute__((aligned(4))) I2 {
-                int b, e;
-            };
-            const I2 r = *reinterpret_cast<const I2 *>(brpt + c);
-            me.kb = r.b, me.ke = r.e;
-        }
-        s_ent[threadIdx.x] = me;
-        __syncthreads();
-        const int nb = a_end - a0 < BS ? a_end - a0 : BS;
-        const int per = (nb + NG - 1) / NG;
-        const int e0 = gid * per;
-        const int e1 = e0 + per < nb ? e0 + per : nb;
-        if (e0 < e1 && !(abl & 4)) {
-            Buf b0, b1;
-            LeanEnt E0 = s_ent[e0], E1;
-            issue(E0, b0);
-            int e = e0;
-            while (true) {
-                const bool more1 = e + 1 < e1;
-                if (more1) {
-                    E1 = s_ent[e + 1];
-                    issue(E1, b1);
-                }
-                consume(E0, b0);
-                if (!more1) break;
-                const bool more0 = e + 2 < e1;
-                if (more0) {
-                    E0 = s_ent[e + 2];
-                    issue(E0, b0);
-                }
-                consume(E1, b1);
-                if (!more0) break;
-                e += 2;
-            }
-        }
-        __syncthreads();
-    }
-    if ((abl & 1) && abl_sum == (acc_t)-1.2345) dense[0] = abl_sum;
-}
-
-// lanes per B row for the lean walk: the smallest power of two that covers the longest B row of the C
-// row in CH chunks, at least 8 (a quarter of a 128-byte line of columns), at most 64
+// lanes per B row for the one-entry-per-lane walk of the node-block kernel (block.h): the smallest power
+// of two that covers the longest B row of the C row in CH chunks, at least 8 (a quarter of a 128-byte line
+// of columns), at most 64
 __device__ __forceinline__ int lean_group(int maxb, int CH)
 {
     int g = 8;
@@ -263,7 +159,7 @@ __device__ __forceinline__ int lean_group(int maxb, int CH)
     return g;
 }
 
-template <int BS, int SPAN_MAX, int MODE, bool LEAN>
+template <int BS, int SPAN_MAX, int MODE>
 __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                   const real *__restrict__ aval,
                                                   const int *__restrict__ brpt, const int *__restrict__ bcol,
@@ -277,15 +173,15 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
                                                   const int *__restrict__ row_span, int bin_off,
                                                   int bin_size, int bnnz,
                                                   const int *__restrict__ bm_off,
-                                                  const unsigned int *__restrict__ bm, int abl)
+                                                  const unsigned int *__restrict__ bm)
 {
     // MODE 1: full call -- the column structure of the row comes from the bitmap written by
     //         k_sym_dense; columns and values are emitted in ascending order.
     // MODE 2: numeric-only re-run -- C.col exists; values are gathered at its columns.
     constexpr int NW = BS / 64;
     acc_t *dense = reinterpret_cast<acc_t *>(nsp_dyn_lds);  // dynamic: (widest window of the bin + 4) values
-    // the walk's scratch: the generic walk parks (B extent, A value) per thread, the lean one a 16-byte record
-    __shared__ __attribute__((aligned(16))) unsigned char s_walk[BS * (LEAN ? sizeof(LeanEnt) : sizeof(int2) + sizeof(real))];
+    __shared__ int2 s_ext[BS];
+    __shared__ real s_av[BS];
     __shared__ int s_wcnt[NW];
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
@@ -293,35 +189,22 @@ __global__ __launch_bounds__(BS) void k_num_dense(const int *__restrict__ arpt, 
     const int off = crpt[rid];
     const int lo = row_lo[rid];
     const int span = row_span[rid];
-    // Generic walk: the VW entries a lane holds have consecutive columns inside a run, so one atomic
+    // The VW entries a lane holds have consecutive columns inside a run, so one atomic
     // instruction sees columns of stride VW across the lanes: the value of column idx lives at
     // (idx & 3) * Q + (idx >> 2), which turns that stride into consecutive 8-byte slots.
-    // Lean walk: consecutive lanes hold consecutive entries; the window is indexed plainly.
     const int Q = (span + 3) >> 2;
-    auto slot_of = [&](int idx) { return LEAN ? idx : __mul24(idx & 3, Q) + (idx >> 2); };
+    auto slot_of = [&](int idx) { return __mul24(idx & 3, Q) + (idx >> 2); };
     for (int i = threadIdx.x; i < 4 * Q; i += BS) dense[i] = 0;
     __syncthreads();
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    if (LEAN) {
-        constexpr int CH = 4;
-        lean_accumulate<BS, CH>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, lo, dense,
-                                reinterpret_cast<LeanEnt *>(s_walk), (abl >> 8) ? (abl >> 8) : lean_group(row_maxb[rid], CH), abl & 255);
-    } else {
-        int2 *s_ext = reinterpret_cast<int2 *>(s_walk);
-        real *s_av = reinterpret_cast<real *>(s_walk + BS * sizeof(int2));
-        const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
-        walk_products<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av,
-                                [&](const IVec &k, const RVec &v, int n, real sc) {
+    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
+    walk_products<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av,
+                            [&](const IVec &k, const RVec &v, int n, real sc) {
 #pragma unroll
-                                    for (int i = 0; i < VW; i++)
-                                        if (i < n) {
-                                            const int idx = k.v[i] - lo;
-                                            unsafeAtomicAdd(dense + __mul24(idx & 3, Q) + (idx >> 2), (acc_t)(sc * v.v[i]));
-                                        }
-                                });
-    }
+                                for (int i = 0; i < VW; i++)
+                                    if (i < n) unsafeAtomicAdd(dense + slot_of(k.v[i] - lo), (acc_t)(sc * v.v[i]));
+                            });
     __syncthreads();
-    if (abl & 8) return;  // diagnostics: no emission
     if (MODE == 2) {
         const int n = crpt[rid + 1] - off;
         for (int p = threadIdx.x; p < n; p += BS) {

@@ -577,11 +577,11 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         /* the first kernel keeps at most two bitmap words per lane: widest windows need 512 threads */ \
         constexpr int BSO = (SPAN / (BS / 64) + 2047) / 2048 <= 2 ? BS : 512;                  \
         static bool big_ok = false;                                                            \
-        allow_big_lds(k_num_dense<BSO, SPAN, MODEX, false>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
-        hipLaunchKernelGGL((k_num_dense<BSO, SPAN, MODEX, false>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BSO), \
+        allow_big_lds(k_num_dense<BSO, SPAN, MODEX>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
+        hipLaunchKernelGGL((k_num_dense<BSO, SPAN, MODEX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BSO), \
                            lds, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,      \
                            c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[bin_],  \
-                           hist[bin_], b->nnz, bm_off, bm, 0);                                 \
+                           hist[bin_], b->nnz, bm_off, bm);                                    \
     }
 #define NSP_NUM_BLOCK_GO(BS, SPAN, MODEX)                                                       \
     {                                                                                          \
