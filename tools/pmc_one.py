@@ -61,6 +61,9 @@ def main():
             spmv(lib, A)
             k, p, s = STANDINS["nlpkkt120"]
             spmv(lib, synth(lib, k, *p, s))
+    elif what == "spmv_hbm":
+        k, p, s = STANDINS["nlpkkt120"]
+        spmv(lib, synth(lib, k, *p, s))
     elif what == "irregular":
         k, p, s = STANDINS["cant_irregular"]
         spgemm(lib, synth(lib, k, *p, s))
