@@ -484,6 +484,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // taking the wide rows there is no limit
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
                            (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
+    static const int tb_pad = getenv("NSPARSE_TB_PAD") ? atoi(getenv("NSPARSE_TB_PAD")) : 0;  // diagnostics: LDS padding of the numeric hash kernels
     constexpr int kBlkU = 4;  // tasks in flight per lane in the node-block kernel
     // diagnostics: extra dynamic LDS per workgroup = fewer groups in flight per CU (what bounds the kernel?)
     static const int blk_pad = getenv("NSPARSE_BLK_PAD") ? atoi(getenv("NSPARSE_BLK_PAD")) : 0;
@@ -559,7 +560,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         L.free_later(slab);
     }
 #define NSP_NUM_TB_GO(BS, TMAX, PMAX, COOPX)                                                    \
-    hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX, COOPX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, arpt, \
+    hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX, COOPX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), tb_pad, st, arpt, \
                        acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm,    \
                        row_prod, row_maxb, off[bin_], hist[bin_], b->nnz, write_col)
 #define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
