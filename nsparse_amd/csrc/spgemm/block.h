@@ -105,7 +105,7 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
         }
     };
     constexpr int NW = BS / 64;
-    constexpr int PARK = BS < 256 ? BS : 256;  // A entries parked per batch
+    constexpr int PARK = BS < 96 ? BS : (BS <= 128 ? 96 : 256);  // A entries parked per batch (a 27-point node stencil has 81; LDS per group bounds the groups in flight)
     constexpr int NWORDS = SPAN_MAX / 32 + 2;
     // The accumulators are COMPACT: the value of column c lives at rank(c) = number of columns of the
     // row below c, read off the bitmap (prefix of the word + popcount inside it).  A row of a
