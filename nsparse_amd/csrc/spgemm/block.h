@@ -37,40 +37,39 @@ constexpr int kBlkRun = 3;         // twin rows of B per run
 constexpr int kBlkAccElems = 4608;  // LDS budget of the accumulator rows of one workgroup (36 KiB)
 
 // grp[r]: bits 0-1 = position of row r inside its group (0: head), bits 2-3 = rows in the group (heads).
-// A group = up to `cap` consecutive rows of one twin chain, cap = how many accumulator rows of this
-// row's nnz fit the LDS budget.  One wavefront per 64-row segment (twin chains never cross multiples
-// of kTwinRun = 64 rows).  Only rows the numeric window bins take form groups.
-__global__ __launch_bounds__(256) void k_twin_groups(const unsigned char *__restrict__ twin,
+// A group = a pattern leader and its first (up to two) twins (k_twin_find: members[]), as many of them
+// as accumulator rows of this pattern's nnz fit the LDS budget; later twins of the same leader and rows
+// outside the numeric window bins are groups of one.  Every row decides for itself from its leader's
+// numbers, so heads and followers agree without talking.
+__global__ __launch_bounds__(256) void k_twin_groups(const int *__restrict__ twin_of,
+                                                     const int *__restrict__ members,
                                                      const int *__restrict__ row_span_num,
                                                      const int *__restrict__ row_nz,
                                                      const int *__restrict__ row_prod, Thr num_thr, int M,
                                                      unsigned char *__restrict__ grp)
 {
-    static_assert(kTwinRun == 64, "one wavefront per chain segment");
-    const int lane = threadIdx.x & 63;
-    const int r = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64 + lane;
-    const bool valid = r < M;
-    const bool t = valid && twin[r] != 0;
-    const unsigned long long heads = __ballot(valid && !t);
-    const unsigned long long vm = __ballot(valid);
-    if (!valid) return;
-    const int nvalid = __popcll(vm);
-    const unsigned long long below = heads & ((2ull << lane) - 1ull);
-    const int h = below ? 63 - __clzll((long long)below) : lane;  // lane of the chain head (lane 0 is one)
-    const unsigned long long above = lane < 63 ? heads >> (lane + 1) : 0ull;
-    const int end = above ? lane + 1 + (__ffsll((long long)above) - 1) : nvalid;
-    const int span = row_span_num[r];  // twins carry their head's numbers (k_twin_copy)
-    const int nzs = ((row_nz[r] + 7) >> 3) << 3;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= M) return;
+    const int l = twin_of[r];
+    const int lead = l >= 0 ? l : r;
+    const int span = row_span_num[lead];
+    const int nzs = ((row_nz[lead] + 7) >> 3) << 3;
     // only rows the numeric binning will put into a window bin (the same rule, bin_of): the followers
     // of a group are left out of the bin lists, which only the node-block kernel understands
-    const bool windowed = span > 0 && nzs > 0 && bin_of(row_nz[r], span, num_thr, row_prod[r]) >= kDenseBin0;
+    const bool windowed = span > 0 && nzs > 0 && bin_of(row_nz[lead], span, num_thr, row_prod[lead]) >= kDenseBin0;
     int cap = windowed ? kBlkAccElems / nzs : 1;
     cap = cap < 1 ? 1 : (cap > kBlkRows ? kBlkRows : cap);
-    const int pos = lane - h;
-    const int gpos = pos % cap;
-    int gsize = end - (lane - gpos);
-    gsize = gsize > cap ? cap : gsize;
-    grp[r] = (unsigned char)(gpos | (gsize << 2));
+    const int m0 = members[kGroupMembers * lead], m1 = members[kGroupMembers * lead + 1];
+    const int nf = m0 < 0 ? 0 : (m1 != m0 ? 2 : 1);  // the lowest and the highest follower that signed up
+    const int gsize = 1 + nf < cap ? 1 + nf : cap;  // rows in the leader's group
+    int code = 1 << 2;                               // a group of one
+    if (l < 0) {
+        code = gsize << 2;
+    } else {
+        const int pos = r == m0 ? 1 : (r == m1 ? 2 : 0);  // which member am I?  (other twins: none)
+        if (pos > 0 && pos < gsize) code = pos;
+    }
+    grp[r] = (unsigned char)code;
 }
 
 template <int BS, int SPAN_MAX, int MODE, int U>
@@ -89,7 +88,8 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                                                   const unsigned int *__restrict__ bm,
                                                   const unsigned char *__restrict__ grp,
                                                   const unsigned char *__restrict__ btwin,
-                                                  unsigned long long *__restrict__ prof)
+                                                  unsigned long long *__restrict__ prof,
+                                                  const int *__restrict__ members)
 {
     // MODE 1: full call (structure = the column bitmap k_sym_dense wrote); MODE 2: numeric-only re-run
     // (structure = C.col, the bitmap is rebuilt from it).
@@ -134,11 +134,14 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
     }
     const int lo = row_lo[rid];
     const int span = row_span[rid];
+    // the rows of the group: the head (a pattern leader) and the twins recorded as its members -- any
+    // rows of the matrix, not necessarily neighbours
     int off[kBlkRows], a_beg[kBlkRows];
 #pragma unroll
     for (int r = 0; r < kBlkRows; r++) {
-        off[r] = r < RA ? crpt[rid + r] : 0;
-        a_beg[r] = r < RA ? arpt[rid + r] : 0;
+        const int rr = (r == 0 || r >= RA) ? rid : members[kGroupMembers * rid + r - 1];
+        off[r] = r < RA ? crpt[rr] : 0;
+        a_beg[r] = r < RA ? arpt[rr] : 0;
     }
     const int nz = crpt[rid + 1] - off[0];
     const int nzs = ((nz + 7) >> 3) << 3;  // the number k_twin_groups sized the group with

@@ -71,7 +71,7 @@ constexpr int kLongCap = 1 << 16;
 constexpr int kDenseBin0 = 6;
 constexpr int kBitsBin0 = 9;
 constexpr int kSetupMaxGrid = 16384;
-constexpr int kTwinRun = 64;  // twin rows (k_row_products): every kTwinRun-th row is kept
+constexpr int kGroupMembers = 2;  // twins of a leader that are recorded as its numeric group (block.h: 3 rows)
 constexpr int kPartialStride = 16;  // long longs per block: hist[NB], max, total, bm, alen
 constexpr int kSymLargeT = 32768;
 constexpr int kSymLargeLimit = 24576;

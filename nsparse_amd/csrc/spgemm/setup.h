@@ -171,6 +171,98 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
     }
 }
 
+// contribution of one column id to the order-independent key of a row pattern (splitmix64 finaliser)
+__device__ __forceinline__ unsigned long long col_key(int c)
+{
+    unsigned long long z = (unsigned long long)(unsigned)c + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Rows of A with EQUAL column patterns ("twin rows": the degrees of freedom of one mesh node), wherever
+// they are: a hash map from pattern to the first row that claimed it, probed by the W lanes that have
+// just walked the row in k_row_products.  An empty slot is claimed with one CAS (the row becomes the
+// LEADER of its pattern); an occupied one is compared column by column with its owner -- equal: the row
+// is a twin of that leader, else the next slot.  A twin does not go through the symbolic phase
+// (k_twin_copy hands it the leader's result); the lowest and the highest twin that signed up are recorded as
+// its group members for the numeric window kernel (block.h).  table / fcnt / members start as all ones.
+struct TwinMap {
+    unsigned long long *table;  // slot -> (first entry of the leader's row << 32 | leader row); ~0 = free
+    unsigned int mask;           // slots - 1
+    int a_nnz;
+    int *twin_of;  // row -> leader or -1
+    unsigned char *twin;
+    int *fcnt;     // leader -> followers that signed up - 1 (only a brake, see below)
+    int *members;  // leader -> the lowest and the highest of the followers that signed up (-1: none)
+};
+
+template <int W>
+__device__ __forceinline__ int twin_probe(const int *__restrict__ arpt, const int *__restrict__ acol, int r,
+                                          unsigned long long key, const TwinMap &tm, int lane)
+{
+    const int beg = arpt[r], len = arpt[r + 1] - beg;
+    int leader = -1;
+    if (len > 0) {
+        key += 0x9E3779B97F4A7C15ull * (unsigned long long)len;
+        unsigned int b = (unsigned int)(key >> 20) & tm.mask;
+        const unsigned long long mine = ((unsigned long long)(unsigned int)beg << 32) | (unsigned int)r;
+        while (true) {
+            unsigned long long cur = 0;
+            if (lane == 0) {
+                cur = __hip_atomic_load(tm.table + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == ~0ull) {
+                    const unsigned long long old = atomicCAS(tm.table + b, ~0ull, mine);
+                    cur = old == ~0ull ? mine : old;
+                }
+            }
+            cur = __shfl(cur, 0, W);
+            if (cur == mine) break;  // this row leads its pattern
+            const int lrow = (int)(unsigned int)cur, cb = (int)(cur >> 32);
+            // the owner's length and its columns in one round of loads (indices clamped: a shorter owner
+            // must not be read past the end of A)
+            const int ce = arpt[lrow + 1];
+            int differs = 0;
+            for (int j = lane; j < len; j += 4 * W) {
+                int x[4], y[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int jj = j + u * W < len ? j + u * W : len - 1;
+                    const int k2 = cb + jj < tm.a_nnz ? cb + jj : tm.a_nnz - 1;
+                    x[u] = acol[beg + jj];
+                    y[u] = acol[k2];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) differs |= x[u] != y[u];
+            }
+            differs |= (ce - cb) != len;
+#pragma unroll
+            for (int o = W / 2; o >= 1; o >>= 1) differs |= __shfl_xor(differs, o);
+            if (!differs) {
+                leader = lrow;
+                break;
+            }
+            b = (b + 1) & tm.mask;
+        }
+    }
+    if (lane == 0) {
+        tm.twin_of[r] = leader;
+        tm.twin[r] = leader >= 0 ? 1 : 0;
+        // sign up as a group member: no value comes back, nothing waits.  The counter is only a brake:
+        // the thousands of one-entry rows that point at the same hub page would otherwise queue on
+        // three addresses.
+        if (leader >= 0 &&
+            __hip_atomic_load(tm.fcnt + leader, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kGroupMembers - 1) {
+            __hip_atomic_fetch_add(tm.fcnt + leader, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_min((unsigned int *)tm.members + kGroupMembers * leader, (unsigned int)r,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_max(tm.members + kGroupMembers * leader + 1, r, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    return leader;
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ arpt,
                                                       const int *__restrict__ acol,
@@ -185,14 +277,13 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
                                                       int *__restrict__ row_maxb,
                                                       int *__restrict__ long_list, int *long_cnt,
                                                       int long_len, const int *__restrict__ todo,
-                                                      unsigned char *__restrict__ twin)
+                                                      TwinMap tw)
 {
     // todo == nullptr: bulk pass, rows of A longer than long_len are deferred to long_list;
     // todo != nullptr: the deferred rows (see kLongFactor)
-    // twin != nullptr: twin[row] = 1 when the row has the column pattern of the row before it (the
-    // degrees of freedom of one node of a finite-element mesh).  Its row of C then has the structure
-    // of that row's: it is left out of the symbolic bins and k_twin_copy hands it the result.  Every
-    // kTwinRun-th row is kept, so a run of twins is at most kTwinRun - 1 rows long.
+    // tw.table != nullptr: an order-independent 64-bit key of the row's column pattern is summed on the
+    // way and twin_probe groups the rows with EQUAL patterns (the degrees of freedom of one node of a
+    // finite-element mesh, wherever the numbering put them).
     const int nrows = todo ? (*long_cnt < kLongCap ? *long_cnt : kLongCap) : M;
     if (!todo && blockIdx.x == 0 && threadIdx.x == 0) {  // scan tails (instead of two memset launches)
         bm_words[M] = 0;
@@ -227,25 +318,18 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             }
             if (__shfl(ok, 0, W) != 0) row = M;  // deferred: nothing to do for this group now
         }
-        int differs = 1;  // from the row before
+        unsigned long long key = 0;
         if (row < M) {
             const int e = arpt[row + 1];
-            const int len = e - arpt[row];
-            // candidate twin: same length as the row before, which then ends where this one starts
-            // (and the same first column: rows of equal length that are NOT twins -- a stencil -- then skip
-            //  the comparison of the other entries)
-            const bool cand = twin && len > 0 && row % kTwinRun != 0 && arpt[row] - arpt[row - 1] == len &&
-                              acol[arpt[row]] == acol[arpt[row] - len];
-            differs = cand ? 0 : 1;
             int j = arpt[row] + lane;
             for (; j + 3 * W < e; j += 4 * W) {  // four independent gathers in flight
                 int c[4];
                 BInfo bi[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) c[u] = __builtin_nontemporal_load(acol + j + u * W);
-                if (cand) {
+                if (tw.table) {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) differs |= acol[j + u * W - len] != c[u];
+                    for (int u = 0; u < 4; u++) key += col_key(c[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; u++) bi[u] = binfo[c[u]];
@@ -259,7 +343,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             }
             for (; j < e; j += W) {
                 const int c = __builtin_nontemporal_load(acol + j);
-                if (cand) differs |= acol[j - len] != c;
+                if (tw.table) key += col_key(c);
                 const BInfo bi = binfo[c];
                 n += bi.len;
                 mb = bi.len > mb ? bi.len : mb;
@@ -271,11 +355,13 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
         for (int o = W / 2; o >= 1; o >>= 1) {
             n += __shfl_xor(n, o);
             const int l = __shfl_xor(lo, o), h = __shfl_xor(hi, o), m2 = __shfl_xor(mb, o);
-            differs |= __shfl_xor(differs, o);
+            key += __shfl_xor(key, o);
             lo = l < lo ? l : lo;
             hi = h > hi ? h : hi;
             mb = m2 > mb ? m2 : mb;
         }
+        int leader = -1;
+        if (tw.table && row < M) leader = twin_probe<W>(arpt, acol, row, key, tw, lane);
         int bin = -1;
         if (row < M && lane == 0) {
             const int ni = n > 0x7fffffffLL ? 0x7fffffff : (int)n;  // saturate (hub rows)
@@ -285,13 +371,12 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             row_lo[row] = hi >= lo ? lo : 0;
             row_span[row] = span;
             row_maxb[row] = mb;
-            // words of the column bitmap the symbolic dense kernel hands to the numeric one
-            const bool is_twin = differs == 0;
-            if (twin) twin[row] = is_twin ? 1 : 0;
-            const int bw = (span > 0 && span <= bm_span_max && !is_twin) ? (span + 31) >> 5 : 0;  // twins share
+            // words of the column bitmap the symbolic dense kernel hands to the numeric one (twins share
+            // their leader's and stay out of the symbolic bins)
+            const int bw = (leader < 0 && span > 0 && span <= bm_span_max) ? (span + 31) >> 5 : 0;
             bm_words[row] = bw;
             row_span_num[row] = 0;  // set by k_sym_dense when it hands a bitmap over
-            bin = is_twin ? -1 : bin_of(ni, span, thr, ni);
+            bin = leader < 0 ? bin_of(ni, span, thr, ni) : -1;
             const int al = arpt[row + 1] - arpt[row];
             if (W >= 16) {  // at most 4 rows per wave: direct LDS atomics are cheapest
                 if (bin >= 0) atomicAdd(&s_hist[bin], 1);
@@ -396,14 +481,14 @@ __global__ __launch_bounds__(64) void k_publish(const BinState *__restrict__ src
 }
 
 // Rows left out of the symbolic bins as twins take the result of the row they repeat.
-__global__ __launch_bounds__(256) void k_twin_copy(const unsigned char *__restrict__ twin, int M,
+__global__ __launch_bounds__(256) void k_twin_copy(const int *__restrict__ twin_of, int M,
                                                    int *__restrict__ row_nz, int *__restrict__ row_span_num,
                                                    int *__restrict__ bm_off)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (r >= M || !twin[r]) return;
-    int l = r - 1;
-    while (l > 0 && twin[l]) l--;  // at most kTwinRun - 2 steps; row 0 is never a twin
+    if (r >= M) return;
+    const int l = twin_of[r];
+    if (l < 0) return;
     row_nz[r] = row_nz[l];
     row_span_num[r] = row_span_num[l];
     if (bm_off) bm_off[r] = bm_off[l];

@@ -144,7 +144,7 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *bin
                                 int *row_prod, int *row_lo, int *row_span, int *bm_words,
                                 int bm_span_max, const Thr &thr, BinState *d_bs, long long *partial,
                                 int *row_span_num, int *row_nz, int *row_maxb, int *long_list,
-                                int *long_cnt, unsigned char *twin, hipStream_t st)
+                                int *long_cnt, TwinMap tw, hipStream_t st)
 {
     const int M = a->M;
     const int w = pick_w_regular(a->nnz, M, a->nnz_max);
@@ -159,7 +159,7 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *bin
         hipLaunchKernelGGL(k_row_products<W>, dim3(grid), dim3(256), 0, st, a->d_rpt, a->d_col, \
                            binfo, M, row_prod, row_lo, row_span, bm_words, bm_span_max, thr,   \
                            partial, row_span_num, row_nz, row_maxb, long_list, long_cnt,       \
-                           kLongFactor * W, no_todo, twin);                                    \
+                           kLongFactor * W, no_todo, tw);                                      \
         break;
     switch (w) {
         NSP_RP(1) NSP_RP(2) NSP_RP(4) NSP_RP(8) NSP_RP(16) NSP_RP(32) NSP_RP(64)
@@ -170,7 +170,7 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *bin
         hipLaunchKernelGGL(k_row_products<64>, dim3(256), dim3(256), 0, st, a->d_rpt, a->d_col, binfo, M,
                            row_prod, row_lo, row_span, bm_words, bm_span_max, thr,
                            partial + (long long)grid * kPartialStride, row_span_num, row_nz, row_maxb,
-                           (int *)nullptr, long_cnt, 0, (const int *)long_list, twin);
+                           (int *)nullptr, long_cnt, 0, (const int *)long_list, tw);
         grid += 256;
     }
     hipLaunchKernelGGL(k_reduce_partials, dim3(grid < 32 ? grid : 32), dim3(256), 0, st, partial, grid, d_bs);
@@ -462,7 +462,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                                  float *ms_bin, int write_col, const int *bm_off,
                                  const unsigned int *bm, int max_alen, bool b_sorted,
                                  const int *max_span, const unsigned char *grp, const unsigned char *btwin,
-                                 const int *listed)
+                                 const int *listed, const int *members)
 {
     int hist[NB], off[NB + 1];
     fold_small_hash_bins(hist_in, hist, off);
@@ -593,7 +593,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         hipLaunchKernelGGL((k_num_block<BS, SPAN, MODEX, kBlkU>), dim3(8 * ceil_div(heads, 8)), dim3(BS), \
                            lds_blk, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
                            c->d_val, row_perm, row_maxb, row_lo, row_span, off[bin_],            \
-                           heads, b->nnz, bm_off, bm, grp, btwin, blk_prof);                   \
+                           heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members);          \
     }
 #define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
@@ -652,7 +652,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
 #define NSP_RANKWIN(MODEX)                                                                      \
     hipLaunchKernelGGL((k_num_block<128, 65536, MODEX, kBlkU>), dim3(8 * ceil_div(heads, 8)), dim3(128), lds_blk, st, \
                        arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_maxb, \
-                       row_lo, row_span, off[bin_], heads, b->nnz, bm_off, bm, grp, btwin, blk_prof)
+                       row_lo, row_span, off[bin_], heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members)
         if (write_col & 1) NSP_RANKWIN(1); else NSP_RANKWIN(2);
 #undef NSP_RANKWIN
         NSP_LAUNCH_CHECK();
@@ -857,11 +857,29 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     int *bm_off = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_span_num = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
-    // rows that repeat the column pattern of the row before them are not run through the symbolic
-    // phase: they take that row's result (k_twin_copy).  NSPARSE_TWINS=0 switches the detection off.
-    unsigned char *twin = (!numeric_only && twins_on && M > 1) ? (unsigned char *)dev_alloc((size_t)M) : nullptr;
+    // rows with the column pattern of another row are not run through the symbolic phase: they take that
+    // row's result (k_twin_find / k_twin_copy).  NSPARSE_TWINS=0 switches the detection off.
+    const bool find_twins = !numeric_only && twins_on && M > 1;
+    unsigned char *twin = nullptr;
+    int *twin_of = nullptr, *fcnt = nullptr, *members = nullptr;
+    unsigned long long *ttable = nullptr;
+    TwinMap tw = {nullptr, 0u, 0, nullptr, nullptr, nullptr, nullptr};
+    if (find_twins) {
+        unsigned int tsize = 1024;
+        while (tsize < 2u * (unsigned int)M) tsize <<= 1;
+        // table, sign-up counters and members in one block, one fill (all ones = free / -1 / none)
+        ttable = (unsigned long long *)dev_alloc(sizeof(unsigned long long) * (size_t)tsize +
+                                                 sizeof(int) * (size_t)M * (1 + kGroupMembers));
+        fcnt = (int *)(ttable + tsize);
+        members = fcnt + M;
+        twin_of = (int *)dev_alloc(sizeof(int) * (size_t)M);
+        twin = (unsigned char *)dev_alloc((size_t)M);
+        NSP_CHECK(hipMemsetAsync(ttable, 0xff, sizeof(unsigned long long) * (size_t)tsize +
+                                                   sizeof(int) * (size_t)M * (1 + kGroupMembers), s0));
+        tw = TwinMap{ttable, tsize - 1, a->nnz, twin_of, twin, fcnt, members};
+    }
     launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
-                        use_bm ? (num_thr.rank_span > num_thr.dense_span[2] ? num_thr.rank_span : num_thr.dense_span[2]) : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, twin, s0);
+                        use_bm ? (num_thr.rank_span > num_thr.dense_span[2] ? num_thr.rank_span : num_thr.dense_span[2]) : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, tw, s0);
     void *bm_scan_tmp = nullptr;
     if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
     const int grid_m = ceil_div(M, 1024);
@@ -905,7 +923,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
             for (int q = 0; q < NB; q++) binned += h_sym->hist[q];
             S.twin_rows = twin ? (int)(M - binned) : 0;
             if (S.twin_rows > 0) {
-                hipLaunchKernelGGL(k_twin_copy, dim3(ceil_div(M, 256)), dim3(256), 0, s0, (const unsigned char *)twin, M,
+                hipLaunchKernelGGL(k_twin_copy, dim3(ceil_div(M, 256)), dim3(256), 0, s0, (const int *)twin_of, M,
                                    row_nz, row_span_num, bm ? bm_off : (int *)nullptr);
                 NSP_LAUNCH_CHECK();
             }
@@ -913,8 +931,9 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
             // of the rows has a twin (a finite-element matrix), not for a few chance repeats
             if (lean_on && bm && (long long)S.twin_rows * 8 >= M) {
                 grp = (unsigned char *)dev_alloc((size_t)M);
-                hipLaunchKernelGGL(k_twin_groups, dim3(ceil_div(M, 256)), dim3(256), 0, s0, (const unsigned char *)twin,
-                                   (const int *)row_span_num, (const int *)row_nz, (const int *)row_prod, num_thr, M, grp);
+                hipLaunchKernelGGL(k_twin_groups, dim3(ceil_div(M, 256)), dim3(256), 0, s0, (const int *)twin_of,
+                                   (const int *)members, (const int *)row_span_num,
+                                   (const int *)row_nz, (const int *)row_prod, num_thr, M, grp);
                 NSP_LAUNCH_CHECK();
             }
         }
@@ -967,7 +986,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_maxb, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
-                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor);
+                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor, members);
     tm.mark(3, s0);
     {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
         const int seq = ++cx.seq;
@@ -996,6 +1015,8 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     dev_free(bm);
     dev_free(bm_scan_tmp);
     if (twin) dev_free(twin);
+    if (ttable) dev_free(ttable);
+    if (twin_of) dev_free(twin_of);
     if (grp) dev_free(grp);
     if (btwin) dev_free(btwin);
     dev_free(row_span_num);

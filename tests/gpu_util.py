@@ -127,20 +127,23 @@ def row_windows(A, B):
     return prod, span
 
 
-TWIN_RUN = 64  # kTwinRun in csrc/spgemm/common.h
-
-
 def twin_rows(A):
-    """Rows of A with the column pattern of the row before them (k_row_products): they are left out
-    of the symbolic bins and take that row's structure.  Every TWIN_RUN-th row is kept."""
+    """Rows of A whose column pattern (the stored sequence of column ids) another row already has
+    (k_twin_find in csrc/spgemm/setup.h): all but one row of every pattern class are left out of the
+    symbolic bins and take that row's structure.  Which row of a class leads is not fixed on the
+    device; the mask marks all but the first, the counts are the same."""
     rpt = np.asarray(A["rpt"], dtype=np.int64)
-    col = np.asarray(A["col"])
+    col = np.ascontiguousarray(A["col"], dtype=np.int32)
     M = len(rpt) - 1
     tw = np.zeros(M, dtype=bool)
-    ln = np.diff(rpt)
-    for r in range(1, M):
-        if r % TWIN_RUN and ln[r] > 0 and ln[r] == ln[r - 1]:
-            tw[r] = np.array_equal(col[rpt[r]:rpt[r + 1]], col[rpt[r - 1]:rpt[r]])
+    seen = set()
+    for r in range(M):
+        if rpt[r + 1] > rpt[r]:
+            k = col[rpt[r]:rpt[r + 1]].tobytes()
+            if k in seen:
+                tw[r] = True
+            else:
+                seen.add(k)
     return tw
 
 

@@ -110,7 +110,8 @@ def test_config3_webbase_class_fp32(lib_s, oracle_s, oracle_d):
         assert A["M"] == 1000005
         assert abs(int(A["rpt"][-1]) - 3105536) < 0.02 * 3105536
         assert abs(tot - 69.5e6) < 0.03 * 69.5e6 and abs(ref["nnz"] - 51.1e6) < 0.03 * 51.1e6
-    assert st.sym_bin_size[0] > 0.5 * A["M"] and sum(list(st.sym_bin_size)[3:]) > 0, "not a binning stress"
+    # (rows with the pattern of another row -- the many pages that link to one hub only -- are not binned)
+    assert st.sym_bin_size[0] + st.twin_rows > 0.5 * A["M"] and sum(list(st.sym_bin_size)[3:]) > 0, "not a binning stress"
 
 
 # ------------------------------------------------------------------------------ config 4

@@ -356,11 +356,11 @@ def test_wide_windows_take_the_window_bins(lib_d, oracle_d):
 
 @pytest.mark.parametrize("prec", ["d", "s"])
 def test_twin_rows_take_their_leaders_structure(prec, lib_d, lib_s, oracle_d, oracle_s):
-    """Rows of A that repeat the column pattern of the row before them (different values) are left out
-    of the symbolic bins.  Runs of every length (a run of 150 is cut by the kept rows at multiples of
-    64), patterns of 1 .. 1500 entries (tiny, hash and window bins, a deferred long row), a run that
-    starts at row 0, look-alikes that differ in one entry, empty rows, and NSPARSE_TWINS=0 for the
-    same answer; the numeric-only re-run must keep working on the shared structure."""
+    """Rows of A with the column pattern of another row (different values) are left out of the symbolic
+    bins, wherever they are: the rows of the runs below are shuffled.  Classes of 1 .. 150 rows, patterns
+    of 1 .. 1500 entries (tiny, hash and window bins, a deferred long row), look-alikes that differ in
+    one entry, empty rows, and NSPARSE_TWINS=0 for the same answer; the numeric-only re-run must keep
+    working on the shared structure."""
     lib, orc = (lib_d, oracle_d) if prec == "d" else (lib_s, oracle_s)
     rng = np.random.default_rng(2024)
     k = 6000
@@ -373,6 +373,9 @@ def test_twin_rows_take_their_leaders_structure(prec, lib_d, lib_s, oracle_d, or
             alt[-1] = alt[-1] + 1 if alt[-1] + 1 < k and (ln < 2 or alt[-1] + 1 != alt[-2]) else alt[-1]
             pats.append(alt)
     m = len(pats)
+    # half of the rows keep their neighbours, half go anywhere
+    order = np.concatenate([np.arange(m // 2), m // 2 + rng.permutation(m - m // 2)])
+    pats = [pats[i] for i in order]
     rpt = np.zeros(m + 1, dtype=np.int32)
     rpt[1:] = np.cumsum([len(p) for p in pats])
     col = np.concatenate(pats).astype(np.int32)
