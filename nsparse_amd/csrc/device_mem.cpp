@@ -160,7 +160,7 @@ Context &ctx()
         for (auto &e : c.ev_t) NSP_CHECK(hipEventCreate(&e));
         for (auto &e : c.ev_bin) NSP_CHECK(hipEventCreate(&e));
         NSP_CHECK(hipHostMalloc((void **)&c.h_pinned, 512 * sizeof(int), hipHostMallocDefault));
-        NSP_CHECK(hipMalloc((void **)&c.d_scratch, 512 * sizeof(int)));
+        NSP_CHECK(hipMalloc((void **)&c.d_scratch, 8192 * sizeof(int)));
         NSP_CHECK(hipHostMalloc((void **)&c.h_mapped, 256 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
         memset(c.h_mapped, 0, 256 * sizeof(int));
         NSP_CHECK(hipHostGetDevicePointer((void **)&c.d_mapped, c.h_mapped, 0));

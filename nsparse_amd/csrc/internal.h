@@ -58,7 +58,7 @@ struct Context {
     hipEvent_t ev_t[8] = {};            // phase timing
     hipEvent_t ev_bin[4 * kMaxBins] = {};  // per-bin begin/end: [0,2B) symbolic, [2B,4B) numeric
     int *h_pinned = nullptr;            // 512 ints of pinned host memory for small D2H
-    int *d_scratch = nullptr;           // 512 ints of device scratch (counters)
+    int *d_scratch = nullptr;           // 8192 ints of device scratch (counters; 512.. workgroup records of the fused tails)
     int *h_mapped = nullptr;            // 256 ints of mapped, coherent host memory (GPU writes, host polls)
     int *d_mapped = nullptr;            // device address of h_mapped
     int seq = 0;                        // publish sequence number

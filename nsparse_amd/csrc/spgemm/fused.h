@@ -1,0 +1,306 @@
+// spgemm/fused.h -- the tails of the set-up and of the symbolic phase as ONE launch each, for matrices of
+// up to 256 K rows.
+// Part of the spgemm_hash.hip translation unit.
+//
+// Between the big kernels of a call sit chains of 1024-rows-per-workgroup helpers that each run for a
+// microsecond and cost four to five (launch, drain, the dependency on the one before):
+//     set-up:    k_reduce_partials -> scan (2 launches) -> k_bin_scatter -> k_publish          24 us
+//     symbolic:  k_twin_copy -> k_twin_groups -> scan (2) -> k_hist -> k_bin_scatter -> k_publish 32 us
+// of a 360 us product on the cant class.  Here every chain is one kernel of ceil((M + 1) / 1024)
+// workgroups (at most 256: one per CU, all resident) with one grid barrier in the middle -- what needs
+// every row's contribution (histogram, scan carries) is on one side, what consumes it on the other -- and
+// a wavefront of workgroup 0 publishes the counters to the host right behind the barrier.  Same results as
+// the chains they replace (which stay for larger M and for numeric-only calls); NSPARSE_FUSED=0 forces
+// the chains.
+//
+// Cross-workgroup data inside a launch is read with agent-scope atomic loads (never through const
+// __restrict__ pointers: the scalar cache is not part of the memory model), produced before a release
+// fence + atomic arrive, consumed after the acquire side of the barrier.
+#pragma once
+#include "block.h"
+#include "common.h"
+#include "setup.h"
+
+namespace nsp {
+namespace spgemm {
+
+constexpr int kFusedMaxBlocks = 256;
+
+struct FusedSync {
+    int *arrive;    // grid barrier counter (zeroed by the per-call fill)
+    int *blk;       // per workgroup: [0] scan carry, [1 + q] rows it lists in bin q   (kFusedRec ints)
+    int *pub_dst;   // mapped host copy of the counter block
+    int *pub_flag;  // sequence flag the host polls
+    int seq;
+};
+constexpr int kFusedRec = NB + 1;
+
+__device__ __forceinline__ int ld_agent(const int *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// every workgroup of the grid has arrived `round` times
+__device__ __forceinline__ void grid_barrier(int *ctr, int round)
+{
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = round * (int)gridDim.x;
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+            __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+}
+
+// exclusive scan of one int per thread over a 1024-thread workgroup; total = sum of all
+__device__ __forceinline__ int block_scan_1024(int v, int *s_w /* 16 */, int &total)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    int before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const int w = s_w[q];
+        all += w;
+        before += q < wv ? w : 0;
+    }
+    total = all;
+    __syncthreads();
+    return before + inc - v;
+}
+
+// rank of the thread's row inside (workgroup, bin): ballot + popcount inside the wave, one LDS atomic per
+// (wave, bin present in the wave)
+__device__ __forceinline__ int rank_in_bin(int bin, int *s_cnt)
+{
+    const int lane = threadIdx.x & 63;
+    int r = 0;
+    unsigned long long todo = __ballot(bin >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int bb = __shfl(bin, leader);
+        const unsigned long long same = __ballot(bin == bb);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&s_cnt[bb], __popcll(same));
+        base = __shfl(base, leader);
+        if (bin == bb) r = base + __popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    return r;
+}
+
+// Second half, shared by both kernels.  Everything the host wants (histogram, listed rows per bin, maxima,
+// totals) was complete at the barrier, so one wavefront of workgroup 0 publishes at once while the others
+// place their rows: a workgroup's rows follow those of the workgroups before it in every bin (sums of the
+// records written before the barrier -- no atomics, and the lists come out in ascending row order).
+__device__ __forceinline__ void fused_tail(int i, int M, int excl, int *out_scan, int bin, bool listed, int rank,
+                                           int *s_base, int *s_pref /* kFusedRec */, int *s_h /* NB */, BinState *bs,
+                                           int *perm, const FusedSync &fs, bool set_nnz)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    static_assert(kFusedRec + 2 <= 16, "one wavefront per quantity");
+    if (wv < kFusedRec) {
+        int acc = 0;
+        for (int t = lane; t < (int)blockIdx.x; t += 64) acc += ld_agent(fs.blk + t * kFusedRec + wv);
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o);
+        if (lane == 0) s_pref[wv] = acc;
+    } else if (wv == kFusedRec) {
+        if (lane < NB) s_h[lane] = ld_agent(&bs->hist[lane]);
+    } else if (wv == kFusedRec + 1 && blockIdx.x == 0) {
+        constexpr int words = (int)(sizeof(BinState) / 4);
+        static_assert(words <= 64, "one word per lane");
+        const int *s = reinterpret_cast<const int *>(bs);
+        if (lane < words) fs.pub_dst[lane] = ld_agent(s + lane);
+        if (set_nnz && lane == 0)
+            reinterpret_cast<BinState *>(fs.pub_dst)->nnz = ld_agent(reinterpret_cast<const int *>(&bs->total));
+        __threadfence_system();
+        if (lane == 0) __hip_atomic_store(fs.pub_flag, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        int off = 0;
+        for (int q = 0; q < (int)threadIdx.x; q++) off += s_h[q];
+        s_base[threadIdx.x] = off + s_pref[1 + threadIdx.x];
+    }
+    __syncthreads();
+    if (out_scan && i <= M) out_scan[i] = s_pref[0] + excl;
+    if (listed) perm[s_base[bin] + rank] = i;
+}
+
+// ---- set-up tail: fold the per-workgroup partials of k_row_products, offsets of the column bitmaps,
+//      symbolic row permutation, publish ---------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict__ partial, int nparts,
+                                                     BinState *bs, const int *__restrict__ bm_words,
+                                                     int *__restrict__ bm_off,
+                                                     const int *__restrict__ row_prod,
+                                                     const int *__restrict__ row_span, int M, Thr thr,
+                                                     int *__restrict__ perm,
+                                                     const unsigned char *__restrict__ skip, FusedSync fs)
+{
+    __shared__ unsigned long long s_acc[kPartialStride];
+    __shared__ int s_max, s_alen;
+    __shared__ int s_cnt[NB], s_base[NB], s_span[NB], s_w[16], s_pref[kFusedRec], s_h[NB];
+    if (threadIdx.x < kPartialStride) s_acc[threadIdx.x] = 0;
+    if (threadIdx.x < NB) s_cnt[threadIdx.x] = s_span[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_max = s_alen = 0;
+    __syncthreads();
+    // (1) this workgroup's slice of the partials (k_reduce_partials)
+    {
+        const int per = (nparts + (int)gridDim.x - 1) / (int)gridDim.x;
+        const int b0 = blockIdx.x * per, b1 = b0 + per < nparts ? b0 + per : nparts;
+        const int f = threadIdx.x & 15;
+        if (f < NB + 4 && b0 < b1) {
+            long long acc = 0;
+            for (int b = b0 + ((int)threadIdx.x >> 4); b < b1; b += 64) {
+                const long long v = partial[(long long)b * kPartialStride + f];
+                acc = (f == NB || f == NB + 3) ? (v > acc ? v : acc) : acc + v;
+            }
+            if (f == NB) atomicMax(&s_max, (int)acc);
+            else if (f == NB + 3) atomicMax(&s_alen, (int)acc);
+            else if (acc) atomicAdd(&s_acc[f], (unsigned long long)acc);
+        }
+    }
+    // (2) bitmap words of this workgroup's rows, scanned; (3) bin and rank of every listed row
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int v = (bm_words && i <= M) ? bm_words[i] : 0;
+    int total = 0;
+    const int excl = block_scan_1024(v, s_w, total);
+    const bool listed = i < M && !(skip && skip[i]);
+    int bin = -1;
+    if (listed) {
+        const int ni = row_prod[i], sp = row_span[i];
+        bin = bin_of(ni, sp, thr, ni);
+        if (bin >= kDenseBin0) atomicMax(&s_span[bin], sp);
+    }
+    const int rank = rank_in_bin(bin, s_cnt);
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        if (s_acc[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], (int)s_acc[threadIdx.x]);
+        if (s_cnt[threadIdx.x]) atomicAdd(&bs->cursor[threadIdx.x], s_cnt[threadIdx.x]);
+        if (s_span[threadIdx.x]) atomicMax(&bs->max_span[threadIdx.x], s_span[threadIdx.x]);
+        __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec + 1 + threadIdx.x, s_cnt[threadIdx.x], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+        if (s_max) atomicMax(&bs->maxv, s_max);
+        if (s_acc[NB + 1]) atomicAdd((unsigned long long *)&bs->total, s_acc[NB + 1]);
+        if (s_acc[NB + 2]) atomicAdd((unsigned long long *)&bs->bm_total, s_acc[NB + 2]);
+        if (s_alen) atomicMax((unsigned long long *)&bs->max_alen, (unsigned long long)s_alen);
+        __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    grid_barrier(fs.arrive, 1);
+    fused_tail(i, M, excl, bm_words ? bm_off : nullptr, bin, listed, rank, s_base, s_pref, s_h, bs, perm, fs, false);
+}
+
+// ---- symbolic tail: twins take their leader's result, node-block groups, C.rpt, numeric histogram and
+//      row permutation, publish (k_twin_copy, k_twin_groups, scan, k_hist, k_bin_scatter, k_publish) -----
+__global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ twin_of,
+                                                        const int *__restrict__ members, int *row_nz,
+                                                        int *row_span_num, int *bm_off,
+                                                        const int *__restrict__ row_prod, int M, Thr thr,
+                                                        BinState *bs, int *__restrict__ crpt,
+                                                        int *__restrict__ perm, unsigned char *__restrict__ grp,
+                                                        FusedSync fs)
+{
+    __shared__ int s_hist[NB], s_cnt[NB], s_base[NB], s_span[NB], s_w[16], s_pref[kFusedRec], s_h[NB];
+    __shared__ int s_max;
+    __shared__ unsigned long long s_sum;
+    if (threadIdx.x < NB) s_hist[threadIdx.x] = s_cnt[threadIdx.x] = s_span[threadIdx.x] = 0;
+    if (threadIdx.x == 0) {
+        s_max = 0;
+        s_sum = 0;
+    }
+    __syncthreads();
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int nz = 0, bin = -1, hbin = -1;
+    bool listed = false;
+    if (i < M) {
+        const int l = twin_of ? twin_of[i] : -1;
+        const int lead = l >= 0 ? l : i;
+        // a leader is no twin: nobody writes the entries read here
+        nz = row_nz[lead];
+        const int sp = row_span_num[lead];
+        if (l >= 0) {
+            row_nz[i] = nz;
+            row_span_num[i] = sp;
+            if (bm_off) bm_off[i] = bm_off[lead];
+        }
+        const int work = row_prod[i];
+        hbin = bin_of(nz, sp, thr, work);
+        int code = 1 << 2;
+        if (grp) {  // k_twin_groups
+            const int nzs = ((nz + 7) >> 3) << 3;
+            const bool windowed = sp > 0 && nzs > 0 && hbin >= kDenseBin0;
+            int cap = windowed ? kBlkAccElems / nzs : 1;
+            cap = cap < 1 ? 1 : (cap > kBlkRows ? kBlkRows : cap);
+            const int m0 = members[kGroupMembers * lead], m1 = members[kGroupMembers * lead + 1];
+            const int nf = m0 < 0 ? 0 : (m1 != m0 ? 2 : 1);
+            const int gsize = 1 + nf < cap ? 1 + nf : cap;
+            if (l < 0) {
+                code = gsize << 2;
+            } else {
+                const int pos = i == m0 ? 1 : (i == m1 ? 2 : 0);
+                if (pos > 0 && pos < gsize) code = pos;
+            }
+            grp[i] = (unsigned char)code;
+        }
+        listed = (code & 3) == 0;
+        if (listed) {
+            bin = hbin;
+            if (bin >= kDenseBin0) atomicMax(&s_span[bin], sp);
+        }
+    }
+    // histogram of every row (k_hist), longest row, 64-bit total
+    {
+        unsigned long long todo = __ballot(hbin >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int b = __shfl(hbin, leader);
+            const unsigned long long same = __ballot(hbin == b);
+            if ((threadIdx.x & 63) == leader) atomicAdd(&s_hist[b], __popcll(same));
+            todo &= ~same;
+        }
+        int v = nz;
+        unsigned long long sum = (unsigned long long)nz;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int m = __shfl_xor(v, o);
+            v = m > v ? m : v;
+            sum += __shfl_xor(sum, o);
+        }
+        if ((threadIdx.x & 63) == 0) {
+            atomicMax(&s_max, v);
+            atomicAdd(&s_sum, sum);
+        }
+    }
+    int total = 0;
+    const int excl = block_scan_1024(nz, s_w, total);
+    const int rank = rank_in_bin(bin, s_cnt);
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        if (s_hist[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], s_hist[threadIdx.x]);
+        if (s_cnt[threadIdx.x]) atomicAdd(&bs->cursor[threadIdx.x], s_cnt[threadIdx.x]);
+        if (s_span[threadIdx.x]) atomicMax(&bs->max_span[threadIdx.x], s_span[threadIdx.x]);
+        __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec + 1 + threadIdx.x, s_cnt[threadIdx.x], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) {
+        if (s_max) atomicMax(&bs->maxv, s_max);
+        if (s_sum) atomicAdd((unsigned long long *)&bs->total, s_sum);
+        __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    grid_barrier(fs.arrive, 1);
+    fused_tail(i, M, excl, crpt, bin, listed, rank, s_base, s_pref, s_h, bs, perm, fs, true);
+}
+
+}  // namespace spgemm
+}  // namespace nsp

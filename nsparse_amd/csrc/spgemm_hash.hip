@@ -66,6 +66,7 @@
 #include "spgemm/numeric.h"
 #include "spgemm/window.h"
 #include "spgemm/block.h"
+#include "spgemm/fused.h"
 #include "spgemm/heavy_tiled.h"
 #include "spgemm/heavy_ranked.h"
 
@@ -140,11 +141,12 @@ static inline int pick_w_regular(long long nnz, int M, int nnz_max)
 }
 
 
-static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *binfo,
+// returns the number of per-workgroup partial records; reduce = false leaves them for k_setup_tail
+static int launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *binfo,
                                 int *row_prod, int *row_lo, int *row_span, int *bm_words,
                                 int bm_span_max, const Thr &thr, BinState *d_bs, long long *partial,
                                 int *row_span_num, int *row_nz, int *row_maxb, int *long_list,
-                                int *long_cnt, TwinMap tw, hipStream_t st)
+                                int *long_cnt, TwinMap tw, bool reduce, hipStream_t st)
 {
     const int M = a->M;
     const int w = pick_w_regular(a->nnz, M, a->nnz_max);
@@ -173,8 +175,10 @@ static void launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *bin
                            (int *)nullptr, long_cnt, 0, (const int *)long_list, tw);
         grid += 256;
     }
-    hipLaunchKernelGGL(k_reduce_partials, dim3(grid < 32 ? grid : 32), dim3(256), 0, st, partial, grid, d_bs);
+    if (reduce)
+        hipLaunchKernelGGL(k_reduce_partials, dim3(grid < 32 ? grid : 32), dim3(256), 0, st, partial, grid, d_bs);
     NSP_LAUNCH_CHECK();
+    return grid;
 }
 
 struct Timer {
@@ -810,7 +814,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // one fill for both counter blocks and the four words at long_cnt (the two list counters and the
     // two words of k_col_range); the ints in between belong to calls that reset them themselves
     static_assert(2 * sizeof(BinState) <= 240 * sizeof(int), "counter blocks end before long_cnt");
-    NSP_CHECK(hipMemsetAsync(cx.d_scratch, 0, 244 * sizeof(int), s0));
+    NSP_CHECK(hipMemsetAsync(cx.d_scratch, 0, 248 * sizeof(int), s0));  // + the four words of the fused tails
 
     // rows of B with the column pattern of the row before them (k_b_info): runs of the numeric
     // window kernel (block.h).  NSPARSE_TWINS=0 switches the whole twin machinery off.
@@ -878,11 +882,25 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                                                    sizeof(int) * (size_t)M * (1 + kGroupMembers), s0));
         tw = TwinMap{ttable, tsize - 1, a->nnz, twin_of, twin, fcnt, members};
     }
-    launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
-                        use_bm ? (num_thr.rank_span > num_thr.dense_span[2] ? num_thr.rank_span : num_thr.dense_span[2]) : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, tw, s0);
+    // matrices of up to 256 K rows: the helper chains behind the big kernels are one launch each (fused.h)
+    static const bool fused_on = !(getenv("NSPARSE_FUSED") && atoi(getenv("NSPARSE_FUSED")) == 0);
+    const int fgrid = ceil_div(M + 1, 1024);
+    const bool fuse = fused_on && !numeric_only && fgrid <= kFusedMaxBlocks;
+    const int nparts = launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
+                        use_bm ? (num_thr.rank_span > num_thr.dense_span[2] ? num_thr.rank_span : num_thr.dense_span[2]) : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, tw, !fuse, s0);
     void *bm_scan_tmp = nullptr;
-    if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
     const int grid_m = ceil_div(M, 1024);
+    if (fuse) {
+        const int seq = ++cx.seq;
+        const FusedSync fs = {cx.d_scratch + 244, cx.d_scratch + 512, cx.d_mapped, cx.d_mapped + 120, seq};
+        hipLaunchKernelGGL(k_setup_tail, dim3(fgrid), dim3(1024), 0, s0, (const long long *)partial, nparts, d_sym,
+                           use_bm ? (const int *)bm_words : (const int *)nullptr, bm_off, (const int *)row_prod,
+                           (const int *)row_span, M, sym_thr, row_perm, (const unsigned char *)twin, fs);
+        NSP_LAUNCH_CHECK();
+        tm.mark(1, s0);
+        wait_published(120, seq, s0);
+    } else {
+    if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
     if (!numeric_only) {
         if (M >= (1 << 18))
             hipLaunchKernelGGL(k_bin_scatter<4>, dim3(ceil_div(M, 4096)), dim3(1024), 0, s0, row_prod, row_span,
@@ -900,6 +918,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         tm.mark(1, s0);  // issued before the host waits: everything between the flag and the first
                          // symbolic launch is GPU idle time
         wait_published(120, seq, s0);
+    }
     }
     S.n_prod = h_sym->total;
     S.max_prod_row = h_sym->maxv;
@@ -922,23 +941,26 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
             long long binned = 0;
             for (int q = 0; q < NB; q++) binned += h_sym->hist[q];
             S.twin_rows = twin ? (int)(M - binned) : 0;
-            if (S.twin_rows > 0) {
-                hipLaunchKernelGGL(k_twin_copy, dim3(ceil_div(M, 256)), dim3(256), 0, s0, (const int *)twin_of, M,
-                                   row_nz, row_span_num, bm ? bm_off : (int *)nullptr);
-                NSP_LAUNCH_CHECK();
-            }
             // groups of twin rows for the numeric window kernel: worth their LDS only when a good share
             // of the rows has a twin (a finite-element matrix), not for a few chance repeats
-            if (lean_on && bm && (long long)S.twin_rows * 8 >= M) {
-                grp = (unsigned char *)dev_alloc((size_t)M);
-                hipLaunchKernelGGL(k_twin_groups, dim3(ceil_div(M, 256)), dim3(256), 0, s0, (const int *)twin_of,
-                                   (const int *)members, (const int *)row_span_num,
-                                   (const int *)row_nz, (const int *)row_prod, num_thr, M, grp);
-                NSP_LAUNCH_CHECK();
+            const bool want_grp = lean_on && bm && (long long)S.twin_rows * 8 >= M;
+            if (want_grp) grp = (unsigned char *)dev_alloc((size_t)M);
+            if (!fuse) {
+                if (S.twin_rows > 0) {
+                    hipLaunchKernelGGL(k_twin_copy, dim3(ceil_div(M, 256)), dim3(256), 0, s0, (const int *)twin_of, M,
+                                       row_nz, row_span_num, bm ? bm_off : (int *)nullptr);
+                    NSP_LAUNCH_CHECK();
+                }
+                if (want_grp) {
+                    hipLaunchKernelGGL(k_twin_groups, dim3(ceil_div(M, 256)), dim3(256), 0, s0, (const int *)twin_of,
+                                       (const int *)members, (const int *)row_span_num,
+                                       (const int *)row_nz, (const int *)row_prod, num_thr, M, grp);
+                    NSP_LAUNCH_CHECK();
+                }
             }
         }
         c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
-        scan_tmp = scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
+        if (!fuse) scan_tmp = scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
     } else {
         // structure given: row_nz[i] = rpt[i+1] - rpt[i] is recovered inside the kernels
         // from C.rpt; for binning we need it explicitly.
@@ -951,6 +973,18 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
     const int *num_span = numeric_only ? row_span : row_span_num;
     if (!numeric_only && bm == nullptr) num_thr.dense_ratio = num_thr.rank_span = 0;
+    if (fuse) {
+        // twins' results, groups, C.rpt, histogram, permutation and the publish in one launch (fused.h)
+        const int seq = ++cx.seq;
+        const FusedSync fs = {cx.d_scratch + 246, cx.d_scratch + 512 + kFusedMaxBlocks * kFusedRec,
+                              reinterpret_cast<int *>(h_num_dev), cx.d_mapped + 121, seq};
+        hipLaunchKernelGGL(k_numeric_setup, dim3(fgrid), dim3(1024), 0, s0,
+                           S.twin_rows > 0 ? (const int *)twin_of : (const int *)nullptr, (const int *)members, row_nz,
+                           row_span_num, bm ? bm_off : (int *)nullptr, (const int *)row_prod, M, num_thr, d_num,
+                           c->d_rpt, row_perm, grp, fs);
+        NSP_LAUNCH_CHECK();
+        wait_published(121, seq, s0);
+    } else {
     hipLaunchKernelGGL(k_hist, dim3(grid_m < 128 ? grid_m : 128), dim3(1024), 0, s0, row_nz, num_span,
                        (const int *)row_prod, M, num_thr, d_num);
     if (M >= (1 << 18))
@@ -966,6 +1000,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                            (int)(sizeof(BinState) / 4), c->d_rpt + M, cx.d_mapped + 121, seq);
         NSP_LAUNCH_CHECK();
         wait_published(121, seq, s0);
+    }
     }
     for (int q = 0; q < NB; q++) S.num_bin_size[q] = h_num->hist[q];
     S.max_nnz_row = h_num->maxv;

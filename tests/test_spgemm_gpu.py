@@ -526,3 +526,35 @@ def test_node_block_kernel_rows_longer_than_a_batch(prec, lib_d, lib_s, oracle_d
         assert orc.check_spgemm(got, ref) == 0
         assert np.array_equal(got["col_again"], got["col"])
         np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9 if prec == "d" else 2e-6)
+
+
+def test_fused_tails_match_the_kernel_chains(lib_d, oracle_d):
+    """Matrices of up to 256 K rows run the helper chains behind the big kernels as one launch each
+    (csrc/spgemm/fused.h); NSPARSE_FUSED=0 keeps the chains.  Same C, same bins, for an FEM brick (twins,
+    node-block groups, window bins) and a power law (tiny / hash bins, deferred long rows)."""
+    for kind, p in ((0, (7, 6, 21)), (2, (50000, 180000, 0))):
+        A = synth(lib_d, kind, *p, seed=77)
+        ref = oracle_d.spgemm(A, A)
+        got, st = spgemm(lib_d, A)
+        assert_parity(oracle_d, got, ref)
+        got0, st0 = spgemm_subprocess(A, {"NSPARSE_FUSED": "0"})
+        assert np.array_equal(got0["rpt"], got["rpt"]) and np.array_equal(got0["col"], got["col"])
+        assert list(st.sym_bin_size) == st0["sym"] and list(st.num_bin_size) == st0["num"]
+
+
+@pytest.mark.parametrize("m", [1023, 1024, 262143, 262144])
+def test_fused_tails_at_their_size_limits(m, lib_d, oracle_d):
+    """The fused tails take M + 1 <= 256 * 1024 scan entries: M = 262143 is the last size they run, 262144 the
+    first for the chains; 1023 / 1024 rows put the scan tail (entry M) in the first / a second workgroup.
+    Bidiagonal-plus-random rows: every bin offset and C.rpt entry is checked against the oracle."""
+    rng = np.random.default_rng(m)
+    ln = rng.integers(0, 4, size=m)
+    ln[rng.integers(0, m, size=5)] = 40
+    rpt = np.zeros(m + 1, dtype=np.int32)
+    rpt[1:] = np.cumsum(ln)
+    col = np.concatenate([np.sort(rng.choice(m, size=k, replace=False)) for k in ln]).astype(np.int32)
+    A = dict(M=m, N=m, rpt=rpt, col=col, val=rng.uniform(0.5, 1.5, size=len(col)))
+    ref = oracle_d.spgemm(A, A)
+    got, st = spgemm(lib_d, A)
+    assert_parity(oracle_d, got, ref)
+    assert sum(st.num_bin_size) == m and sum(st.sym_bin_size) + st.twin_rows == m
