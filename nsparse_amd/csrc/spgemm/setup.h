@@ -103,8 +103,13 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
                                                 int *__restrict__ long_list, int *long_cnt, int long_len,
                                                 const int *__restrict__ todo,
                                                 const unsigned int *__restrict__ range,
-                                                unsigned char *__restrict__ btwin)
+                                                unsigned char *__restrict__ btwin,
+                                                unsigned long long *__restrict__ fill, long long fill_words)
 {
+    // fill: fill_words 64-bit words set to all ones on the way (the twin map of k_row_products, which runs
+    // next: a fill launch less).
+    for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < fill_words; w += (long long)gridDim.x * 256)
+        fill[w] = ~0ull;
     // btwin != nullptr: btwin[r] = 1 when row r of B has exactly the column pattern of row r - 1 (the
     // degrees of freedom of one mesh node): the numeric window kernel then treats consecutive A entries
     // that point at such rows as one run (block.h).  Long rows (second pass) are never marked.
@@ -475,6 +480,17 @@ __global__ __launch_bounds__(64) void k_publish(const BinState *__restrict__ src
     const int *s = reinterpret_cast<const int *>(src);
     for (int i = threadIdx.x; i < words; i += 64) dst[i] = s[i];
     if (nnz_src && threadIdx.x == 0) reinterpret_cast<BinState *>(dst)->nnz = *nnz_src;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// End of a call: zero the counter blocks for the next one (a fill launch less at its start -- the host
+// keeps Context::counters_clean), then raise the flag the host polls.
+__global__ __launch_bounds__(256) void k_finish(int *scratch, int *flag, int seq)
+{
+    if (threadIdx.x < 120) scratch[threadIdx.x] = 0;
+    if (threadIdx.x >= 240 && threadIdx.x < 248) scratch[threadIdx.x] = 0;
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -814,13 +814,36 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // one fill for both counter blocks and the four words at long_cnt (the two list counters and the
     // two words of k_col_range); the ints in between belong to calls that reset them themselves
     static_assert(2 * sizeof(BinState) <= 240 * sizeof(int), "counter blocks end before long_cnt");
-    NSP_CHECK(hipMemsetAsync(cx.d_scratch, 0, 248 * sizeof(int), s0));  // + the four words of the fused tails
+    // (+ the four words of the fused tails).  A call that ran to its end has left them zeroed (k_finish).
+    if (!cx.counters_clean) NSP_CHECK(hipMemsetAsync(cx.d_scratch, 0, 248 * sizeof(int), s0));
+    cx.counters_clean = false;
 
     // rows of B with the column pattern of the row before them (k_b_info): runs of the numeric
     // window kernel (block.h).  NSPARSE_TWINS=0 switches the whole twin machinery off.
     static const bool twins_on = !(getenv("NSPARSE_TWINS") && atoi(getenv("NSPARSE_TWINS")) == 0);
     static const bool lean_on = !(getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0);
     unsigned char *btwin = (twins_on && lean_on && K > 1) ? (unsigned char *)dev_alloc((size_t)K) : nullptr;
+    // rows with the column pattern of another row are not run through the symbolic phase: they take that
+    // row's result (twin_probe / k_twin_copy).  NSPARSE_TWINS=0 switches the detection off.
+    const bool find_twins = !numeric_only && twins_on && M > 1;
+    unsigned char *twin = nullptr;
+    int *twin_of = nullptr, *fcnt = nullptr, *members = nullptr;
+    unsigned long long *ttable = nullptr;
+    long long twin_fill_words = 0;
+    TwinMap tw = {nullptr, 0u, 0, nullptr, nullptr, nullptr, nullptr};
+    if (find_twins) {
+        unsigned int tsize = 1024;
+        while (tsize < 2u * (unsigned int)M) tsize <<= 1;
+        // table, sign-up counters and members in one block, one fill (all ones = free / -1 / none)
+        // (k_b_info fills it on its way, in 64-bit words)
+        twin_fill_words = (long long)tsize + ((long long)M * (1 + kGroupMembers) + 1) / 2;
+        ttable = (unsigned long long *)dev_alloc(sizeof(unsigned long long) * (size_t)twin_fill_words);
+        fcnt = (int *)(ttable + tsize);
+        members = fcnt + M;
+        twin_of = (int *)dev_alloc(sizeof(int) * (size_t)M);
+        twin = (unsigned char *)dev_alloc((size_t)M);
+        tw = TwinMap{ttable, tsize - 1, a->nnz, twin_of, twin, fcnt, members};
+    }
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
     {
         const int wb = pick_w_regular(b->nnz, K, b->nnz_max);
@@ -844,7 +867,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 #define NSP_BI(W)                                                                              \
     case W:                                                                                    \
         hipLaunchKernelGGL(k_b_info<W>, dim3(gb), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym, \
-                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range, btwin); \
+                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range, btwin, ttable, twin_fill_words); \
         break;
         switch (wb) {
             NSP_BI(1) NSP_BI(2) NSP_BI(4) NSP_BI(8) NSP_BI(16) NSP_BI(32) NSP_BI(64)
@@ -852,7 +875,8 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 #undef NSP_BI
         if (blist)
             hipLaunchKernelGGL(k_b_info<64>, dim3(256), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym,
-                               (int *)nullptr, long_cnt, 0, (const int *)long_list, (const unsigned int *)nullptr, btwin);
+                               (int *)nullptr, long_cnt, 0, (const int *)long_list, (const unsigned int *)nullptr, btwin,
+                               (unsigned long long *)nullptr, 0LL);
         if (range_part) dev_free(range_part);  // stream-ordered reuse, see scan_exclusive
     }
     long long *partial = (long long *)dev_alloc(sizeof(long long) * kPartialStride * kSetupMaxGrid);
@@ -861,27 +885,6 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     int *bm_off = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_span_num = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
-    // rows with the column pattern of another row are not run through the symbolic phase: they take that
-    // row's result (k_twin_find / k_twin_copy).  NSPARSE_TWINS=0 switches the detection off.
-    const bool find_twins = !numeric_only && twins_on && M > 1;
-    unsigned char *twin = nullptr;
-    int *twin_of = nullptr, *fcnt = nullptr, *members = nullptr;
-    unsigned long long *ttable = nullptr;
-    TwinMap tw = {nullptr, 0u, 0, nullptr, nullptr, nullptr, nullptr};
-    if (find_twins) {
-        unsigned int tsize = 1024;
-        while (tsize < 2u * (unsigned int)M) tsize <<= 1;
-        // table, sign-up counters and members in one block, one fill (all ones = free / -1 / none)
-        ttable = (unsigned long long *)dev_alloc(sizeof(unsigned long long) * (size_t)tsize +
-                                                 sizeof(int) * (size_t)M * (1 + kGroupMembers));
-        fcnt = (int *)(ttable + tsize);
-        members = fcnt + M;
-        twin_of = (int *)dev_alloc(sizeof(int) * (size_t)M);
-        twin = (unsigned char *)dev_alloc((size_t)M);
-        NSP_CHECK(hipMemsetAsync(ttable, 0xff, sizeof(unsigned long long) * (size_t)tsize +
-                                                   sizeof(int) * (size_t)M * (1 + kGroupMembers), s0));
-        tw = TwinMap{ttable, tsize - 1, a->nnz, twin_of, twin, fcnt, members};
-    }
     // matrices of up to 256 K rows: the helper chains behind the big kernels are one launch each (fused.h)
     static const bool fused_on = !(getenv("NSPARSE_FUSED") && atoi(getenv("NSPARSE_FUSED")) == 0);
     const int fgrid = ceil_div(M + 1, 1024);
@@ -1025,10 +1028,10 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     tm.mark(3, s0);
     {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
         const int seq = ++cx.seq;
-        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s0, d_num, cx.d_mapped + 128, 0, (const int *)nullptr,
-                           cx.d_mapped + 122, seq);
+        hipLaunchKernelGGL(k_finish, dim3(1), dim3(256), 0, s0, cx.d_scratch, cx.d_mapped + 122, seq);
         NSP_LAUNCH_CHECK();
         wait_published(122, seq, s0);
+        cx.counters_clean = true;
     }
     LN.collect(S.ms_num_bin);
     sym_used.collect(S.ms_sym_bin);
