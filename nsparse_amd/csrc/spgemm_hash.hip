@@ -385,6 +385,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     // bin 10 with windows wider than the 2^20-bit window and sorted rows of B: cursor kernel, every
     // product seen once (k_sym_bits would walk all products once per 2^20-column piece)
     static const int sym_cursor_on = !(getenv("NSPARSE_SYM_CURSOR") && getenv("NSPARSE_SYM_CURSOR")[0] == '0');
+    static const int sym_long_len = getenv("NSPARSE_SYM_LONG") ? atoi(getenv("NSPARSE_SYM_LONG")) : 32;
     if (hist[10] > 0 && now(10) && sym_cursor_on && b_sorted && max_span[10] > 32768 * 32 && max_alen > 0) {
         hipStream_t st = L.begin(10);
         const int rows = hist[10];
@@ -395,7 +396,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         hipLaunchKernelGGL((k_num_ranked<1024, 1048576, 8, 1024, true>), dim3(groups), dim3(1024), 0, st, arpt, acol,
                            (const real *)nullptr, brpt, bcol, (const real *)nullptr, (const int *)nullptr,
                            (int *)nullptr, (real *)nullptr, row_perm, off[10], rows, d_bs, row_lo, row_span, slab,
-                           stride_ints, amax, 0, 128, -1, 0, (unsigned long long *)nullptr, row_nz);
+                           stride_ints, amax, 0, sym_long_len, -1, 0, (unsigned long long *)nullptr, row_nz);
         NSP_LAUNCH_CHECK();
         L.end(10);
         L.free_later(slab);
@@ -479,7 +480,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // host; the cursor slab returns to the cache when the call has drained (collect()).
     constexpr int kTileW = 12288;  // LDS accumulators are double in both builds
     static const int tiled_on = !(getenv("NSPARSE_TILED") && getenv("NSPARSE_TILED")[0] == '0');
-    static const int long_len = getenv("NSPARSE_TILED_LONG") ? atoi(getenv("NSPARSE_TILED_LONG")) : 128;
+    // B rows longer than this are swept by whole wavefronts (R-MAT-16 / 18 / 22: 128 -> 32 saves 9 / 8 / 4 %)
+    static const int long_len = getenv("NSPARSE_TILED_LONG") ? atoi(getenv("NSPARSE_TILED_LONG")) : 32;
     static const int tile_sel = getenv("NSPARSE_TILED_W") ? atoi(getenv("NSPARSE_TILED_W")) : 0;
     // rows with fewer than one non-zero per ranked_dens columns of their window take the ranked
     // kernel (0: none, < 0: all)
