@@ -89,8 +89,11 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                                                   const unsigned char *__restrict__ grp,
                                                   const unsigned char *__restrict__ btwin,
                                                   unsigned long long *__restrict__ prof,
-                                                  const int *__restrict__ members)
+                                                  const int *__restrict__ members,
+                                                  const int4 *__restrict__ desc)
 {
+    // desc != nullptr: k_numeric_setup left a 48-byte record per listed row, IN LIST ORDER (fused.h:
+    // BlkDesc): the row words come back in one round trip instead of list -> row words -> members' words.
     // MODE 1: full call (structure = the column bitmap k_sym_dense wrote); MODE 2: numeric-only re-run
     // (structure = C.col, the bitmap is rebuilt from it).
     // prof != nullptr (NSPARSE_BLK_PROF=1): thread 0 of every group head adds the shader-clock cycles of
@@ -124,33 +127,46 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
     __shared__ int s_wcnt[NW];
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
-    const int rid = row_perm[bin_off + slot];
-    const int gcode = grp ? (int)grp[rid] : (1 << 2);
-    if (gcode & 3) return;  // a follower: its group head computes this row
-    const int RA = gcode >> 2;
+    int rid, RA, lo, span, maxb, bmo = 0, alen;
+    int off[kBlkRows], a_beg[kBlkRows];
+    if (desc) {
+        const int4 d0 = desc[3 * (bin_off + slot)], d1 = desc[3 * (bin_off + slot) + 1],
+                   d2 = desc[3 * (bin_off + slot) + 2];
+        rid = d0.x, lo = d0.y, span = d0.z, maxb = d0.w;
+        bmo = d1.x, a_beg[0] = d1.y, alen = d1.z, RA = d1.w;
+        a_beg[1] = d2.z, a_beg[2] = d2.w;
+        off[0] = crpt[rid];
+        off[1] = RA > 1 ? crpt[d2.x] : 0;
+        off[2] = RA > 2 ? crpt[d2.y] : 0;
+    } else {
+        rid = row_perm[bin_off + slot];
+        const int gcode = grp ? (int)grp[rid] : (1 << 2);
+        if (gcode & 3) return;  // a follower: its group head computes this row
+        RA = gcode >> 2;
+        lo = row_lo[rid];
+        span = row_span[rid];
+        // the rows of the group: the head (a pattern leader) and the twins recorded as its members -- any
+        // rows of the matrix, not necessarily neighbours
+#pragma unroll
+        for (int r = 0; r < kBlkRows; r++) {
+            const int rr = (r == 0 || r >= RA) ? rid : members[kGroupMembers * rid + r - 1];
+            off[r] = r < RA ? crpt[rr] : 0;
+            a_beg[r] = r < RA ? arpt[rr] : 0;
+        }
+        alen = arpt[rid + 1] - a_beg[0];
+        maxb = row_maxb[rid];
+        if (MODE == 1) bmo = bm_off[rid];
+    }
     if (prof && threadIdx.x == 0) {
         prof[8ull * blockIdx.x + 6] = 1;
         prof[8ull * blockIdx.x + 7] = (unsigned long long)RA;
     }
-    const int lo = row_lo[rid];
-    const int span = row_span[rid];
-    // the rows of the group: the head (a pattern leader) and the twins recorded as its members -- any
-    // rows of the matrix, not necessarily neighbours
-    int off[kBlkRows], a_beg[kBlkRows];
-#pragma unroll
-    for (int r = 0; r < kBlkRows; r++) {
-        const int rr = (r == 0 || r >= RA) ? rid : members[kGroupMembers * rid + r - 1];
-        off[r] = r < RA ? crpt[rr] : 0;
-        a_beg[r] = r < RA ? arpt[rr] : 0;
-    }
     const int nz = crpt[rid + 1] - off[0];
     const int nzs = ((nz + 7) >> 3) << 3;  // the number k_twin_groups sized the group with
-    const int alen = arpt[rid + 1] - a_beg[0];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nw = (span + 31) >> 5;
-    const int maxb = row_maxb[rid];
     if (MODE == 1) {
-        const unsigned int *bits = bm + bm_off[rid];
+        const unsigned int *bits = bm + bmo;
         for (int i = threadIdx.x; i < nw; i += BS) s_bits[i] = bits[i];
     } else {
         for (int i = threadIdx.x; i < nw; i += BS) s_bits[i] = 0;

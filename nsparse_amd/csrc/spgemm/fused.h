@@ -101,7 +101,8 @@ __device__ __forceinline__ int rank_in_bin(int bin, int *s_cnt)
 // totals) was complete at the barrier, so one wavefront of workgroup 0 publishes at once while the others
 // place their rows: a workgroup's rows follow those of the workgroups before it in every bin (sums of the
 // records written before the barrier -- no atomics, and the lists come out in ascending row order).
-__device__ __forceinline__ void fused_tail(int i, int M, int excl, int *out_scan, int bin, bool listed, int rank,
+// returns the list position of the thread's row (-1: not listed)
+__device__ __forceinline__ int fused_tail(int i, int M, int excl, int *out_scan, int bin, bool listed, int rank,
                                            int *s_base, int *s_pref /* kFusedRec */, int *s_h /* NB */, BinState *bs,
                                            int *perm, const FusedSync &fs, bool set_nnz)
 {
@@ -133,7 +134,9 @@ __device__ __forceinline__ void fused_tail(int i, int M, int excl, int *out_scan
     }
     __syncthreads();
     if (out_scan && i <= M) out_scan[i] = s_pref[0] + excl;
-    if (listed) perm[s_base[bin] + rank] = i;
+    if (!listed) return -1;
+    perm[s_base[bin] + rank] = i;
+    return s_base[bin] + rank;
 }
 
 // ---- set-up tail: fold the per-workgroup partials of k_row_products, offsets of the column bitmaps,
@@ -209,8 +212,14 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
                                                         const int *__restrict__ row_prod, int M, Thr thr,
                                                         BinState *bs, int *__restrict__ crpt,
                                                         int *__restrict__ perm, unsigned char *__restrict__ grp,
-                                                        FusedSync fs)
+                                                        FusedSync fs, int4 *__restrict__ desc,
+                                                        const int *__restrict__ arpt,
+                                                        const int *__restrict__ row_lo,
+                                                        const int *__restrict__ row_maxb)
 {
+    // desc != nullptr: a record per row listed in a window bin, in list order, for the node-block kernel
+    // (block.h): {row, lo, span, longest B row | bitmap offset, first A entry, A entries, rows in the group |
+    // member rows, their first A entries}
     __shared__ int s_hist[NB], s_cnt[NB], s_base[NB], s_span[NB], s_w[16], s_pref[kFusedRec], s_h[NB];
     __shared__ int s_max;
     __shared__ unsigned long long s_sum;
@@ -223,6 +232,7 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
     const int i = blockIdx.x * 1024 + threadIdx.x;
     int nz = 0, bin = -1, hbin = -1;
     bool listed = false;
+    int4 d0 = make_int4(0, 0, 0, 0), d1 = d0, d2 = d0;
     if (i < M) {
         const int l = twin_of ? twin_of[i] : -1;
         const int lead = l >= 0 ? l : i;
@@ -237,12 +247,13 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
         const int work = row_prod[i];
         hbin = bin_of(nz, sp, thr, work);
         int code = 1 << 2;
+        int m0 = -1, m1 = -1;
         if (grp) {  // k_twin_groups
             const int nzs = ((nz + 7) >> 3) << 3;
             const bool windowed = sp > 0 && nzs > 0 && hbin >= kDenseBin0;
             int cap = windowed ? kBlkAccElems / nzs : 1;
             cap = cap < 1 ? 1 : (cap > kBlkRows ? kBlkRows : cap);
-            const int m0 = members[kGroupMembers * lead], m1 = members[kGroupMembers * lead + 1];
+            m0 = members[kGroupMembers * lead], m1 = members[kGroupMembers * lead + 1];
             const int nf = m0 < 0 ? 0 : (m1 != m0 ? 2 : 1);
             const int gsize = 1 + nf < cap ? 1 + nf : cap;
             if (l < 0) {
@@ -256,7 +267,15 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
         listed = (code & 3) == 0;
         if (listed) {
             bin = hbin;
-            if (bin >= kDenseBin0) atomicMax(&s_span[bin], sp);
+            if (bin >= kDenseBin0) {
+                atomicMax(&s_span[bin], sp);
+                if (desc) {
+                    const int ra = code >> 2, ab = arpt[i];
+                    d0 = make_int4(i, row_lo[i], sp, row_maxb[i]);
+                    d1 = make_int4(bm_off ? bm_off[i] : 0, ab, arpt[i + 1] - ab, ra);
+                    d2 = make_int4(m0, m1, ra > 1 ? arpt[m0] : 0, ra > 2 ? arpt[m1] : 0);
+                }
+            }
         }
     }
     // histogram of every row (k_hist), longest row, 64-bit total
@@ -299,7 +318,12 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
         __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     grid_barrier(fs.arrive, 1);
-    fused_tail(i, M, excl, crpt, bin, listed, rank, s_base, s_pref, s_h, bs, perm, fs, true);
+    const int pos = fused_tail(i, M, excl, crpt, bin, listed, rank, s_base, s_pref, s_h, bs, perm, fs, true);
+    if (desc && pos >= 0 && bin >= kDenseBin0) {
+        desc[3 * pos] = d0;
+        desc[3 * pos + 1] = d1;
+        desc[3 * pos + 2] = d2;
+    }
 }
 
 }  // namespace spgemm

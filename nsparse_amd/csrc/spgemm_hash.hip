@@ -467,7 +467,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                                  float *ms_bin, int write_col, const int *bm_off,
                                  const unsigned int *bm, int max_alen, bool b_sorted,
                                  const int *max_span, const unsigned char *grp, const unsigned char *btwin,
-                                 const int *listed, const int *members)
+                                 const int *listed, const int *members, const int4 *desc)
 {
     int hist[NB], off[NB + 1];
     fold_small_hash_bins(hist_in, hist, off);
@@ -599,7 +599,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         hipLaunchKernelGGL((k_num_block<BS, SPAN, MODEX, kBlkU>), dim3(8 * ceil_div(heads, 8)), dim3(BS), \
                            lds_blk, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
                            c->d_val, row_perm, row_maxb, row_lo, row_span, off[bin_],            \
-                           heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members);          \
+                           heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members, desc);    \
     }
 #define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
@@ -658,7 +658,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
 #define NSP_RANKWIN(MODEX)                                                                      \
     hipLaunchKernelGGL((k_num_block<128, 65536, MODEX, kBlkU>), dim3(8 * ceil_div(heads, 8)), dim3(128), lds_blk, st, \
                        arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_maxb, \
-                       row_lo, row_span, off[bin_], heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members)
+                       row_lo, row_span, off[bin_], heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members, desc)
         if (write_col & 1) NSP_RANKWIN(1); else NSP_RANKWIN(2);
 #undef NSP_RANKWIN
         NSP_LAUNCH_CHECK();
@@ -795,6 +795,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     void *scan_tmp = nullptr;
     unsigned int *bm = nullptr;
     unsigned char *grp = nullptr;
+    int4 *blk_desc = nullptr;  // row records of the node-block kernel, in list order (k_numeric_setup)
     BinLauncher sym_used(cx, 0);
     int *row_prod = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_nz = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
@@ -978,6 +979,8 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
     const int *num_span = numeric_only ? row_span : row_span_num;
     if (!numeric_only && bm == nullptr) num_thr.dense_ratio = num_thr.rank_span = 0;
+    if (fuse && bm && lean_on && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
+        blk_desc = (int4 *)dev_alloc(sizeof(int4) * 3 * (size_t)M);
     if (fuse) {
         // twins' results, groups, C.rpt, histogram, permutation and the publish in one launch (fused.h)
         const int seq = ++cx.seq;
@@ -986,7 +989,8 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         hipLaunchKernelGGL(k_numeric_setup, dim3(fgrid), dim3(1024), 0, s0,
                            S.twin_rows > 0 ? (const int *)twin_of : (const int *)nullptr, (const int *)members, row_nz,
                            row_span_num, bm ? bm_off : (int *)nullptr, (const int *)row_prod, M, num_thr, d_num,
-                           c->d_rpt, row_perm, grp, fs);
+                           c->d_rpt, row_perm, grp, fs, blk_desc, (const int *)a->d_rpt, (const int *)row_lo,
+                           (const int *)row_maxb);
         NSP_LAUNCH_CHECK();
         wait_published(121, seq, s0);
     } else {
@@ -1026,7 +1030,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_maxb, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
-                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor, members);
+                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor, members, blk_desc);
     tm.mark(3, s0);
     {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
         const int seq = ++cx.seq;
@@ -1058,6 +1062,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     if (ttable) dev_free(ttable);
     if (twin_of) dev_free(twin_of);
     if (grp) dev_free(grp);
+    if (blk_desc) dev_free(blk_desc);
     if (btwin) dev_free(btwin);
     dev_free(row_span_num);
     dev_free(bm_off);
