@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_twin_groups(const int *__restrict__ twi
     grp[r] = (unsigned char)code;
 }
 
-template <int BS, int SPAN_MAX, int MODE, int U>
+template <int BS, int SPAN_MAX, int MODE, int U, bool KEYED = false>
 __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                   const real *__restrict__ aval,
                                                   const int *__restrict__ brpt, const int *__restrict__ bcol,
@@ -90,8 +90,12 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                                                   const unsigned char *__restrict__ btwin,
                                                   unsigned long long *__restrict__ prof,
                                                   const int *__restrict__ members,
-                                                  const int4 *__restrict__ desc)
+                                                  const int4 *__restrict__ desc,
+                                                  const int *__restrict__ bkey)
 {
+    // KEYED (C = A * A with twin rows that are NOT neighbours): bkey[c] = pattern leader of row c of B or
+    // -1; the entries of an A row whose rows of B share a pattern form a run wherever they sit in the row
+    // (grouped by counting among the parked entries), instead of only when they are neighbours.
     // desc != nullptr: k_numeric_setup left a 48-byte record per listed row, IN LIST ORDER (fused.h:
     // BlkDesc): the row words come back in one round trip instead of list -> row words -> members' words.
     // MODE 1: full call (structure = the column bitmap k_sym_dense wrote); MODE 2: numeric-only re-run
@@ -125,6 +129,12 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
     // words, read back to back without conditions (the values of B are zero for the rows a run lacks)
     __shared__ real s_a[(PARK + 2) * kBlkRows];
     __shared__ int s_wcnt[NW];
+    // the parked entries of a run (bytes 0..2; PARK = the zero entry behind the last one) and, keyed runs
+    // only, the key of every parked entry and the run its leader opened
+    static_assert(!KEYED || PARK < 255, "parked entries are named by a byte");
+    __shared__ unsigned int s_ent[KEYED ? PARK : 1];
+    __shared__ int s_key[KEYED ? PARK : 1];  // later: the run an entry's leader opened
+    int *s_runof = s_key;
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
     int rid, RA, lo, span, maxb, bmo = 0, alen;
@@ -203,24 +213,57 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
             if ((int)threadIdx.x < PARK)
                 s_a[threadIdx.x * kBlkRows + r] = (valid && r < RA) ? __builtin_nontemporal_load(aval + a_beg[r] + j) : (real)0;
         if (threadIdx.x < 2 * kBlkRows) s_a[PARK * kBlkRows + threadIdx.x] = 0;  // what a run at the very end reads past
-        const int cprev = __shfl_up(c, 1);
-        // entry j continues the run of entry j - 1 when its row of B is the twin of that one's (same
-        // columns, hence same length) and directly follows it; runs never cross a wavefront
-        const bool head = !(lane > 0 && tw && c == cprev + 1);
-        const unsigned long long hm = __ballot(head || !valid);
-        const unsigned long long vm = __ballot(valid);
-        const int nvalid = __popcll(vm);  // valid lanes are a prefix
-        const unsigned long long below = hm & ((2ull << lane) - 1ull);
-        const int h = 63 - __clzll((long long)below);  // lane 0 is always a head
-        const int pos = lane - h;
-        const int d = pos % kBlkRun;
-        const bool leader = valid && d == 0;
+        int d, nB, my_run, nruns = 0;
+        bool leader;
+        if constexpr (!KEYED) {
+            const int cprev = __shfl_up(c, 1);
+            // entry j continues the run of entry j - 1 when its row of B is the twin of that one's (same
+            // columns, hence same length) and directly follows it; runs never cross a wavefront
+            const bool head = !(lane > 0 && tw && c == cprev + 1);
+            const unsigned long long hm = __ballot(head || !valid);
+            const unsigned long long vm = __ballot(valid);
+            const int nvalid = __popcll(vm);  // valid lanes are a prefix
+            const unsigned long long below = hm & ((2ull << lane) - 1ull);
+            const int h = 63 - __clzll((long long)below);  // lane 0 is always a head
+            const int pos = lane - h;
+            d = pos % kBlkRun;
+            leader = valid && d == 0;
+            const unsigned long long above = lane < 63 ? hm >> (lane + 1) : 0ull;
+            int end = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
+            end = end < nvalid ? end : nvalid;
+            nB = end - lane;
+            nB = nB > kBlkRun ? kBlkRun : nB;
+        } else {
+            // keyed runs: position of the entry among the parked entries with its key, by counting
+            int key = -3;
+            if (valid) {
+                const int l = bkey[c];
+                key = l >= 0 ? l : c;
+            }
+            if ((int)threadIdx.x < PARK) s_key[threadIdx.x] = key;
+            __syncthreads();
+            const int nb = alen - a0 < PARK ? alen - a0 : PARK;
+            int before = 0, total = 0, last1 = -1, last2 = -1;
+            if (valid) {
+                for (int i = 0; i < nb; i++) {
+                    const bool eq = s_key[i] == key;
+                    total += eq;
+                    if (eq && i < (int)threadIdx.x) {
+                        before++;
+                        last2 = last1;
+                        last1 = i;
+                    }
+                }
+            }
+            d = before % kBlkRun;
+            leader = valid && d == 0;
+            nB = total - before;
+            nB = nB > kBlkRun ? kBlkRun : nB;
+            // (kept for the followers below: the entry that leads my run)
+            tw = false;
+            c = d == 1 ? last1 : (d == 2 ? last2 : (int)threadIdx.x);
+        }
         const unsigned long long lm = __ballot(leader);
-        const unsigned long long above = lane < 63 ? hm >> (lane + 1) : 0ull;
-        int end = above ? lane + 1 + (__ffsll((long long)above) - 1) : 64;
-        end = end < nvalid ? end : nvalid;
-        int nB = end - lane;
-        nB = nB > kBlkRun ? kBlkRun : nB;
         if (lane == 0) s_wcnt[wv] = __popcll(lm);
         __syncthreads();  // also: bitmap in LDS, accumulators cleared, s_a written
         stamp(1);
@@ -234,16 +277,27 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                 carry += __shfl(inc, 63);
             }
         }
-        int wbase = 0, nruns = 0;
+        int wbase = 0;
 #pragma unroll
         for (int u = 0; u < NW; u++) {
             wbase += u < wv ? s_wcnt[u] : 0;
             nruns += s_wcnt[u];
         }
+        my_run = wbase + __popcll(lm & ((2ull << lane) - 1ull)) - 1;  // of the last leader at or below this lane
+        if constexpr (KEYED) {
+            if (leader) s_runof[threadIdx.x] = my_run;  // (every s_key was read before the barrier above)
+            __syncthreads();
+            if (valid && !leader) my_run = s_runof[c];
+        }
         if (valid) {
-            const int my_run = wbase + __popcll(lm & ((2ull << lane) - 1ull)) - 1;
             reinterpret_cast<int *>(&s_rec[my_run])[d] = kb;
-            if (leader) s_rec[my_run].w = (ke - kb) | (nB << 21) | ((int)threadIdx.x << 23);
+            if constexpr (KEYED) reinterpret_cast<unsigned char *>(&s_ent[my_run])[d] = (unsigned char)threadIdx.x;
+            if (leader) {
+                s_rec[my_run].w = (ke - kb) | (nB << 21) | (KEYED ? 0 : (int)threadIdx.x << 23);
+                if constexpr (KEYED)
+                    for (int q = nB; q < kBlkRun; q++)
+                        reinterpret_cast<unsigned char *>(&s_ent[my_run])[q] = (unsigned char)PARK;
+            }
         }
         __syncthreads();
         stamp(2);
@@ -257,7 +311,7 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
         const int t1 = t0 + per < ntask ? t0 + per : ntask;
         int u = t0 / nch, ch = t0 - u * nch;
         for (int tb = t0; tb < t1; tb += U) {
-            int col[U], meta[U];
+            int col[U], ru[U], meta[U];
             real v[kBlkRun][U];
             bool ok[U];
 #pragma unroll
@@ -268,6 +322,7 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                 const int nb = (rec.w >> 21) & 3;
                 const int p = gl + (ch << lg);
                 ok[i] = live && p < len;
+                ru[i] = live ? u : 0;
                 meta[i] = rec.w;
                 const unsigned idx = ok[i] ? (unsigned)p : 0u;  // masked lanes re-read entry 0 of the run
                 const unsigned k0 = len > 0 ? (unsigned)rec.x : 0u;  // an empty row may start at the very end
@@ -284,14 +339,23 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
 #pragma unroll
             for (int i = 0; i < U; i++) {
                 if (ok[i]) {
-                    const int j0 = (int)((unsigned)meta[i] >> 23);
+                    int e[kBlkRun];  // the parked entries of the run (past its end: zero values of B)
+                    if constexpr (KEYED) {
+                        const unsigned int ent = s_ent[ru[i]];
+#pragma unroll
+                        for (int dd = 0; dd < kBlkRun; dd++) e[dd] = (int)((ent >> (8 * dd)) & 0xffu);
+                    } else {  // neighbours: leader entry, + 1, + 2
+                        const int j0 = (int)((unsigned int)meta[i] >> 23);
+#pragma unroll
+                        for (int dd = 0; dd < kBlkRun; dd++) e[dd] = j0 + dd;
+                    }
                     const int idx = col[i] - lo;
                     const int rank = s_pre[idx >> 5] + __popc(s_bits[idx >> 5] & ((1u << (idx & 31)) - 1u));
                     real a[kBlkRun][kBlkRows];
 #pragma unroll
                     for (int dd = 0; dd < kBlkRun; dd++)
 #pragma unroll
-                        for (int r = 0; r < kBlkRows; r++) a[dd][r] = s_a[(j0 + dd) * kBlkRows + r];
+                        for (int r = 0; r < kBlkRows; r++) a[dd][r] = s_a[e[dd] * kBlkRows + r];
 #pragma unroll
                     for (int r = 0; r < kBlkRows; r++) {
                         if (r < RA) {

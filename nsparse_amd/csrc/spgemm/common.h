@@ -92,6 +92,8 @@ struct BinState {
     int b_unsorted;      // some row of B does not have strictly ascending columns
     int queue_head2;     // second persistent-kernel queue of the heavy numeric bin
     int max_span[NB];    // widest column window among the rows of each bin (sizes the LDS of the window kernels)
+    int far_twins;       // twin rows more than two rows away from their pattern leader (k_numeric_setup)
+    int ab_differ;       // the structure of B is not that of A (k_b_info, when asked to compare)
 };
 
 struct Stats {

@@ -221,11 +221,12 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
     // (block.h): {row, lo, span, longest B row | bitmap offset, first A entry, A entries, rows in the group |
     // member rows, their first A entries}
     __shared__ int s_hist[NB], s_cnt[NB], s_base[NB], s_span[NB], s_w[16], s_pref[kFusedRec], s_h[NB];
-    __shared__ int s_max;
+    __shared__ int s_max, s_far;
     __shared__ unsigned long long s_sum;
     if (threadIdx.x < NB) s_hist[threadIdx.x] = s_cnt[threadIdx.x] = s_span[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
         s_max = 0;
+        s_far = 0;
         s_sum = 0;
     }
     __syncthreads();
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
             row_nz[i] = nz;
             row_span_num[i] = sp;
             if (bm_off) bm_off[i] = bm_off[lead];
+            if (l - i > 2 || i - l > 2) atomicAdd(&s_far, 1);  // (a matrix with neighbouring twins has none)
         }
         const int work = row_prod[i];
         hbin = bin_of(nz, sp, thr, work);
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
     if (threadIdx.x == 0) {
         if (s_max) atomicMax(&bs->maxv, s_max);
         if (s_sum) atomicAdd((unsigned long long *)&bs->total, s_sum);
+        if (s_far) atomicAdd(&bs->far_twins, s_far);
         __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     grid_barrier(fs.arrive, 1);

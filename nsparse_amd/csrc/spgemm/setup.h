@@ -104,8 +104,12 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
                                                 const int *__restrict__ todo,
                                                 const unsigned int *__restrict__ range,
                                                 unsigned char *__restrict__ btwin,
-                                                unsigned long long *__restrict__ fill, long long fill_words)
+                                                unsigned long long *__restrict__ fill, long long fill_words,
+                                                const int *__restrict__ cmp_rpt, const int *__restrict__ cmp_col)
 {
+    // cmp_rpt / cmp_col (A's arrays, when A has the shape and nnz of B): bs->ab_differ is raised when the
+    // STRUCTURE of B is not that of A.  C = A * A is usually called with two copies of A; what was learnt
+    // about the rows of A (their pattern classes) then holds for the rows of B.
     // fill: fill_words 64-bit words set to all ones on the way (the twin map of k_row_products, which runs
     // next: a fill launch less).
     for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < fill_words; w += (long long)gridDim.x * 256)
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
         const int q = base + (int)threadIdx.x / W;
         const int r = q < nrows ? (todo ? todo[q] : r0 + q) : -1;
         int lo = 0x7fffffff, hi = -1, b = 0, e = 0;
-        bool bad = false;
+        bool bad = false, ab_diff = false;
         if (r >= 0) {
             b = brpt[r];
             e = brpt[r + 1];
@@ -148,8 +152,10 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
             // candidate twin of the row before: same length (that row ends where this one starts)
             const bool cand = btwin && !todo && r > 0 && len > 0 && b - brpt[r - 1] == len;
             differs = cand ? 0 : 1;
+            if (cmp_rpt != nullptr && lane == 0) ab_diff |= cmp_rpt[r] != b || cmp_rpt[r + 1] != e;
             for (int k = b + lane; k < e; k += W) {
                 const int c = bcol[k];
+                if (cmp_col != nullptr && !ab_diff) ab_diff |= cmp_col[k] != c;
                 if (k > b) bad |= c <= bcol[k - 1];  // strictly ascending?  (neighbour is in cache)
                 if (cand) differs |= bcol[k - len] != c;
                 lo = c < lo ? c : lo;
@@ -164,6 +170,9 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
             hi = h > hi ? h : hi;
         }
         if (bad) atomicOr(&bs->b_unsorted, 1);
+        // (a look first: when B is another matrix every row differs)
+        if (ab_diff && __hip_atomic_load(&bs->ab_differ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+            atomicOr(&bs->ab_differ, 1);
         if (r >= 0 && !defer && lane == 0) {
             if (btwin) btwin[r] = differs == 0 ? 1 : 0;
             BInfo o;

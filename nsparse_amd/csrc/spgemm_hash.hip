@@ -467,7 +467,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                                  float *ms_bin, int write_col, const int *bm_off,
                                  const unsigned int *bm, int max_alen, bool b_sorted,
                                  const int *max_span, const unsigned char *grp, const unsigned char *btwin,
-                                 const int *listed, const int *members, const int4 *desc)
+                                 const int *listed, const int *members, const int4 *desc, const int *bkey)
 {
     int hist[NB], off[NB + 1];
     fold_small_hash_bins(hist_in, hist, off);
@@ -590,16 +590,22 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                            c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[bin_],  \
                            hist[bin_], b->nnz, bm_off, bm);                                    \
     }
-#define NSP_NUM_BLOCK_GO(BS, SPAN, MODEX)                                                       \
+#define NSP_NUM_BLOCK_GO2(BS, SPAN, MODEX, KEYEDX)                                               \
     {                                                                                          \
         static bool big_ok = false;                                                            \
-        allow_big_lds(k_num_block<BS, SPAN, MODEX, kBlkU>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
+        allow_big_lds(k_num_block<BS, SPAN, MODEX, kBlkU, KEYEDX>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
         /* followers of a group head are not listed (k_bin_scatter): listed[bin] heads */        \
         const int heads = grp ? listed[bin_] : hist[bin_];                                     \
-        hipLaunchKernelGGL((k_num_block<BS, SPAN, MODEX, kBlkU>), dim3(8 * ceil_div(heads, 8)), dim3(BS), \
+        hipLaunchKernelGGL((k_num_block<BS, SPAN, MODEX, kBlkU, KEYEDX>), dim3(8 * ceil_div(heads, 8)), dim3(BS), \
                            lds_blk, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
                            c->d_val, row_perm, row_maxb, row_lo, row_span, off[bin_],            \
-                           heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members, desc);    \
+                           heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members, desc, bkey); \
+    }
+// keyed runs (twin rows of B that are not neighbours): the default 128-thread, full-call form only
+#define NSP_NUM_BLOCK_GO(BS, SPAN, MODEX)                                                       \
+    {                                                                                          \
+        if (bkey != nullptr && BS == 128 && MODEX == 1) NSP_NUM_BLOCK_GO2(128, SPAN, 1, true)  \
+        else NSP_NUM_BLOCK_GO2(BS, SPAN, MODEX, false)                                         \
     }
 #define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
@@ -658,7 +664,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
 #define NSP_RANKWIN(MODEX)                                                                      \
     hipLaunchKernelGGL((k_num_block<128, 65536, MODEX, kBlkU>), dim3(8 * ceil_div(heads, 8)), dim3(128), lds_blk, st, \
                        arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_maxb, \
-                       row_lo, row_span, off[bin_], heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members, desc)
+                       row_lo, row_span, off[bin_], heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members, desc, (const int *)nullptr)
         if (write_col & 1) NSP_RANKWIN(1); else NSP_RANKWIN(2);
 #undef NSP_RANKWIN
         NSP_LAUNCH_CHECK();
@@ -848,10 +854,17 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         tw = TwinMap{ttable, tsize - 1, a->nnz, twin_of, twin, fcnt, members};
     }
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
+    const bool same_shape = find_twins && lean_on && M == K && a->N == b->N && a->nnz == b->nnz;
+    const int *cmp_rpt = nullptr, *cmp_col = nullptr;
     {
         const int wb = pick_w_regular(b->nnz, K, b->nnz_max);
         int gb = ceil_div((long long)K * wb, 256);
         int *blist = (b->nnz_max > 0 && b->nnz_max <= kLongFactor * wb) ? nullptr : long_list;
+        // two copies of one matrix (C = A * A as the reference's sample calls it)?  k_b_info compares on its way
+        if (same_shape) {
+            cmp_rpt = a->d_rpt;
+            cmp_col = a->d_col;
+        }
         // A with fewer rows than B: a row block of a partitioned product (B replicated).  Then only
         // the rows of B its columns reach get a record -- for a banded matrix the block's own
         // stretch, so the set-up cost does not grow with the number of ranks.
@@ -870,7 +883,8 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 #define NSP_BI(W)                                                                              \
     case W:                                                                                    \
         hipLaunchKernelGGL(k_b_info<W>, dim3(gb), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym, \
-                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range, btwin, ttable, twin_fill_words); \
+                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range, btwin, ttable, twin_fill_words, \
+                           cmp_rpt, cmp_col); \
         break;
         switch (wb) {
             NSP_BI(1) NSP_BI(2) NSP_BI(4) NSP_BI(8) NSP_BI(16) NSP_BI(32) NSP_BI(64)
@@ -879,7 +893,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         if (blist)
             hipLaunchKernelGGL(k_b_info<64>, dim3(256), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym,
                                (int *)nullptr, long_cnt, 0, (const int *)long_list, (const unsigned int *)nullptr, btwin,
-                               (unsigned long long *)nullptr, 0LL);
+                               (unsigned long long *)nullptr, 0LL, cmp_rpt, cmp_col);
         if (range_part) dev_free(range_part);  // stream-ordered reuse, see scan_exclusive
     }
     long long *partial = (long long *)dev_alloc(sizeof(long long) * kPartialStride * kSetupMaxGrid);
@@ -1025,12 +1039,19 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     }
     S.nnz_c = too_big ? h_num->total : c->nnz;
 
+    // C = A * A on a matrix whose twin rows are mostly NOT neighbours (k_numeric_setup counted them): the
+    // node-block kernel builds its runs of B rows from the pattern leaders instead of from neighbouring entries
+    static const bool keyed_on = !(getenv("NSPARSE_KEYED") && atoi(getenv("NSPARSE_KEYED")) == 0);
+    const int *bkey = (keyed_on && fuse && grp && twin_of && same_shape && h_sym->ab_differ == 0 &&
+                       (long long)h_num->far_twins * 4 > (long long)S.twin_rows)
+                          ? (const int *)twin_of
+                          : (const int *)nullptr;
     // ---- numeric --------------------------------------------------------------------
     if (!too_big) {
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_maxb, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
-                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor, members, blk_desc);
+                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor, members, blk_desc, bkey);
     tm.mark(3, s0);
     {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
         const int seq = ++cx.seq;

@@ -558,3 +558,32 @@ def test_fused_tails_at_their_size_limits(m, lib_d, oracle_d):
     got, st = spgemm(lib_d, A)
     assert_parity(oracle_d, got, ref)
     assert sum(st.num_bin_size) == m and sum(st.sym_bin_size) + st.twin_rows == m
+
+
+@pytest.mark.parametrize("prec", ["d", "s"])
+def test_keyed_runs_of_twin_b_rows(prec, lib_d, lib_s, oracle_d, oracle_s):
+    """C = A * A on a 3-dof brick whose numbering is shuffled inside bands (synth kind 5): twin rows are not
+    neighbours, so the node-block kernel builds its runs of B rows from the pattern leaders of A's rows
+    (two copies of one matrix: k_b_info compares the structures).  Against the oracle, against
+    NSPARSE_KEYED=0, and with a B of the same shape and nnz but ANOTHER structure (columns of some rows
+    moved): the comparison must notice and the product must still be right."""
+    lib, orc = (lib_d, oracle_d) if prec == "d" else (lib_s, oracle_s)
+    A = synth(lib, 5, 6, 6, 24, seed=0x5EED0022)
+    got, st = spgemm(lib, A)
+    assert st.twin_rows > A["M"] // 2
+    assert_parity(orc, got, orc.spgemm(A, A))
+    got0, _ = spgemm_subprocess(A, {"NSPARSE_KEYED": "0"}, prec=prec)
+    assert np.array_equal(got0["rpt"], got["rpt"]) and np.array_equal(got0["col"], got["col"])
+    np.testing.assert_allclose(got0["val"], got["val"], rtol=1e-9 if prec == "d" else 2e-5)
+    # same shape, same nnz, other structure: last column of every 7th row moved to a free place
+    B = dict(A, col=A["col"].copy())
+    rpt, n = A["rpt"], A["N"]
+    moved = 0
+    for r in range(0, A["M"], 7):
+        seg = B["col"][rpt[r]:rpt[r + 1]]
+        if len(seg) and seg[-1] + 1 < n:
+            seg[-1] += 1
+            moved += 1
+    assert moved > 100
+    got, _ = spgemm(lib, A, B)
+    assert_parity(orc, got, orc.spgemm(A, B))
