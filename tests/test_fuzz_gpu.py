@@ -62,3 +62,50 @@ def test_random_products(seed, lib_d, oracle_d, lib_s, oracle_s):
     else:
         assert oracle_d.check_spgemm(got, ref) == 0
     assert sum(st.sym_bin_size) + st.twin_rows == m and sum(st.num_bin_size) == m
+
+
+def _node_block_square(rng):
+    """A square matrix with d unknowns per node of a random banded node graph (every unknown of a node has
+    the node's column pattern: twin rows in classes of d), renumbered not at all / inside bands / globally."""
+    nodes = int(rng.choice([5, 40, 300, 1500]))
+    d = int(rng.choice([1, 2, 3, 4, 6]))
+    bw = min(int(rng.integers(1, 30)), nodes - 1)
+    g = sp.random(nodes, nodes, density=min(1.0, rng.choice([2.0, 6.0, 20.0]) / nodes), format="csr",
+                  random_state=rng, dtype=np.float64)
+    g = (g + sp.diags([np.ones(nodes)] * 3, [-bw, 0, bw], shape=(nodes, nodes), format="csr")).tocsr()
+    a = sp.kron(g, np.ones((d, d)), format="csr")
+    n = a.shape[0]
+    mode = int(rng.integers(0, 3))
+    perm = np.arange(n)
+    if mode == 1:      # shuffled inside bands of a few nodes
+        band = d * int(rng.integers(2, 12))
+        for s in range(0, n, band):
+            perm[s:s + band] = s + rng.permutation(min(band, n - s))
+    elif mode == 2:    # anywhere
+        perm = rng.permutation(n)
+    a = a[perm][:, perm].tocsr()
+    a.sort_indices()
+    a.data = rng.random(a.data.size) + 0.1
+    return dict(M=n, N=n, rpt=a.indptr.astype(np.int32), col=a.indices.astype(np.int32), val=a.data.astype(np.float64))
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NSPARSE_FUZZ_SQ_SEEDS", "24"))))
+def test_random_node_block_squares(seed, lib_d, oracle_d, lib_s, oracle_s):
+    """C = A * A with two copies of A (as the reference's sample calls it) on node-block matrices: twin rows
+    by pattern in classes of 1..6, groups of three, keyed runs when the numbering scatters the classes."""
+    if os.environ.get("NSPARSE_FUZZ_PREC", "d") == "s":
+        lib_d, oracle_d = lib_s, oracle_s
+    rng = np.random.default_rng(int(os.environ.get("NSPARSE_FUZZ_BASE", "1000")) + 7919 * seed)
+    A = _node_block_square(rng)
+    A["val"] = A["val"].astype(lib_d.real)
+    ref = oracle_d.spgemm(A, A)
+    got, st = spgemm(lib_d, A, numeric_again=True)
+    assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
+    if lib_d.real == np.float32:
+        from oracle.oracle import Oracle
+        assert oracle_d.check_spgemm(got, oracle_fp64_accumulated(Oracle("d"), A, A)) == 0
+    else:
+        assert oracle_d.check_spgemm(got, ref) == 0
+    assert np.array_equal(got["col_again"], got["col"])
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9 if lib_d.real == np.float64 else 2e-5)
+    assert sum(st.sym_bin_size) + st.twin_rows == A["M"] and sum(st.num_bin_size) == A["M"]
