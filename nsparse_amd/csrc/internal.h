@@ -62,6 +62,7 @@ struct Context {
     int *h_mapped = nullptr;            // 256 ints of mapped, coherent host memory (GPU writes, host polls)
     int *d_mapped = nullptr;            // device address of h_mapped
     int seq = 0;                        // publish sequence number
+    int num_cus = 0;                    // compute units of the device (grid barriers need every workgroup resident)
     bool counters_clean = false;        // the SpGEMM counter blocks of d_scratch were zeroed behind the last call
     bool profiling = false;
     bool bin_timing = false;            // per-bin begin / end events in spgemm_kernel_hash (two API calls per bin)

@@ -861,7 +861,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         int gb = ceil_div((long long)K * wb, 256);
         int *blist = (b->nnz_max > 0 && b->nnz_max <= kLongFactor * wb) ? nullptr : long_list;
         // two copies of one matrix (C = A * A as the reference's sample calls it)?  k_b_info compares on its way
-        if (same_shape) {
+        if (same_shape && !(a->d_rpt == b->d_rpt && a->d_col == b->d_col)) {  // (one object: nothing to compare)
             cmp_rpt = a->d_rpt;
             cmp_col = a->d_col;
         }
@@ -905,7 +905,9 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // matrices of up to 256 K rows: the helper chains behind the big kernels are one launch each (fused.h)
     static const bool fused_on = !(getenv("NSPARSE_FUSED") && atoi(getenv("NSPARSE_FUSED")) == 0);
     const int fgrid = ceil_div(M + 1, 1024);
-    const bool fuse = fused_on && !numeric_only && fgrid <= kFusedMaxBlocks;
+    // (one 1024-thread workgroup per CU at most: the grid barrier needs all of them resident, also on a
+    //  partitioned or CU-masked device)
+    const bool fuse = fused_on && !numeric_only && fgrid <= kFusedMaxBlocks && fgrid <= cx.num_cus;
     const int nparts = launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
                         use_bm ? (num_thr.rank_span > num_thr.dense_span[2] ? num_thr.rank_span : num_thr.dense_span[2]) : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, tw, !fuse, s0);
     void *bm_scan_tmp = nullptr;
