@@ -104,12 +104,8 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
                                                 const int *__restrict__ todo,
                                                 const unsigned int *__restrict__ range,
                                                 unsigned char *__restrict__ btwin,
-                                                unsigned long long *__restrict__ fill, long long fill_words,
-                                                const int *__restrict__ cmp_rpt, const int *__restrict__ cmp_col)
+                                                unsigned long long *__restrict__ fill, long long fill_words)
 {
-    // cmp_rpt / cmp_col (A's arrays, when A has the shape and nnz of B): bs->ab_differ is raised when the
-    // STRUCTURE of B is not that of A.  C = A * A is usually called with two copies of A; what was learnt
-    // about the rows of A (their pattern classes) then holds for the rows of B.
     // fill: fill_words 64-bit words set to all ones on the way (the twin map of k_row_products, which runs
     // next: a fill launch less).
     for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < fill_words; w += (long long)gridDim.x * 256)
@@ -134,7 +130,7 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
         const int q = base + (int)threadIdx.x / W;
         const int r = q < nrows ? (todo ? todo[q] : r0 + q) : -1;
         int lo = 0x7fffffff, hi = -1, b = 0, e = 0;
-        bool bad = false, ab_diff = false;
+        bool bad = false;
         if (r >= 0) {
             b = brpt[r];
             e = brpt[r + 1];
@@ -152,10 +148,8 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
             // candidate twin of the row before: same length (that row ends where this one starts)
             const bool cand = btwin && !todo && r > 0 && len > 0 && b - brpt[r - 1] == len;
             differs = cand ? 0 : 1;
-            if (cmp_rpt != nullptr && lane == 0) ab_diff |= cmp_rpt[r] != b || cmp_rpt[r + 1] != e;
             for (int k = b + lane; k < e; k += W) {
                 const int c = bcol[k];
-                if (cmp_col != nullptr && !ab_diff) ab_diff |= cmp_col[k] != c;
                 if (k > b) bad |= c <= bcol[k - 1];  // strictly ascending?  (neighbour is in cache)
                 if (cand) differs |= bcol[k - len] != c;
                 lo = c < lo ? c : lo;
@@ -170,9 +164,6 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
             hi = h > hi ? h : hi;
         }
         if (bad) atomicOr(&bs->b_unsorted, 1);
-        // (a look first: when B is another matrix every row differs)
-        if (ab_diff && __hip_atomic_load(&bs->ab_differ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-            atomicOr(&bs->ab_differ, 1);
         if (r >= 0 && !defer && lane == 0) {
             if (btwin) btwin[r] = differs == 0 ? 1 : 0;
             BInfo o;
@@ -492,6 +483,30 @@ __global__ __launch_bounds__(64) void k_publish(const BinState *__restrict__ src
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Is the STRUCTURE of B that of A (same shape and nnz given)?  C = A * A is usually called with two copies of
+// A (the reference's sample uploads both); what was learnt about the rows of A -- their pattern classes --
+// then holds for the rows of B (keyed runs, block.h).  Launched behind the set-up tail: it runs while the
+// host is busy with the first flag, so it costs the call nothing.  bs->ab_differ is raised on a mismatch
+// (a look first: when B is another matrix every workgroup finds one).
+__global__ __launch_bounds__(256) void k_ab_compare(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                    const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                    int M, int nnz, BinState *bs)
+{
+    bool diff = false;
+    const int stride = gridDim.x * 256;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i <= M; i += stride) diff |= arpt[i] != brpt[i];
+    const int n4 = ((reinterpret_cast<size_t>(acol) | reinterpret_cast<size_t>(bcol)) & 15) == 0 ? nnz >> 2 : 0;
+    const int4 *a4 = reinterpret_cast<const int4 *>(acol), *b4 = reinterpret_cast<const int4 *>(bcol);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const int4 x = a4[i], y = b4[i];
+        diff |= x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w;
+    }
+    for (int i = 4 * n4 + blockIdx.x * 256 + threadIdx.x; i < nnz; i += stride) diff |= acol[i] != bcol[i];
+    if (__ballot(diff) != 0 && (threadIdx.x & 63) == 0 &&
+        __hip_atomic_load(&bs->ab_differ, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
+        atomicOr(&bs->ab_differ, 1);
 }
 
 // End of a call: zero the counter blocks for the next one (a fill launch less at its start -- the host

@@ -855,16 +855,10 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     }
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
     const bool same_shape = find_twins && lean_on && M == K && a->N == b->N && a->nnz == b->nnz;
-    const int *cmp_rpt = nullptr, *cmp_col = nullptr;
     {
         const int wb = pick_w_regular(b->nnz, K, b->nnz_max);
         int gb = ceil_div((long long)K * wb, 256);
         int *blist = (b->nnz_max > 0 && b->nnz_max <= kLongFactor * wb) ? nullptr : long_list;
-        // two copies of one matrix (C = A * A as the reference's sample calls it)?  k_b_info compares on its way
-        if (same_shape && !(a->d_rpt == b->d_rpt && a->d_col == b->d_col)) {  // (one object: nothing to compare)
-            cmp_rpt = a->d_rpt;
-            cmp_col = a->d_col;
-        }
         // A with fewer rows than B: a row block of a partitioned product (B replicated).  Then only
         // the rows of B its columns reach get a record -- for a banded matrix the block's own
         // stretch, so the set-up cost does not grow with the number of ranks.
@@ -883,8 +877,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 #define NSP_BI(W)                                                                              \
     case W:                                                                                    \
         hipLaunchKernelGGL(k_b_info<W>, dim3(gb), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym, \
-                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range, btwin, ttable, twin_fill_words, \
-                           cmp_rpt, cmp_col); \
+                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range, btwin, ttable, twin_fill_words); \
         break;
         switch (wb) {
             NSP_BI(1) NSP_BI(2) NSP_BI(4) NSP_BI(8) NSP_BI(16) NSP_BI(32) NSP_BI(64)
@@ -893,7 +886,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         if (blist)
             hipLaunchKernelGGL(k_b_info<64>, dim3(256), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym,
                                (int *)nullptr, long_cnt, 0, (const int *)long_list, (const unsigned int *)nullptr, btwin,
-                               (unsigned long long *)nullptr, 0LL, cmp_rpt, cmp_col);
+                               (unsigned long long *)nullptr, 0LL);
         if (range_part) dev_free(range_part);  // stream-ordered reuse, see scan_exclusive
     }
     long long *partial = (long long *)dev_alloc(sizeof(long long) * kPartialStride * kSetupMaxGrid);
@@ -920,6 +913,15 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                            (const int *)row_span, M, sym_thr, row_perm, (const unsigned char *)twin, fs);
         NSP_LAUNCH_CHECK();
         tm.mark(1, s0);
+        // two copies of one matrix (C = A * A as the reference's sample calls it)?  Compared while the host is
+        // busy with the flag; the answer (d_num->ab_differ) travels with the second publish.
+        if (same_shape && !(a->d_rpt == b->d_rpt && a->d_col == b->d_col)) {
+            int gc = ceil_div(a->nnz, 4 * 256);
+            gc = gc < 1 ? 1 : (gc > 2048 ? 2048 : gc);
+            hipLaunchKernelGGL(k_ab_compare, dim3(gc), dim3(256), 0, s0, (const int *)a->d_rpt, (const int *)a->d_col,
+                               (const int *)b->d_rpt, (const int *)b->d_col, M, a->nnz, d_num);
+            NSP_LAUNCH_CHECK();
+        }
         wait_published(120, seq, s0);
     } else {
     if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
@@ -1044,7 +1046,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // C = A * A on a matrix whose twin rows are mostly NOT neighbours (k_numeric_setup counted them): the
     // node-block kernel builds its runs of B rows from the pattern leaders instead of from neighbouring entries
     static const bool keyed_on = !(getenv("NSPARSE_KEYED") && atoi(getenv("NSPARSE_KEYED")) == 0);
-    const int *bkey = (keyed_on && fuse && grp && twin_of && same_shape && h_sym->ab_differ == 0 &&
+    const int *bkey = (keyed_on && fuse && grp && twin_of && same_shape && h_num->ab_differ == 0 &&
                        (long long)h_num->far_twins * 4 > (long long)S.twin_rows)
                           ? (const int *)twin_of
                           : (const int *)nullptr;
