@@ -5,6 +5,7 @@
 //   csr_memcpy / csr_memcpyDtH     cuda-c/src/nsparse.cu:146-168
 //   release_csr / release_amb      cuda-c/src/nsparse.cu:209-235
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -152,7 +153,19 @@ Context &ctx()
     Context &c = per_dev[current_device()];
     std::lock_guard<std::mutex> lk(mu);
     if (!c.ready) {
+        // the streams of the big-LDS bins (hash bin 4, heavy bin 5, bit-window bin 10) get the highest
+        // priority: their few, large workgroups should take CUs as they free up instead of queueing behind a
+        // million small rows and running alone at the end (NSPARSE_STREAM_PRIO=0: all equal)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        const bool prio_on = !(getenv("NSPARSE_STREAM_PRIO") && atoi(getenv("NSPARSE_STREAM_PRIO")) == 0);
         for (int i = 0; i < kMaxBins; i++) {
+            const bool big = prio_on && (i == 4 || i == 5 || i == 10);
+            if (big) {
+                NSP_CHECK(hipStreamCreateWithPriority(&c.stream[i], hipStreamNonBlocking, prio_hi));
+                NSP_CHECK(hipEventCreateWithFlags(&c.ev_join[i], hipEventDisableTiming));
+                continue;
+            }
             NSP_CHECK(hipStreamCreateWithFlags(&c.stream[i], hipStreamNonBlocking));
             NSP_CHECK(hipEventCreateWithFlags(&c.ev_join[i], hipEventDisableTiming));
         }
