@@ -9,11 +9,12 @@
 // ds_add_f64 (tools/lds_atomic: 5-20 lane-operations per clock per CU; the kernel needed 1.3).
 //
 // So this kernel cuts the instructions and the bytes per product, by the structure finite-element
-// matrices have: the degrees of freedom of one mesh node are consecutive rows with ONE column
-// pattern ("twin rows", already detected for the symbolic phase).
+// matrices have: the degrees of freedom of one mesh node are rows with ONE column pattern ("twin
+// rows", found by pattern for the symbolic phase -- neighbours or not).
 //   * up to 3 twin rows of A are one workgroup: the A entries are parked once, every element of B is
 //     loaded once and used for all of them (3 windows in LDS);
-//   * consecutive A entries whose rows of B are twins (the 3 dof of the node the entry points to)
+//   * A entries whose rows of B are twins (the 3 dof of the node the entry points to: neighbouring
+//     entries, or -- KEYED, C = A * A on a scattered numbering -- entries grouped by pattern leader)
 //     are one RUN: the lane that holds column p of the run loads the column id once and the values of
 //     the (up to 3) rows, forms  sum_d a[r][d] * b[d][p]  in registers and issues ONE ds_add_f64 per
 //     C row -- a 3 x 3 node block costs 4 loads, 9 multiply-adds and 3 atomics for 9 products,
@@ -37,8 +38,8 @@ constexpr int kBlkRun = 3;         // twin rows of B per run
 constexpr int kBlkAccElems = 4608;  // LDS budget of the accumulator rows of one workgroup (36 KiB)
 
 // grp[r]: bits 0-1 = position of row r inside its group (0: head), bits 2-3 = rows in the group (heads).
-// A group = a pattern leader and its first (up to two) twins (k_twin_find: members[]), as many of them
-// as accumulator rows of this pattern's nnz fit the LDS budget; later twins of the same leader and rows
+// A group = a pattern leader and the lowest / highest twin that signed up with it (twin_probe:
+// members[]), as many of them as accumulator rows of this pattern's nnz fit the LDS budget; later twins of the same leader and rows
 // outside the numeric window bins are groups of one.  Every row decides for itself from its leader's
 // numbers, so heads and followers agree without talking.
 __global__ __launch_bounds__(256) void k_twin_groups(const int *__restrict__ twin_of,
