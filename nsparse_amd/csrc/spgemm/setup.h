@@ -366,7 +366,16 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             mb = m2 > mb ? m2 : mb;
         }
         int leader = -1;
-        if (tw.table && row < M) leader = twin_probe<W>(arpt, acol, row, key, tw, lane);
+        // (rows of the tiny symbolic bin are not worth a probe: nothing to skip there, and they are no
+        //  candidates for the node-block groups -- on a web graph that is most of a million rows)
+        if (tw.table && row < M) {
+            if (n > thr.tiny) {
+                leader = twin_probe<W>(arpt, acol, row, key, tw, lane);
+            } else if (lane == 0) {
+                tw.twin_of[row] = -1;
+                tw.twin[row] = 0;
+            }
+        }
         int bin = -1;
         if (row < M && lane == 0) {
             const int ni = n > 0x7fffffffLL ? 0x7fffffff : (int)n;  // saturate (hub rows)

@@ -127,18 +127,19 @@ def row_windows(A, B):
     return prod, span
 
 
-def twin_rows(A):
+def twin_rows(A, prod, tiny=32):
     """Rows of A whose column pattern (the stored sequence of column ids) another row already has
-    (k_twin_find in csrc/spgemm/setup.h): all but one row of every pattern class are left out of the
-    symbolic bins and take that row's structure.  Which row of a class leads is not fixed on the
-    device; the mask marks all but the first, the counts are the same."""
+    (twin_probe in csrc/spgemm/setup.h): all but one row of every pattern class are left out of the
+    symbolic bins and take that row's structure.  Rows with at most `tiny` products (prod: products per
+    row; the tiny symbolic bin) are not probed.  Which row of a class leads is not fixed on the device;
+    the mask marks all but the first, the counts are the same."""
     rpt = np.asarray(A["rpt"], dtype=np.int64)
     col = np.ascontiguousarray(A["col"], dtype=np.int32)
     M = len(rpt) - 1
     tw = np.zeros(M, dtype=bool)
     seen = set()
     for r in range(M):
-        if rpt[r + 1] > rpt[r]:
+        if rpt[r + 1] > rpt[r] and prod[r] > tiny:
             k = col[rpt[r]:rpt[r + 1]].tobytes()
             if k in seen:
                 tw[r] = True

@@ -63,7 +63,7 @@ def _bins_match(orc, st, row_prod, row_nz, lib, A, B=None):
     sym, num = ladders(lib)
     prod, span = row_windows(A, B)
     assert np.array_equal(prod, row_prod)
-    tw = twin_rows(A)  # not binned in the symbolic phase
+    tw = twin_rows(A, row_prod)  # not binned in the symbolic phase
     assert st.twin_rows == int(tw.sum())
     assert list(st.sym_bin_size)[:11] == np.bincount(bins_of(row_prod, span, sym)[~tw], minlength=11).tolist()
     assert list(st.num_bin_size)[:10] == np.bincount(numeric_bins(row_nz, row_prod, span, sym, num), minlength=10).tolist()
@@ -388,7 +388,7 @@ def test_twin_rows_take_their_leaders_structure(prec, lib_d, lib_s, oracle_d, or
              val=(b.data + 0.5).astype(lib.real))
     ref = orc.spgemm(A, B)
     got, st = spgemm(lib, A, B, numeric_again=True)
-    tw = twin_rows(A)
+    tw = twin_rows(A, row_windows(A, B)[0])
     assert st.twin_rows == int(tw.sum()) and st.twin_rows > 200
     assert sum(st.sym_bin_size) + st.twin_rows == m and sum(st.num_bin_size) == m
     assert_parity(orc, got, ref)
