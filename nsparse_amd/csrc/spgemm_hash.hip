@@ -40,11 +40,13 @@
 //
 // Source map (one translation unit; this file holds the host pipeline):
 //   spgemm/common.h        bin ladders, BinState, hash probe, product walk, wave helpers
-//   spgemm/setup.h         k_b_info, k_row_products, k_reduce_partials, k_hist, k_bin_scatter, k_publish
+//   spgemm/setup.h         k_b_info, k_row_products (+ twin_probe), k_reduce_partials, k_hist, k_bin_scatter,
+//                          k_publish, k_ab_compare, k_finish
+//   spgemm/fused.h         k_setup_tail, k_numeric_setup                  (the helper chains as one launch, M < 256 K)
 //   spgemm/symbolic.h      k_sym_small, k_sym_tb, k_sym_global            (bins 0-5)
 //   spgemm/numeric.h       k_num_small, k_num_tb, k_num_global            (bins 0-4, fallback)
 //   spgemm/window.h        k_sym_dense, k_sym_bits, k_num_dense           (bins 6-10)
-//   spgemm/block.h         k_num_block, k_twin_groups                     (numeric bins 6-8: node blocks)
+//   spgemm/block.h         k_num_block, k_twin_groups                     (numeric bins 6-9: node blocks)
 //   spgemm/heavy_tiled.h   k_num_tiled                                    (bin 5, dense tiles)
 //   spgemm/heavy_ranked.h  k_num_ranked                                   (bin 5, thin rows)
 //
