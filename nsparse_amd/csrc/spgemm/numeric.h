@@ -281,10 +281,22 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
 {
     __shared__ __attribute__((aligned(16))) acc_t vals[TMAX];
     __shared__ __attribute__((aligned(16))) int keys[TMAX];
-    __shared__ __attribute__((aligned(16))) int srt[PMAX];
-    __shared__ int2 s_ext[BS];
-    __shared__ real s_av[BS];
-    __shared__ DeferList<true, (PMAX / 16 > 32 ? PMAX / 16 : 32)> s_defer;
+    // the scratch of the product walk and the sort buffer are never alive together: one block of LDS for
+    // both (a row of the 256-slot bin: 5.6 -> 4.6 KB, so the 32 wavefronts of a CU all get a row instead of 29)
+    struct WalkScratch {
+        int2 ext[BS];
+        real av[BS];
+        DeferList<true, (PMAX / 16 > 32 ? PMAX / 16 : 32)> defer;
+    };
+    union Overlay {
+        WalkScratch w;
+        int srt[PMAX];
+    };
+    __shared__ __attribute__((aligned(16))) Overlay s_ov;
+    int *srt = s_ov.srt;
+    int2 *s_ext = s_ov.w.ext;
+    real *s_av = s_ov.w.av;
+    auto &s_defer = s_ov.w.defer;
     __shared__ int s_cnt;
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
