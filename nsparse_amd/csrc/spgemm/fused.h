@@ -147,8 +147,13 @@ __global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict
                                                      const int *__restrict__ row_prod,
                                                      const int *__restrict__ row_span, int M, Thr thr,
                                                      int *__restrict__ perm,
-                                                     const unsigned char *__restrict__ skip, FusedSync fs)
+                                                     const unsigned char *__restrict__ skip, FusedSync fs,
+                                                     int4 *__restrict__ desc, const int *__restrict__ arpt,
+                                                     const int *__restrict__ row_lo,
+                                                     const int *__restrict__ row_maxb)
 {
+    // desc != nullptr: a record per row listed in a window bin, in list order, for k_sym_dense (window.h):
+    // {row, lo, span, longest B row | first A entry, end of the A row, products, bitmap offset | bitmap words}
     __shared__ unsigned long long s_acc[kPartialStride];
     __shared__ int s_max, s_alen;
     __shared__ int s_cnt[NB], s_base[NB], s_span[NB], s_w[16], s_pref[kFusedRec], s_h[NB];
@@ -179,10 +184,17 @@ __global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict
     const int excl = block_scan_1024(v, s_w, total);
     const bool listed = i < M && !(skip && skip[i]);
     int bin = -1;
+    int4 d0 = make_int4(0, 0, 0, 0), d1 = d0;
     if (listed) {
         const int ni = row_prod[i], sp = row_span[i];
         bin = bin_of(ni, sp, thr, ni);
-        if (bin >= kDenseBin0) atomicMax(&s_span[bin], sp);
+        if (bin >= kDenseBin0) {
+            atomicMax(&s_span[bin], sp);
+            if (desc) {
+                d0 = make_int4(i, row_lo[i], sp, row_maxb[i]);
+                d1 = make_int4(arpt[i], arpt[i + 1], ni, 0);
+            }
+        }
     }
     const int rank = rank_in_bin(bin, s_cnt);
     __syncthreads();
@@ -201,7 +213,14 @@ __global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict
         __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     grid_barrier(fs.arrive, 1);
-    fused_tail(i, M, excl, bm_words ? bm_off : nullptr, bin, listed, rank, s_base, s_pref, s_h, bs, perm, fs, false);
+    const int pos = fused_tail(i, M, excl, bm_words ? bm_off : nullptr, bin, listed, rank, s_base, s_pref, s_h, bs,
+                               perm, fs, false);
+    if (desc && pos >= 0 && bin >= kDenseBin0) {
+        d1.w = s_pref[0] + excl;  // this row's bitmap offset (what the scan wrote to bm_off[i])
+        desc[3 * pos] = d0;
+        desc[3 * pos + 1] = d1;
+        desc[3 * pos + 2] = make_int4(v, 0, 0, 0);
+    }
 }
 
 // ---- symbolic tail: twins take their leader's result, node-block groups, C.rpt, numeric histogram and

@@ -32,8 +32,11 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
                                                   int bnnz, const int *__restrict__ bm_off,
                                                   unsigned int *__restrict__ bm,
                                                   int *__restrict__ row_span_num,
-                                                  const unsigned char *__restrict__ btwin)
+                                                  const unsigned char *__restrict__ btwin,
+                                                  const int4 *__restrict__ desc)
 {
+    // desc != nullptr: k_setup_tail left a record per listed row, in list order (fused.h): the row words
+    // come back in one round trip instead of list -> row words.
     // flags: dynamic LDS sized by the widest window actually in the bin, (span/4 + 8) words -- a
     // bin spans a 4x range of windows and a static array for its upper end would cost occupancy
     unsigned int *flag4 = reinterpret_cast<unsigned int *>(nsp_dyn_lds);
@@ -41,9 +44,25 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
     __shared__ int s_nz;
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
-    const int rid = row_perm[bin_off + slot];
-    const int lo = row_lo[rid];
-    const int span = row_span[rid];
+    int rid, lo, span, a_beg, a_end, prod, maxb, bmo = 0, bw = 0;
+    if (desc) {
+        const int4 d0 = desc[3 * (bin_off + slot)], d1 = desc[3 * (bin_off + slot) + 1],
+                   d2 = desc[3 * (bin_off + slot) + 2];
+        rid = d0.x, lo = d0.y, span = d0.z, maxb = d0.w;
+        a_beg = d1.x, a_end = d1.y, prod = d1.z, bmo = d1.w;
+        bw = d2.x;
+    } else {
+        rid = row_perm[bin_off + slot];
+        lo = row_lo[rid];
+        span = row_span[rid];
+        a_beg = arpt[rid], a_end = arpt[rid + 1];
+        prod = row_prod[rid];
+        maxb = row_maxb[rid];
+        if (bm != nullptr) {
+            bmo = bm_off[rid];
+            bw = bm_off[rid + 1] - bmo;
+        }
+    }
     const int words = (span + 3) >> 2;
     {
         uint4 *f4 = reinterpret_cast<uint4 *>(flag4);
@@ -56,8 +75,7 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
     // lanes past the end of a B row store into scratch bytes behind the flags instead of being
     // masked off: a select costs less than an exec-mask save / restore per element
     const int dummy = 4 * words + 32 + (threadIdx.x & 31);
-    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid], VWS);
+    const int g = group_width(prod, a_end - a_beg, BS, maxb, VWS);
     walk_products<BS, false, VWS>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg,
                              a_end, g, s_ext, (real *)nullptr,
                              [&](const IVecS &k, const RVecS &, int n, real) {
@@ -74,8 +92,7 @@ __global__ __launch_bounds__(BS) void k_sym_dense(const int *__restrict__ arpt, 
     // -> one word.  The numeric dense kernel then needs no flags of its own (one LDS atomic
     // per product instead of an atomic and a store) and no sort.
     if (bm != nullptr) {
-        const int bw = bm_off[rid + 1] - bm_off[rid];
-        unsigned int *dst = bm + bm_off[rid];
+        unsigned int *dst = bm + bmo;
         for (int wi = threadIdx.x; wi < bw; wi += BS) {
             unsigned int bits = 0;
 #pragma unroll

@@ -327,7 +327,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
                                   int max_prod, BinState *d_bs, Context &cx, float *ms_bin,
                                   int *fail_rows, const int *bm_off, unsigned int *bm,
                                   int *row_span_num, const int *max_span, int max_alen, bool b_sorted,
-                                  const unsigned char *btwin)
+                                  const unsigned char *btwin, const int4 *sdesc)
 {
     int hist[NB], off[NB + 1];
     fold_small_hash_bins(hist_in, hist, off);
@@ -359,7 +359,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         const size_t lds = sizeof(int) * (size_t)((span_b + 63) / 64 * 16 + 16);               \
         hipLaunchKernelGGL((k_sym_dense<BS, SPAN>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), lds, st, \
                            arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_lo, row_span, row_nz, \
-                           off[BIN], hist[BIN], b->nnz, bm_off, bm, row_span_num, btwin);      \
+                           off[BIN], hist[BIN], b->nnz, bm_off, bm, row_span_num, btwin, sdesc); \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -804,6 +804,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     unsigned int *bm = nullptr;
     unsigned char *grp = nullptr;
     int4 *blk_desc = nullptr;  // row records of the node-block kernel, in list order (k_numeric_setup)
+    int4 *sym_desc = nullptr;  // row records of k_sym_dense, in list order (k_setup_tail)
     BinLauncher sym_used(cx, 0);
     int *row_prod = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
     int *row_nz = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
@@ -907,12 +908,15 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                         use_bm ? (num_thr.rank_span > num_thr.dense_span[2] ? num_thr.rank_span : num_thr.dense_span[2]) : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, tw, !fuse, s0);
     void *bm_scan_tmp = nullptr;
     const int grid_m = ceil_div(M, 1024);
+    if (fuse && use_bm && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
+        sym_desc = (int4 *)dev_alloc(sizeof(int4) * 3 * (size_t)M);
     if (fuse) {
         const int seq = ++cx.seq;
         const FusedSync fs = {cx.d_scratch + 244, cx.d_scratch + 512, cx.d_mapped, cx.d_mapped + 120, seq};
         hipLaunchKernelGGL(k_setup_tail, dim3(fgrid), dim3(1024), 0, s0, (const long long *)partial, nparts, d_sym,
                            use_bm ? (const int *)bm_words : (const int *)nullptr, bm_off, (const int *)row_prod,
-                           (const int *)row_span, M, sym_thr, row_perm, (const unsigned char *)twin, fs);
+                           (const int *)row_span, M, sym_thr, row_perm, (const unsigned char *)twin, fs, sym_desc,
+                           (const int *)a->d_rpt, (const int *)row_lo, (const int *)row_maxb);
         NSP_LAUNCH_CHECK();
         tm.mark(1, s0);
         // two copies of one matrix (C = A * A as the reference's sample calls it)?  Compared while the host is
@@ -961,7 +965,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         BinLauncher LS = symbolic_phase(a, b, row_prod, row_maxb, row_lo, row_span, row_nz, row_perm, h_sym->hist,
                                         h_sym->maxv, d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows,
                                         bm_off, bm, row_span_num, h_sym->max_span, (int)h_sym->max_alen,
-                                        h_sym->b_unsorted == 0, btwin);
+                                        h_sym->b_unsorted == 0, btwin, bm ? (const int4 *)sym_desc : (const int4 *)nullptr);
         sym_used = LS;
         {
             long long binned = 0;
@@ -1090,6 +1094,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     if (twin_of) dev_free(twin_of);
     if (grp) dev_free(grp);
     if (blk_desc) dev_free(blk_desc);
+    if (sym_desc) dev_free(sym_desc);
     if (btwin) dev_free(btwin);
     dev_free(row_span_num);
     dev_free(bm_off);
