@@ -47,8 +47,13 @@ __device__ __forceinline__ void grid_barrier(int *ctr, int round)
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const int target = round * (int)gridDim.x;
-        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target)
+        // (a workgroup that never arrives -- some tenant holding the CUs for good -- must not become a silent
+        //  hang: after some seconds of polling the kernel aborts and the host sees a launch failure)
+        unsigned int spins = 0;
+        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1u << 23)) __builtin_trap();
+        }
     }
     __syncthreads();
 }
