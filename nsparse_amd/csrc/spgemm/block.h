@@ -145,10 +145,11 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                    d2 = desc[3 * (bin_off + slot) + 2];
         rid = d0.x, lo = d0.y, span = d0.z, maxb = d0.w;
         bmo = d1.x, a_beg[0] = d1.y, alen = d1.z, RA = d1.w;
-        a_beg[1] = d2.z, a_beg[2] = d2.w;
         off[0] = crpt[rid];
         off[1] = RA > 1 ? crpt[d2.x] : 0;
         off[2] = RA > 2 ? crpt[d2.y] : 0;
+        a_beg[1] = RA > 1 ? arpt[d2.x] : 0;
+        a_beg[2] = RA > 2 ? arpt[d2.y] : 0;
     } else {
         rid = row_perm[bin_off + slot];
         const int gcode = grp ? (int)grp[rid] : (1 << 2);

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
 {
     // desc != nullptr: a record per row listed in a window bin, in list order, for the node-block kernel
     // (block.h): {row, lo, span, longest B row | bitmap offset, first A entry, A entries, rows in the group |
-    // member rows, their first A entries}
+    // member rows}
     __shared__ int s_hist[NB], s_cnt[NB], s_base[NB], s_span[NB], s_w[16], s_pref[kFusedRec], s_h[NB];
     __shared__ int s_max, s_far;
     __shared__ unsigned long long s_sum;
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
                     const int ra = code >> 2, ab = arpt[i];
                     d0 = make_int4(i, row_lo[i], sp, row_maxb[i]);
                     d1 = make_int4(bm_off ? bm_off[i] : 0, ab, arpt[i + 1] - ab, ra);
-                    d2 = make_int4(m0, m1, ra > 1 ? arpt[m0] : 0, ra > 2 ? arpt[m1] : 0);
+                    d2 = make_int4(m0, m1, 0, 0);  // (their first A entries: read by the kernel with its C.rpt words)
                 }
             }
         }
