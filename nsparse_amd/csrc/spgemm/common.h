@@ -72,6 +72,7 @@ constexpr int kDenseBin0 = 6;
 constexpr int kBitsBin0 = 9;
 constexpr int kSetupMaxGrid = 16384;
 constexpr int kGroupMembers = 2;  // twins of a leader that are recorded as its numeric group (block.h: 3 rows)
+constexpr int kTwinEager = 8;     // rows this long claim their map slot / sign up without looking first (twin_probe)
 constexpr int kPartialStride = 16;  // long longs per block: hist[NB], max, total, bm, alen
 constexpr int kSymLargeT = 32768;
 constexpr int kSymLargeLimit = 24576;

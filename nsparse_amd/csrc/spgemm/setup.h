@@ -215,7 +215,11 @@ __device__ __forceinline__ int twin_probe(const int *__restrict__ arpt, const in
         while (true) {
             unsigned long long cur = 0;
             if (lane == 0) {
-                cur = __hip_atomic_load(tm.table + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // short rows look before they claim: thousands of them may share one pattern (one-entry rows
+                // that point at a hub page) and would queue on the slot; rows of kTwinEager entries and more
+                // claim at once -- one round trip instead of two for a leader
+                cur = len >= kTwinEager ? ~0ull
+                                        : __hip_atomic_load(tm.table + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (cur == ~0ull) {
                     const unsigned long long old = atomicCAS(tm.table + b, ~0ull, mine);
                     cur = old == ~0ull ? mine : old;
@@ -257,7 +261,8 @@ __device__ __forceinline__ int twin_probe(const int *__restrict__ arpt, const in
         // the thousands of one-entry rows that point at the same hub page would otherwise queue on
         // three addresses.
         if (leader >= 0 &&
-            __hip_atomic_load(tm.fcnt + leader, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kGroupMembers - 1) {
+            (len >= kTwinEager ||
+             __hip_atomic_load(tm.fcnt + leader, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kGroupMembers - 1)) {
             __hip_atomic_fetch_add(tm.fcnt + leader, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_fetch_min((unsigned int *)tm.members + kGroupMembers * leader, (unsigned int)r,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
