@@ -238,14 +238,15 @@ typedef struct {
                                * twin rows (below) are in none                        */
     int num_bin_size[12];     /* rows per numeric bin                               */
     int sym_fail_rows;        /* rows that overflowed LDS and went to the global table */
-    float ms_setup;           /* products + binning              (HIP events)       */
+    float ms_setup;           /* products + binning   (HIP events; the four phase times are 0 unless
+                               * nsparse_set_bin_timing(1) or profiling mode)               */
     float ms_symbolic;        /* all symbolic kernels + scan     (HIP events)       */
     float ms_numeric;         /* numeric binning + all numeric kernels              */
     float ms_total;           /* whole call                                         */
     float ms_sym_bin[12];      /* per-bin kernel time, HIP events on the bin's own stream */
     float ms_num_bin[12];
-    int twin_rows;            /* rows with the column pattern of the row before them: not in the
-                               * symbolic bins, they take that row's structure               */
+    int twin_rows;            /* rows with the column pattern of another row (found by pattern): not in
+                               * the symbolic bins, they take their pattern leader's structure */
 } nsparse_spgemm_stats;
 void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out);
 
@@ -267,10 +268,10 @@ void nsparse_get_spgemm_bins(int *sym_thresholds, int *num_thresholds);
  *    and rocprof, per-bin timings on); 0 (default): bins overlap on their own streams.  */
 void nsparse_set_profiling(int on);
 
-/* Per-bin kernel times in nsparse_spgemm_stats (ms_sym_bin / ms_num_bin): HIP events around the
- * kernels of every bin.  Off by default -- two runtime calls per bin on the launch path, which is
- * the critical path of matrices that use many bins; the phase times (ms_setup ... ms_total) are
- * always measured.  Profiling mode implies it.  Returns the previous setting.                  */
+/* Times in nsparse_spgemm_stats -- per bin (ms_sym_bin / ms_num_bin: HIP events around the kernels of
+ * every bin) and per phase (ms_setup ... ms_total: four event records per call).  Off by default: every
+ * event record is a runtime call on the launch path and a packet on the stream (cant class: 0.337 ->
+ * 0.325 ms without the four phase events).  Profiling mode implies it.  Returns the previous setting. */
 int nsparse_set_bin_timing(int on);
 
 /* 1 (default): device blocks released by release_csr/release_amb and the internal

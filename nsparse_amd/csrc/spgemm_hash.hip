@@ -183,13 +183,21 @@ static int launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *binf
     return grid;
 }
 
+// Phase times of the statistics (ms_setup / ms_symbolic / ms_numeric / ms_total): four event records per call,
+// only when per-bin timing or profiling is switched on -- an event record is a couple of microseconds of
+// host time and a packet on the stream, on a call of 335.
 struct Timer {
     Context &cx;
-    explicit Timer(Context &c) : cx(c) {}
-    void mark(int i, hipStream_t st) { NSP_CHECK(hipEventRecord(cx.ev_t[i], st)); }
+    bool on;
+    explicit Timer(Context &c) : cx(c), on(c.bin_timing || c.profiling) {}
+    void mark(int i, hipStream_t st)
+    {
+        if (on) NSP_CHECK(hipEventRecord(cx.ev_t[i], st));
+    }
     float ms(int i, int j)
     {
         float v = 0;
+        if (!on) return v;
         NSP_CHECK(hipEventSynchronize(cx.ev_t[j]));
         NSP_CHECK(hipEventElapsedTime(&v, cx.ev_t[i], cx.ev_t[j]));
         return v;
