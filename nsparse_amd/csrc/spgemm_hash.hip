@@ -814,15 +814,42 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     int4 *blk_desc = nullptr;  // row records of the node-block kernel, in list order (k_numeric_setup)
     int4 *sym_desc = nullptr;  // row records of k_sym_dense, in list order (k_setup_tail)
     BinLauncher sym_used(cx, 0);
-    int *row_prod = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
-    int *row_nz = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
-    int *row_perm = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
-    int *row_lo = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
-    int *row_span = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
-    int *row_maxb = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
     const int K = b->M;
-    BInfo *binfo = (BInfo *)dev_alloc(sizeof(BInfo) * (size_t)(K > 0 ? K : 1));
-    int *long_list = (int *)dev_alloc(sizeof(int) * kLongCap);  // reused: B rows first, then A rows
+    // The per-row arrays, the records of B, the partials and the twin map are ONE block of the cache, carved
+    // up here: a lookup under the cache lock per array (seventeen of them) was host time at the very start
+    // of the call, before the first kernel is even queued.
+    static const bool twins_on = !(getenv("NSPARSE_TWINS") && atoi(getenv("NSPARSE_TWINS")) == 0);
+    static const bool lean_on = !(getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0);
+    const bool find_twins = !numeric_only && twins_on && M > 1;
+    const bool want_btwin = twins_on && lean_on && K > 1;
+    unsigned int tsize = 1024;
+    while (find_twins && tsize < 2u * (unsigned int)M) tsize <<= 1;
+    const long long twin_fill_words = find_twins ? (long long)tsize + ((long long)M * (1 + kGroupMembers) + 1) / 2 : 0;
+    size_t carve = 0;
+    auto reserve = [&](size_t bytes) {
+        const size_t o = carve;
+        carve += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t M1 = (size_t)(M > 0 ? M : 1);
+    const size_t o_prod = reserve(sizeof(int) * (M1 + 1)), o_nz = reserve(sizeof(int) * (M1 + 1)),
+                 o_perm = reserve(sizeof(int) * M1), o_lo = reserve(sizeof(int) * M1),
+                 o_span = reserve(sizeof(int) * M1), o_maxb = reserve(sizeof(int) * M1),
+                 o_binfo = reserve(sizeof(BInfo) * (size_t)(K > 0 ? K : 1)), o_long = reserve(sizeof(int) * kLongCap),
+                 o_part = reserve(sizeof(long long) * kPartialStride * kSetupMaxGrid),
+                 o_bmw = reserve(sizeof(int) * (M1 + 1)), o_bmo = reserve(sizeof(int) * (M1 + 1)),
+                 o_spn = reserve(sizeof(int) * M1), o_btwin = reserve(want_btwin ? (size_t)K : 0),
+                 o_table = reserve(sizeof(unsigned long long) * (size_t)twin_fill_words),
+                 o_twof = reserve(find_twins ? sizeof(int) * M1 : 0), o_twin = reserve(find_twins ? M1 : 0);
+    char *block = (char *)dev_alloc(carve);
+    int *row_prod = (int *)(block + o_prod);
+    int *row_nz = (int *)(block + o_nz);
+    int *row_perm = (int *)(block + o_perm);
+    int *row_lo = (int *)(block + o_lo);
+    int *row_span = (int *)(block + o_span);
+    int *row_maxb = (int *)(block + o_maxb);
+    BInfo *binfo = (BInfo *)(block + o_binfo);
+    int *long_list = (int *)(block + o_long);  // reused: B rows first, then A rows
     int *long_cnt = cx.d_scratch + 240;                         // [0] B pass, [1] A pass
     if (g_dense_enabled < 0) {
         const char *e = getenv("NSPARSE_DENSE");
@@ -840,28 +867,21 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 
     // rows of B with the column pattern of the row before them (k_b_info): runs of the numeric
     // window kernel (block.h).  NSPARSE_TWINS=0 switches the whole twin machinery off.
-    static const bool twins_on = !(getenv("NSPARSE_TWINS") && atoi(getenv("NSPARSE_TWINS")) == 0);
-    static const bool lean_on = !(getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0);
-    unsigned char *btwin = (twins_on && lean_on && K > 1) ? (unsigned char *)dev_alloc((size_t)K) : nullptr;
+    unsigned char *btwin = want_btwin ? (unsigned char *)(block + o_btwin) : nullptr;
     // rows with the column pattern of another row are not run through the symbolic phase: they take that
     // row's result (twin_probe / k_twin_copy).  NSPARSE_TWINS=0 switches the detection off.
-    const bool find_twins = !numeric_only && twins_on && M > 1;
     unsigned char *twin = nullptr;
     int *twin_of = nullptr, *fcnt = nullptr, *members = nullptr;
     unsigned long long *ttable = nullptr;
-    long long twin_fill_words = 0;
     TwinMap tw = {nullptr, 0u, 0, nullptr, nullptr, nullptr, nullptr};
     if (find_twins) {
-        unsigned int tsize = 1024;
-        while (tsize < 2u * (unsigned int)M) tsize <<= 1;
-        // table, sign-up counters and members in one block, one fill (all ones = free / -1 / none)
-        // (k_b_info fills it on its way, in 64-bit words)
-        twin_fill_words = (long long)tsize + ((long long)M * (1 + kGroupMembers) + 1) / 2;
-        ttable = (unsigned long long *)dev_alloc(sizeof(unsigned long long) * (size_t)twin_fill_words);
+        // table, sign-up counters and members side by side, one fill (all ones = free / -1 / none;
+        // k_b_info fills them on its way, in 64-bit words)
+        ttable = (unsigned long long *)(block + o_table);
         fcnt = (int *)(ttable + tsize);
         members = fcnt + M;
-        twin_of = (int *)dev_alloc(sizeof(int) * (size_t)M);
-        twin = (unsigned char *)dev_alloc((size_t)M);
+        twin_of = (int *)(block + o_twof);
+        twin = (unsigned char *)(block + o_twin);
         tw = TwinMap{ttable, tsize - 1, a->nnz, twin_of, twin, fcnt, members};
     }
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
@@ -900,11 +920,11 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                                (unsigned long long *)nullptr, 0LL);
         if (range_part) dev_free(range_part);  // stream-ordered reuse, see scan_exclusive
     }
-    long long *partial = (long long *)dev_alloc(sizeof(long long) * kPartialStride * kSetupMaxGrid);
+    long long *partial = (long long *)(block + o_part);
     // column bitmaps handed from the symbolic to the numeric dense kernels
-    int *bm_words = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
-    int *bm_off = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
-    int *row_span_num = (int *)dev_alloc(sizeof(int) * (size_t)(M > 0 ? M : 1));
+    int *bm_words = (int *)(block + o_bmw);
+    int *bm_off = (int *)(block + o_bmo);
+    int *row_span_num = (int *)(block + o_spn);
     const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
     // matrices of up to 256 K rows: the helper chains behind the big kernels are one launch each (fused.h)
     static const bool fused_on = !(getenv("NSPARSE_FUSED") && atoi(getenv("NSPARSE_FUSED")) == 0);
@@ -1097,25 +1117,10 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     dev_free(scan_tmp);
     dev_free(bm);
     dev_free(bm_scan_tmp);
-    if (twin) dev_free(twin);
-    if (ttable) dev_free(ttable);
-    if (twin_of) dev_free(twin_of);
     if (grp) dev_free(grp);
     if (blk_desc) dev_free(blk_desc);
     if (sym_desc) dev_free(sym_desc);
-    if (btwin) dev_free(btwin);
-    dev_free(row_span_num);
-    dev_free(bm_off);
-    dev_free(bm_words);
-    dev_free(partial);
-    dev_free(long_list);
-    dev_free(binfo);
-    dev_free(row_maxb);
-    dev_free(row_span);
-    dev_free(row_lo);
-    dev_free(row_perm);
-    dev_free(row_nz);
-    dev_free(row_prod);
+    dev_free(block);
     if (too_big) {
         char msg[160];
         snprintf(msg, sizeof(msg), "nnz(C) = %lld does not fit the int row pointers of sfCSR", (long long)S.nnz_c);
