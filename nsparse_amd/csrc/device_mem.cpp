@@ -106,6 +106,13 @@ void dev_free(void *p)
     NSP_CHECK(hipFree(p));
 }
 
+bool dev_cache_enabled()
+{
+    Cache &c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    return c.enabled;
+}
+
 void dev_cache_enable(bool on)
 {
     Cache &c = cache();

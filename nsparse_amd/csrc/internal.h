@@ -35,6 +35,7 @@ void clear_error();
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);
 void dev_cache_enable(bool on);
+bool dev_cache_enabled();
 void dev_cache_trim();
 
 // ---- threading ---------------------------------------------------------------------

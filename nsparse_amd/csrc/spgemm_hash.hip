@@ -825,31 +825,41 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     unsigned int tsize = 1024;
     while (find_twins && tsize < 2u * (unsigned int)M) tsize <<= 1;
     const long long twin_fill_words = find_twins ? (long long)tsize + ((long long)M * (1 + kGroupMembers) + 1) / 2 : 0;
-    size_t carve = 0;
+    // (with the cache switched off -- "reference-compatible" timing -- every array is its own hipMalloc as
+    //  before: the runtime serves small blocks from pools, one block of megabytes is mapped for real and
+    //  made that timing 1.17 -> 1.62 ms)
+    const bool pooled = dev_cache_enabled();
+    constexpr int kCarveMax = 16;
+    size_t carve = 0, c_off[kCarveMax], c_sz[kCarveMax];
+    int ncarve = 0;
     auto reserve = [&](size_t bytes) {
-        const size_t o = carve;
+        c_off[ncarve] = carve;
+        c_sz[ncarve] = bytes;
         carve += (bytes + 255) & ~(size_t)255;
-        return o;
+        return ncarve++;
     };
     const size_t M1 = (size_t)(M > 0 ? M : 1);
-    const size_t o_prod = reserve(sizeof(int) * (M1 + 1)), o_nz = reserve(sizeof(int) * (M1 + 1)),
-                 o_perm = reserve(sizeof(int) * M1), o_lo = reserve(sizeof(int) * M1),
-                 o_span = reserve(sizeof(int) * M1), o_maxb = reserve(sizeof(int) * M1),
-                 o_binfo = reserve(sizeof(BInfo) * (size_t)(K > 0 ? K : 1)), o_long = reserve(sizeof(int) * kLongCap),
-                 o_part = reserve(sizeof(long long) * kPartialStride * kSetupMaxGrid),
-                 o_bmw = reserve(sizeof(int) * (M1 + 1)), o_bmo = reserve(sizeof(int) * (M1 + 1)),
-                 o_spn = reserve(sizeof(int) * M1), o_btwin = reserve(want_btwin ? (size_t)K : 0),
-                 o_table = reserve(sizeof(unsigned long long) * (size_t)twin_fill_words),
-                 o_twof = reserve(find_twins ? sizeof(int) * M1 : 0), o_twin = reserve(find_twins ? M1 : 0);
-    char *block = (char *)dev_alloc(carve);
-    int *row_prod = (int *)(block + o_prod);
-    int *row_nz = (int *)(block + o_nz);
-    int *row_perm = (int *)(block + o_perm);
-    int *row_lo = (int *)(block + o_lo);
-    int *row_span = (int *)(block + o_span);
-    int *row_maxb = (int *)(block + o_maxb);
-    BInfo *binfo = (BInfo *)(block + o_binfo);
-    int *long_list = (int *)(block + o_long);  // reused: B rows first, then A rows
+    const int o_prod = reserve(sizeof(int) * (M1 + 1)), o_nz = reserve(sizeof(int) * (M1 + 1)),
+              o_perm = reserve(sizeof(int) * M1), o_lo = reserve(sizeof(int) * M1),
+              o_span = reserve(sizeof(int) * M1), o_maxb = reserve(sizeof(int) * M1),
+              o_binfo = reserve(sizeof(BInfo) * (size_t)(K > 0 ? K : 1)), o_long = reserve(sizeof(int) * kLongCap),
+              o_part = reserve(sizeof(long long) * kPartialStride * kSetupMaxGrid),
+              o_bmw = reserve(sizeof(int) * (M1 + 1)), o_bmo = reserve(sizeof(int) * (M1 + 1)),
+              o_spn = reserve(sizeof(int) * M1), o_btwin = reserve(want_btwin ? (size_t)K : 0),
+              o_table = reserve(sizeof(unsigned long long) * (size_t)twin_fill_words),
+              o_twof = reserve(find_twins ? sizeof(int) * M1 : 0), o_twin = reserve(find_twins ? M1 : 0);
+    char *block_base = pooled ? (char *)dev_alloc(carve) : nullptr;
+    char *c_ptr[kCarveMax];
+    for (int q = 0; q < ncarve; q++)
+        c_ptr[q] = pooled ? block_base + c_off[q] : (c_sz[q] ? (char *)dev_alloc(c_sz[q]) : nullptr);
+    int *row_prod = (int *)(c_ptr[o_prod]);
+    int *row_nz = (int *)(c_ptr[o_nz]);
+    int *row_perm = (int *)(c_ptr[o_perm]);
+    int *row_lo = (int *)(c_ptr[o_lo]);
+    int *row_span = (int *)(c_ptr[o_span]);
+    int *row_maxb = (int *)(c_ptr[o_maxb]);
+    BInfo *binfo = (BInfo *)(c_ptr[o_binfo]);
+    int *long_list = (int *)(c_ptr[o_long]);  // reused: B rows first, then A rows
     int *long_cnt = cx.d_scratch + 240;                         // [0] B pass, [1] A pass
     if (g_dense_enabled < 0) {
         const char *e = getenv("NSPARSE_DENSE");
@@ -867,7 +877,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 
     // rows of B with the column pattern of the row before them (k_b_info): runs of the numeric
     // window kernel (block.h).  NSPARSE_TWINS=0 switches the whole twin machinery off.
-    unsigned char *btwin = want_btwin ? (unsigned char *)(block + o_btwin) : nullptr;
+    unsigned char *btwin = want_btwin ? (unsigned char *)(c_ptr[o_btwin]) : nullptr;
     // rows with the column pattern of another row are not run through the symbolic phase: they take that
     // row's result (twin_probe / k_twin_copy).  NSPARSE_TWINS=0 switches the detection off.
     unsigned char *twin = nullptr;
@@ -877,11 +887,11 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     if (find_twins) {
         // table, sign-up counters and members side by side, one fill (all ones = free / -1 / none;
         // k_b_info fills them on its way, in 64-bit words)
-        ttable = (unsigned long long *)(block + o_table);
+        ttable = (unsigned long long *)(c_ptr[o_table]);
         fcnt = (int *)(ttable + tsize);
         members = fcnt + M;
-        twin_of = (int *)(block + o_twof);
-        twin = (unsigned char *)(block + o_twin);
+        twin_of = (int *)(c_ptr[o_twof]);
+        twin = (unsigned char *)(c_ptr[o_twin]);
         tw = TwinMap{ttable, tsize - 1, a->nnz, twin_of, twin, fcnt, members};
     }
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
@@ -920,11 +930,11 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                                (unsigned long long *)nullptr, 0LL);
         if (range_part) dev_free(range_part);  // stream-ordered reuse, see scan_exclusive
     }
-    long long *partial = (long long *)(block + o_part);
+    long long *partial = (long long *)(c_ptr[o_part]);
     // column bitmaps handed from the symbolic to the numeric dense kernels
-    int *bm_words = (int *)(block + o_bmw);
-    int *bm_off = (int *)(block + o_bmo);
-    int *row_span_num = (int *)(block + o_spn);
+    int *bm_words = (int *)(c_ptr[o_bmw]);
+    int *bm_off = (int *)(c_ptr[o_bmo]);
+    int *row_span_num = (int *)(c_ptr[o_spn]);
     const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
     // matrices of up to 256 K rows: the helper chains behind the big kernels are one launch each (fused.h)
     static const bool fused_on = !(getenv("NSPARSE_FUSED") && atoi(getenv("NSPARSE_FUSED")) == 0);
@@ -936,7 +946,9 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                         use_bm ? (num_thr.rank_span > num_thr.dense_span[2] ? num_thr.rank_span : num_thr.dense_span[2]) : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, tw, !fuse, s0);
     void *bm_scan_tmp = nullptr;
     const int grid_m = ceil_div(M, 1024);
-    if (fuse && use_bm && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
+    // (row records: not with the cache off -- two more megabyte-sized hipMalloc / hipFree pairs cost more
+    //  than the round trips they save)
+    if (pooled && fuse && use_bm && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
         sym_desc = (int4 *)dev_alloc(sizeof(int4) * 3 * (size_t)M);
     if (fuse) {
         const int seq = ++cx.seq;
@@ -1031,7 +1043,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
     const int *num_span = numeric_only ? row_span : row_span_num;
     if (!numeric_only && bm == nullptr) num_thr.dense_ratio = num_thr.rank_span = 0;
-    if (fuse && bm && lean_on && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
+    if (pooled && fuse && bm && lean_on && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
         blk_desc = (int4 *)dev_alloc(sizeof(int4) * 3 * (size_t)M);
     if (fuse) {
         // twins' results, groups, C.rpt, histogram, permutation and the publish in one launch (fused.h)
@@ -1120,7 +1132,12 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     if (grp) dev_free(grp);
     if (blk_desc) dev_free(blk_desc);
     if (sym_desc) dev_free(sym_desc);
-    dev_free(block);
+    if (pooled) {
+        dev_free(block_base);
+    } else {
+        for (int q = 0; q < ncarve; q++)
+            if (c_ptr[q]) dev_free(c_ptr[q]);
+    }
     if (too_big) {
         char msg[160];
         snprintf(msg, sizeof(msg), "nnz(C) = %lld does not fit the int row pointers of sfCSR", (long long)S.nnz_c);
