@@ -264,6 +264,15 @@ void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out);
  * else 1 + #(hash_t < n).                                                               */
 void nsparse_get_spgemm_bins(int *sym_thresholds, int *num_thresholds);
 
+/* The fused helper kernels of spgemm_kernel_hash (matrices of up to 256 K rows) hold a grid barrier inside an
+ * ordinary launch, so every workgroup of their grid must be resident at once.  *coresident: how many
+ * 1024-thread workgroups the census at first use found resident together on the current device AS THIS PROCESS
+ * SEES IT (HSA_CU_MASK / ROC_GLOBAL_CU_MASK, partitions; -1: no census yet) -- larger grids take the kernel
+ * chains.  *fallbacks: calls that were repeated with the chains because a barrier timed out after all (CUs
+ * taken away since the census).  Returns 1 while the device's context still fuses, 0 once it has given up.
+ * Either pointer may be NULL.                                                                          */
+int nsparse_fused_state(int *coresident, int *fallbacks);
+
 /* 1: serialise the row bins on one stream (clean per-kernel durations for roofline work
  *    and rocprof, per-bin timings on); 0 (default): bins overlap on their own streams.  */
 void nsparse_set_profiling(int on);
@@ -276,7 +285,10 @@ int nsparse_set_bin_timing(int on);
 
 /* 1 (default): device blocks released by release_csr/release_amb and the internal
  * workspaces are kept in a cache and reused; 0: every call hipMalloc/hipFree's
- * like upstream ("reference-compatible timing").                               */
+ * like upstream ("reference-compatible timing"); 2: no cache either, but the
+ * blocks come from the runtime's stream-ordered allocator (hipMallocAsync /
+ * hipFreeAsync, default pool set to keep freed memory) -- an allocation call per
+ * array inside every call as upstream, without hipFree's device-wide wait.     */
 void nsparse_set_workspace_cache(int on);
 /* Return every cached device block to the driver. */
 void nsparse_trim_workspace(void);
@@ -312,10 +324,24 @@ int nsparse_load_plan(sfPlan *plan, const char *path);
  *   kind 2: power-law web graph   p0 rows, ~p1 nnz              (webbase class)
  *   kind 3: R-MAT scale p0, edge factor p1 (or exactly p2 edges when p2 > 0, for fractional
  *           factors), duplicates merged                           (config 5)
+ *   kind 4: web graph of 32-page sites, p0 rows, ~p1 nnz: index pages, popular directories,
+ *           template sites -- the SuiteSparse statistics of webbase-1M (config 3)
+ *   kind 5: kind 0 renumbered inside bands of three mesh planes, 7.4 % of the node couplings
+ *           dropped (3 x 3 dof at once): the SuiteSparse statistics of cant, irregular numbering
+ *   kind 6: kind 5 + scalar perturbations: p2 = nz + permille * 2^32; that share of the nodes
+ *           gets one dof constrained (row = diagonal, column gone) or loses one scalar
+ *           coupling, so its rows no longer share one column pattern
  * Rows [row_begin,row_end) only (row_end <= 0: all rows) so that one rank of a
  * row-sharded run can generate just its block.                                  */
 void nsparse_synth_csr(sfCSR *mat, int kind, long long p0, long long p1, long long p2,
                        unsigned long long seed, long long row_begin, long long row_end);
+
+/* *mat (host arrays) as a Matrix Market file in SuiteSparse conventions (1-based coordinate
+ * format, entries sorted by column then row): flavour 0 real general, 1 real symmetric (lower
+ * triangle only; the matrix must be symmetric), 2 pattern general, 3 pattern symmetric.  Values
+ * carry enough digits to read back bit-identical.  0 on success.  Lets the loader and the sample
+ * drivers run at full size on a box without network (the stand-ins as files).                  */
+int nsparse_write_mtx(const sfCSR *mat, const char *path, int flavour);
 
 #ifdef __cplusplus
 }

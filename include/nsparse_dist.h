@@ -1,0 +1,97 @@
+/*
+ * nsparse_dist.h -- row-sharded AMB SpMV across the GPUs of one node, native (C ABI, RCCL).
+ *
+ * The reference is single-GPU; this is the multi-GPU row of the hot path that
+ * BASELINE.json's north_star / SURVEY 8e name: 1-D row blocks balanced by non-zeros, every rank
+ * converts ITS block to AMB against the full x (replicated), computes its part of y with the same
+ * kernel as sf_spmv_amb (reference kernel_spmv_amb.cu:10-104), then ONE ncclAllGather puts the
+ * whole y on every rank.  The shards of y are disjoint: no cross-GPU reduction, the result does
+ * not depend on the rank count.
+ *
+ * libnsparse_dist_{d,s}.so links libnsparse_{d,s}.so and RCCL; the product libraries themselves
+ * stay RCCL-free.  One rank per GPU: one process per GPU (nsparse_dist_init with an id the
+ * caller broadcasts: MPI_Bcast, a file, torch.distributed ...) or one thread per GPU of one
+ * process (nsparse_dist_init_all).  Everything here is plain pointers and sizes.
+ *
+ * Per SpMV on one stream, nothing else: [memset of the local y when the matrix has several
+ * column segments] -> k_spmv_amb_row -> ncclAllGather (in place, recvcount = rows of the longest
+ * block) -> [one copy kernel that closes the gaps when the blocks are unequal].  No host
+ * synchronisation, no allocation, no Python.  nsparse_dist_capture() records that sequence once
+ * into a hipGraph; afterwards a SpMV is one hipGraphLaunch.
+ */
+#ifndef NSPARSE_AMD_NSPARSE_DIST_H
+#define NSPARSE_AMD_NSPARSE_DIST_H
+
+#include "nsparse.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NSPARSE_DIST_ID_BYTES 128 /* sizeof(ncclUniqueId) */
+
+typedef struct nsparse_dist *nsparse_dist_t;
+
+/* ---- partition (host, no device): SURVEY 8e ------------------------------------------------
+ * cuts[0] = 0 <= cuts[1] <= ... <= cuts[world] = M; rank r owns rows [cuts[r], cuts[r+1]).
+ * Rank r ends at the row boundary, rounded to a multiple of `align` rows (the AMB chunk: 64),
+ * where the running non-zero count reaches (r+1)/world of the total.  Blocks may be empty.
+ * Returns 0, or -1 on bad arguments.                                                           */
+int nsparse_dist_partition_nnz(const int *rpt, int M, int world, int align, int *cuts);
+/* Same rule on 64-bit per-row work (SpGEMM: intermediate products per row, what the reference's
+ * set_intprod_num counts, kernel_spgemm_hash_d.cu:70-86).                                      */
+int nsparse_dist_partition_work(const long long *work_per_row, int M, int world, int align, int *cuts);
+/* Rows [begin, end) of a HOST sfCSR as a new host sfCSR over the same columns (malloc'd arrays,
+ * free with release_cpu_csr).                                                                  */
+int nsparse_dist_csr_row_block(const sfCSR *full, int begin, int end, sfCSR *block);
+
+/* ---- communicator --------------------------------------------------------------------------
+ * Rank 0 makes an id, the caller hands it to every rank, every rank calls init with its GPU
+ * current (hipSetDevice before).  Collective.  0 on success, else 2000 + ncclResult_t or a HIP
+ * error code (also in nsparse_dist_last_error()).                                              */
+int nsparse_dist_unique_id(char id[NSPARSE_DIST_ID_BYTES]);
+/* id == NULL: no communicator -- the handle computes its own rows (gather = 0) only; that is how the
+ * tests run the ranks of a partition one after the other on a single GPU.                       */
+int nsparse_dist_init(nsparse_dist_t *h, const char id[NSPARSE_DIST_ID_BYTES], int rank, int world);
+/* One process, `world` GPUs (devices 0 .. world-1), one handle per GPU: ncclCommInitAll.  The
+ * caller then drives handle r from its own thread with device r current.                       */
+int nsparse_dist_init_all(nsparse_dist_t *handles, int world);
+void nsparse_dist_destroy(nsparse_dist_t h);
+
+/* ---- SpMV ----------------------------------------------------------------------------------
+ * a_local: this rank's row block, device arrays valid (csr_memcpy), M = cuts[rank+1] - cuts[rank]
+ * rows, N = columns of the whole matrix.  Converts it to AMB (sf_csr2amb; *plan as there: isPlan
+ * FALSE lets the library choose and writes the choice back).  cuts: the world+1 row cuts, equal
+ * on every rank.  d_x_any: device vector of N + MAX_BLOCK_SIZE elements for the plan search.     */
+int nsparse_dist_spmv_setup(nsparse_dist_t h, sfCSR *a_local, const int *cuts, real *d_x_any, sfPlan *plan);
+/* Elements the caller must allocate for the gathered y: world * (rows of the longest block),
+ * at least M.  (The all-gather is in place with equal shares.)                                  */
+long long nsparse_dist_y_elems(nsparse_dist_t h);
+/* y[0, M) = A x on every rank.  Asynchronous on the handle's stream.  gather = 0: only this
+ * rank's rows, at d_y + cuts[rank] (compute-only timing).                                       */
+int nsparse_dist_spmv(nsparse_dist_t h, real *d_y, const real *d_x, int gather);
+/* Record the sequence for (d_y, d_x, gather) into a hipGraph; later nsparse_dist_spmv calls with
+ * the same three arguments replay it with one hipGraphLaunch.  0, or an error (plain launches
+ * keep working).                                                                                */
+int nsparse_dist_capture(nsparse_dist_t h, real *d_y, const real *d_x, int gather);
+int nsparse_dist_sync(nsparse_dist_t h);
+/* The gap-closing step by itself (unequal blocks are gathered in equal shares of `rpr` elements):
+ * y[cuts[r] + i] = staged[r * rpr + i].  d_cuts: world + 1 ints on the device.  Exposed so that
+ * the step can be checked on one GPU.                                                           */
+int nsparse_dist_close_gaps(real *d_y, const real *d_staged, const int *d_cuts, int world, int rpr, int M, void *stream);
+/* `iters` back-to-back SpMVs from a native loop: *ms_wall = host clock from the first enqueue to
+ * the end of the last one (per SpMV), *ms_events = the same by HIP events on the handle's
+ * stream, *us_host = host time per SpMV spent enqueueing (no wait included).  Any may be NULL. */
+int nsparse_dist_spmv_loop(nsparse_dist_t h, real *d_y, const real *d_x, int gather, int iters,
+                           double *ms_wall, double *ms_events, double *us_host);
+/* The rank's AMB matrix and plan (footprint model, tests); owned by the handle.                 */
+const sfAMB *nsparse_dist_amb(nsparse_dist_t h);
+const sfPlan *nsparse_dist_plan(nsparse_dist_t h);
+void *nsparse_dist_stream(nsparse_dist_t h); /* hipStream_t */
+
+int nsparse_dist_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

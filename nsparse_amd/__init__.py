@@ -4,4 +4,5 @@ The product is the C-ABI library (include/nsparse.h -> nsparse_amd/lib/libnspars
 sources in nsparse_amd/csrc/).  This Python package only holds the ctypes binding used by the
 tests and the bench harness, and the row-sharded multi-GPU driver.
 """
-from .capi import load, load_vendor, Lib, VendorLib, sfCSR, sfAMB, sfPlan, SpgemmStats, SIGNATURES, VENDOR_SIGNATURES  # noqa: F401
+from .capi import (load, load_vendor, load_dist, Lib, VendorLib, DistLib, sfCSR, sfAMB, sfPlan, SpgemmStats,  # noqa: F401
+                   SIGNATURES, VENDOR_SIGNATURES, DIST_SIGNATURES, DIST_ID_BYTES)

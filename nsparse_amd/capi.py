@@ -83,6 +83,7 @@ SIGNATURES = {
     "nsparse_get_spgemm_stats": (None, [_P(SpgemmStats)]),
     "nsparse_spgemm_set_sorted": (C.c_int, [C.c_int]),
     "nsparse_get_spgemm_bins": (None, [c_int_p, c_int_p]),
+    "nsparse_fused_state": (C.c_int, [c_int_p, c_int_p]),
     "nsparse_set_profiling": (None, [C.c_int]),
     "nsparse_set_bin_timing": (C.c_int, [C.c_int]),
     "nsparse_set_workspace_cache": (None, [C.c_int]),
@@ -93,6 +94,7 @@ SIGNATURES = {
     "nsparse_load_csr_bin": (C.c_int, [_P(sfCSR), C.c_char_p]),
     "nsparse_save_plan": (C.c_int, [_P(sfPlan), C.c_char_p]),
     "nsparse_load_plan": (C.c_int, [_P(sfPlan), C.c_char_p]),
+    "nsparse_write_mtx": (C.c_int, [_P(sfCSR), C.c_char_p, C.c_int]),
     "nsparse_synth_csr": (None, [_P(sfCSR), C.c_int, C.c_longlong, C.c_longlong, C.c_longlong,
                                  C.c_ulonglong, C.c_longlong, C.c_longlong]),
 }
@@ -106,8 +108,34 @@ VENDOR_SIGNATURES = {
     "nsparse_vendor_last_error": (C.c_int, []),
 }
 
+# every entry point declared in include/nsparse_dist.h (libnsparse_dist_{d,s}.so: row-sharded SpMV over RCCL)
+c_double_p = C.POINTER(C.c_double)
+DIST_SIGNATURES = {
+    "nsparse_dist_partition_nnz": (C.c_int, [c_int_p, C.c_int, C.c_int, C.c_int, c_int_p]),
+    "nsparse_dist_partition_work": (C.c_int, [C.POINTER(C.c_longlong), C.c_int, C.c_int, C.c_int, c_int_p]),
+    "nsparse_dist_csr_row_block": (C.c_int, [_P(sfCSR), C.c_int, C.c_int, _P(sfCSR)]),
+    "nsparse_dist_unique_id": (C.c_int, [C.c_char_p]),
+    "nsparse_dist_init": (C.c_int, [_P(C.c_void_p), C.c_char_p, C.c_int, C.c_int]),
+    "nsparse_dist_init_all": (C.c_int, [_P(C.c_void_p), C.c_int]),
+    "nsparse_dist_destroy": (None, [C.c_void_p]),
+    "nsparse_dist_spmv_setup": (C.c_int, [C.c_void_p, _P(sfCSR), c_int_p, C.c_void_p, _P(sfPlan)]),
+    "nsparse_dist_y_elems": (C.c_longlong, [C.c_void_p]),
+    "nsparse_dist_spmv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "nsparse_dist_capture": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "nsparse_dist_sync": (C.c_int, [C.c_void_p]),
+    "nsparse_dist_close_gaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "nsparse_dist_spmv_loop": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, c_double_p, c_double_p,
+                                         c_double_p]),
+    "nsparse_dist_amb": (_P(sfAMB), [C.c_void_p]),
+    "nsparse_dist_plan": (_P(sfPlan), [C.c_void_p]),
+    "nsparse_dist_stream": (C.c_void_p, [C.c_void_p]),
+    "nsparse_dist_last_error": (C.c_int, []),
+}
+DIST_ID_BYTES = 128
+
 _libs = {}
 _vendor = {}
+_dist = {}
 
 
 class Lib:
@@ -221,6 +249,49 @@ class VendorLib:
             fn.restype = res
             fn.argtypes = args
             setattr(self, name, fn)
+
+
+class DistLib:
+    """libnsparse_dist_{d,s}.so: the native row-sharded multi-GPU SpMV (include/nsparse_dist.h).  It links the
+    product library of the same precision (one instance per process: the loader finds the copy load() mapped)
+    and RCCL."""
+
+    def __init__(self, precision):
+        assert precision in ("d", "s")
+        load(precision)  # the product library first, so that both handles name one mapped object
+        path = os.path.join(LIB_DIR, f"libnsparse_dist_{precision}.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} is missing: build it with `make -C nsparse_amd/csrc dist`")
+        self.precision = precision
+        self.path = path
+        self.dll = C.CDLL(path, mode=C.RTLD_LOCAL)
+        for name, (res, args) in DIST_SIGNATURES.items():
+            fn = getattr(self.dll, name)
+            fn.restype = res
+            fn.argtypes = args
+            setattr(self, name, fn)
+
+    def partition_nnz(self, rpt, world, align=64):
+        rpt = np.ascontiguousarray(rpt, dtype=np.int32)
+        cuts = np.zeros(world + 1, dtype=np.int32)
+        rc = self.nsparse_dist_partition_nnz(rpt.ctypes.data_as(c_int_p), len(rpt) - 1, world, align,
+                                             cuts.ctypes.data_as(c_int_p))
+        assert rc == 0, rc
+        return cuts
+
+    def partition_work(self, work, world, align=1):
+        work = np.ascontiguousarray(work, dtype=np.int64)
+        cuts = np.zeros(world + 1, dtype=np.int32)
+        rc = self.nsparse_dist_partition_work(work.ctypes.data_as(C.POINTER(C.c_longlong)), len(work), world, align,
+                                              cuts.ctypes.data_as(c_int_p))
+        assert rc == 0, rc
+        return cuts
+
+
+def load_dist(precision="d"):
+    if precision not in _dist:
+        _dist[precision] = DistLib(precision)
+    return _dist[precision]
 
 
 def load_vendor(precision="d"):

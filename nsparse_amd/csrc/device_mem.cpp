@@ -16,13 +16,19 @@
 namespace nsp {
 
 namespace {
-constexpr int kMaxDevices = 16;
+constexpr int kMaxDevices = 128;  // an 8-GPU MI300X node in CPX mode exposes 64 devices
 // One cache for the process, one idle list per device: a block goes back to the list of the device
 // it was allocated on, whatever device is current when it is released.  Guarded by its own mutex
 // (csr_memcpy / release_* may be called from any thread).
 struct Cache {
     bool enabled = true;
-    struct Live { size_t bytes; int dev; };
+    // nsparse_set_workspace_cache(2): cache off, blocks from the runtime's stream-ordered allocator
+    // (hipMallocAsync / hipFreeAsync on the null stream, default pool told to keep what is freed) instead of
+    // hipMalloc / hipFree -- still an allocation call per array inside every spgemm_kernel_hash, as in the
+    // reference (spgemm_hash.cu:40-44), but served by the runtime's pool and without hipFree's device-wide wait
+    bool async = false;
+    bool pool_set[kMaxDevices] = {};
+    struct Live { size_t bytes; int dev; bool async; };
     std::unordered_map<void *, Live> live;               // blocks handed out
     std::multimap<size_t, void *> idle[kMaxDevices];     // blocks waiting for reuse
     size_t idle_bytes = 0;
@@ -37,7 +43,12 @@ int current_device()
 {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess) d = 0;
-    return d >= 0 && d < kMaxDevices ? d : 0;
+    if (d < 0 || d >= kMaxDevices) {
+        // never alias a foreign device to context 0 (its streams and scratch live on device 0)
+        set_error(-50, "device id beyond the library's per-device tables (128)", __FILE__, __LINE__);
+        return 0;
+    }
+    return d;
 }
 void trim_locked(Cache &c)
 {
@@ -68,13 +79,28 @@ void *dev_alloc(size_t bytes)
         // accept an idle block up to 25 % (+1 MiB) larger than the request
         if (it != idle.end() && it->first <= want + want / 4 + (1u << 20)) {
             void *p = it->second;
-            c.live[p] = {it->first, dev};
+            c.live[p] = {it->first, dev, false};
             c.idle_bytes -= it->first;
             idle.erase(it);
             return p;
         }
     }
     void *p = nullptr;
+    if (c.async) {
+        if (!c.pool_set[dev]) {
+            hipMemPool_t pool = nullptr;
+            unsigned long long keep = ~0ull;
+            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess)
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            c.pool_set[dev] = true;
+        }
+        if (hipMallocAsync(&p, want, 0) == hipSuccess) {
+            c.live[p] = {want, dev, true};
+            return p;
+        }
+        (void)hipGetLastError();  // no stream-ordered allocator on this runtime: plain hipMalloc below
+        p = nullptr;
+    }
     hipError_t e = hipMalloc(&p, want);
     if (e != hipSuccess && c.enabled && c.idle_bytes > 0) {
         (void)hipGetLastError();
@@ -82,7 +108,7 @@ void *dev_alloc(size_t bytes)
         e = hipMalloc(&p, want);
     }
     NSP_CHECK(e);
-    if (c.enabled) c.live[p] = {want, dev};
+    if (c.enabled) c.live[p] = {want, dev, false};
     return p;
 }
 
@@ -94,6 +120,11 @@ void dev_free(void *p)
         std::lock_guard<std::mutex> lk(c.mu);
         auto it = c.live.find(p);
         if (it != c.live.end()) {
+            if (it->second.async) {
+                c.live.erase(it);
+                NSP_CHECK(hipFreeAsync(p, 0));
+                return;
+            }
             if (c.enabled) {
                 c.idle[it->second.dev].emplace(it->second.bytes, p);
                 c.idle_bytes += it->second.bytes;
@@ -119,6 +150,14 @@ void dev_cache_enable(bool on)
     std::lock_guard<std::mutex> lk(c.mu);
     if (!on) trim_locked(c);
     c.enabled = on;
+    c.async = false;
+}
+
+void dev_cache_async(bool on)
+{
+    Cache &c = cache();
+    std::lock_guard<std::mutex> lk(c.mu);
+    c.async = on;
 }
 
 void dev_cache_trim()
@@ -194,7 +233,11 @@ Context &ctx()
 
 extern "C" {
 
-void nsparse_set_workspace_cache(int on) { nsp::dev_cache_enable(on != 0); }
+void nsparse_set_workspace_cache(int on)
+{
+    nsp::dev_cache_enable(on == 1);
+    if (on == 2) nsp::dev_cache_async(true);
+}
 void nsparse_trim_workspace(void) { nsp::dev_cache_trim(); }
 void nsparse_set_profiling(int on)
 {

@@ -1,0 +1,382 @@
+// dist_spmv.hip -- libnsparse_dist_{d,s}.so: row-sharded AMB SpMV over RCCL (include/nsparse_dist.h).
+//
+// New design (the reference is single-GPU); the algorithm is SURVEY 8e / BASELINE.json north_star:
+// 1-D row blocks cut by non-zeros, x replicated, one ncclAllGather of y per SpMV.  The SpMV kernel is the
+// product library's (nsparse_spmv_amb_async = the launch path of sf_spmv_amb, reference
+// kernel_spmv_amb.cu:10-104); this file adds the partition, the communicator and the per-iteration sequence
+//     [memset y_local] -> k_spmv_amb_row -> ncclAllGather (in place) -> [k_close_gaps]
+// on ONE stream with no host synchronisation, optionally replayed from a hipGraph.
+//
+// xGMI is point to point (7 links per GPU) and a shard of y is small (3.5 MB per rank for the nlpkkt120
+// class at 8 ranks): one collective with the whole shard as the message, nothing to bucket; the collective
+// needs the finished shard, so there is nothing to overlap inside one SpMV either.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "nsparse_dist.h"
+
+namespace {
+
+thread_local int g_err = 0;
+
+inline int fail_hip(hipError_t e, const char *what, int line)
+{
+    g_err = (int)e;
+    fprintf(stderr, "nsparse_dist: HIP error %d (%s) at %s:%d\n", (int)e, hipGetErrorString(e), what, line);
+    return g_err;
+}
+inline int fail_nccl(ncclResult_t r, const char *what, int line)
+{
+    g_err = 2000 + (int)r;
+    fprintf(stderr, "nsparse_dist: RCCL error %d (%s) at %s:%d\n", (int)r, ncclGetErrorString(r), what, line);
+    return g_err;
+}
+#define D_HIP(x)                                                    \
+    do {                                                            \
+        hipError_t e_ = (x);                                        \
+        if (e_ != hipSuccess) return fail_hip(e_, #x, __LINE__);    \
+    } while (0)
+#define D_NCCL(x)                                                   \
+    do {                                                            \
+        ncclResult_t r_ = (x);                                      \
+        if (r_ != ncclSuccess) return fail_nccl(r_, #x, __LINE__);  \
+    } while (0)
+
+constexpr ncclDataType_t kNcclReal = sizeof(real) == 8 ? ncclDouble : ncclFloat;
+
+// Unequal blocks are gathered with equal shares of `rpr` elements (share r holds rows of block r at its
+// start); this closes the gaps: y[cuts[r] + i] = staged[r * rpr + i].  One launch, 16 B per row moved.
+__global__ __launch_bounds__(256) void k_close_gaps(real *__restrict__ y, const real *__restrict__ staged,
+                                                    const int *__restrict__ cuts, int world, int rpr, int M)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= M) return;
+    // the block of row i: world <= 64, a short scan of a cached array
+    int r = 0;
+    while (r + 1 < world && cuts[r + 1] <= i) r++;
+    y[i] = staged[(long long)r * rpr + (i - cuts[r])];
+}
+
+}  // namespace
+
+struct nsparse_dist {
+    int rank = 0, world = 1, device = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    // matrix
+    sfAMB amb;
+    sfPlan plan;
+    bool have_amb = false;
+    std::vector<int> cuts;
+    int *d_cuts = nullptr;
+    int M = 0, rpr = 0, m_local = 0;
+    bool equal_blocks = true;   // cuts[r] == r * rpr for every non-empty block: the gather lands in place
+    real *staged = nullptr;     // world * rpr elements, unequal blocks only
+    // graph
+    hipGraphExec_t gexec = nullptr;
+    hipGraph_t graph = nullptr;
+    real *g_y = nullptr;
+    const real *g_x = nullptr;
+    int g_gather = -1;
+};
+
+namespace {
+
+int enqueue(nsparse_dist *h, real *d_y, const real *d_x, int gather)
+{
+    hipStream_t st = h->stream;
+    const bool direct = h->equal_blocks || !gather || h->world == 1;
+    real *y_loc = direct ? d_y + h->cuts[h->rank] : h->staged + (long long)h->rank * h->rpr;
+    if (h->m_local > 0)
+        nsparse_spmv_amb_async(y_loc, &h->amb, const_cast<real *>(d_x), &h->plan, (void *)st);
+    if (!gather || (h->world == 1 && !h->comm)) return 0;
+    if (!h->comm) return g_err = -4;  // handle made without an id: local rows only
+    real *buf = direct ? d_y : h->staged;
+    D_NCCL(ncclAllGather(buf + (long long)h->rank * h->rpr, buf, (size_t)h->rpr, kNcclReal, h->comm, st));
+    if (!direct) return nsparse_dist_close_gaps(d_y, h->staged, h->d_cuts, h->world, h->rpr, h->M, (void *)st);
+    return 0;
+}
+
+template <typename T>
+int partition(const T *prefix, int M, int world, int align, int *cuts)
+{
+    // prefix[i] = work before row i, prefix[M] = total
+    if (!prefix || !cuts || M < 0 || world < 1 || align < 1) return -1;
+    const double total = (double)prefix[M];
+    cuts[0] = 0;
+    for (int r = 1; r < world; r++) {
+        const double target = total * (double)r / (double)world;  // == python's total * r / world below 2^53
+        int lo = 0, hi = M + 1;  // first i with prefix[i] >= target
+        while (lo < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            if ((double)prefix[mid] < target) lo = mid + 1;
+            else hi = mid;
+        }
+        long long row = (long long)std::nearbyint((double)lo / (double)align) * align;  // half to even, like round()
+        if (row < cuts[r - 1]) row = cuts[r - 1];
+        if (row > M) row = M;
+        cuts[r] = (int)row;
+    }
+    cuts[world] = M;
+    return 0;
+}
+
+int new_handle(nsparse_dist **out, ncclComm_t comm, int rank, int world, int device)
+{
+    nsparse_dist *h = new nsparse_dist();
+    h->rank = rank;
+    h->world = world;
+    h->device = device;
+    h->comm = comm;
+    memset(&h->amb, 0, sizeof(h->amb));
+    memset(&h->plan, 0, sizeof(h->plan));
+    D_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    D_HIP(hipEventCreate(&h->ev[0]));
+    D_HIP(hipEventCreate(&h->ev[1]));
+    *out = h;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nsparse_dist_last_error(void) { return g_err; }
+
+int nsparse_dist_partition_nnz(const int *rpt, int M, int world, int align, int *cuts)
+{
+    return partition(rpt, M, world, align, cuts);
+}
+
+int nsparse_dist_partition_work(const long long *work_per_row, int M, int world, int align, int *cuts)
+{
+    if (!work_per_row || M < 0) return -1;
+    std::vector<long long> prefix((size_t)M + 1);
+    prefix[0] = 0;
+    for (int i = 0; i < M; i++) prefix[i + 1] = prefix[i] + work_per_row[i];
+    return partition(prefix.data(), M, world, align, cuts);
+}
+
+int nsparse_dist_csr_row_block(const sfCSR *full, int begin, int end, sfCSR *block)
+{
+    if (!full || !block || begin < 0 || end < begin || end > full->M) return -1;
+    const int lo = full->rpt[begin], hi = full->rpt[end];
+    const int m = end - begin, nnz = hi - lo;
+    memset(block, 0, sizeof(*block));
+    block->rpt = (int *)malloc(sizeof(int) * ((size_t)m + 1));
+    block->col = (int *)malloc(sizeof(int) * (size_t)(nnz > 0 ? nnz : 1));
+    block->val = (real *)malloc(sizeof(real) * (size_t)(nnz > 0 ? nnz : 1));
+    if (!block->rpt || !block->col || !block->val) return -2;
+    int longest = 0;
+    for (int i = 0; i <= m; i++) block->rpt[i] = full->rpt[begin + i] - lo;
+    for (int i = 0; i < m; i++) longest = block->rpt[i + 1] - block->rpt[i] > longest ? block->rpt[i + 1] - block->rpt[i] : longest;
+    if (nnz > 0) {
+        memcpy(block->col, full->col + lo, sizeof(int) * (size_t)nnz);
+        memcpy(block->val, full->val + lo, sizeof(real) * (size_t)nnz);
+    }
+    block->M = m;
+    block->N = full->N;
+    block->nnz = nnz;
+    block->nnz_max = longest;
+    block->matrix_name = full->matrix_name;
+    return 0;
+}
+
+int nsparse_dist_unique_id(char id[NSPARSE_DIST_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == NSPARSE_DIST_ID_BYTES, "id size");
+    ncclUniqueId u;
+    D_NCCL(ncclGetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return 0;
+}
+
+int nsparse_dist_init(nsparse_dist_t *h, const char id[NSPARSE_DIST_ID_BYTES], int rank, int world)
+{
+    g_err = 0;
+    if (!h || world < 1 || rank < 0 || rank >= world) return g_err = -1;
+    int device = 0;
+    D_HIP(hipGetDevice(&device));
+    ncclComm_t comm = nullptr;
+    if (id) {
+        ncclUniqueId u;
+        memcpy(&u, id, sizeof(u));
+        D_NCCL(ncclCommInitRank(&comm, world, u, rank));
+    }
+    return new_handle(h, comm, rank, world, device);
+}
+
+int nsparse_dist_init_all(nsparse_dist_t *handles, int world)
+{
+    g_err = 0;
+    if (!handles || world < 1) return g_err = -1;
+    std::vector<ncclComm_t> comms((size_t)world, nullptr);
+    if (world > 1) D_NCCL(ncclCommInitAll(comms.data(), world, nullptr));  // devices 0 .. world-1
+    int before = 0;
+    D_HIP(hipGetDevice(&before));
+    for (int r = 0; r < world; r++) {
+        D_HIP(hipSetDevice(r));
+        const int rc = new_handle(&handles[r], comms[r], r, world, r);
+        if (rc) return rc;
+    }
+    D_HIP(hipSetDevice(before));
+    return 0;
+}
+
+void nsparse_dist_destroy(nsparse_dist_t h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->graph) (void)hipGraphDestroy(h->graph);
+    if (h->have_amb) release_amb(h->amb);
+    if (h->staged) (void)hipFree(h->staged);
+    if (h->d_cuts) (void)hipFree(h->d_cuts);
+    if (h->comm) (void)ncclCommDestroy(h->comm);
+    if (h->ev[0]) (void)hipEventDestroy(h->ev[0]);
+    if (h->ev[1]) (void)hipEventDestroy(h->ev[1]);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int nsparse_dist_spmv_setup(nsparse_dist_t h, sfCSR *a_local, const int *cuts, real *d_x_any, sfPlan *plan)
+{
+    g_err = 0;
+    if (!h || !a_local || !cuts || !plan) return g_err = -1;
+    if (h->have_amb) return g_err = -3;  // one matrix per handle
+    h->cuts.assign(cuts, cuts + h->world + 1);
+    h->M = h->cuts[h->world];
+    if (h->cuts[0] != 0) return g_err = -1;
+    int rpr = 1;
+    for (int r = 0; r < h->world; r++) {
+        const int len = h->cuts[r + 1] - h->cuts[r];
+        if (len < 0) return g_err = -1;
+        rpr = len > rpr ? len : rpr;
+    }
+    h->rpr = rpr;
+    h->m_local = h->cuts[h->rank + 1] - h->cuts[h->rank];
+    if (a_local->M != h->m_local) return g_err = -2;
+    h->equal_blocks = true;
+    for (int r = 0; r < h->world; r++)
+        if (h->cuts[r + 1] > h->cuts[r] && (long long)h->cuts[r] != (long long)r * rpr) h->equal_blocks = false;
+    if (h->m_local > 0) {
+        sf_csr2amb(&h->amb, a_local, d_x_any, plan);  // synchronous; takes the product library's API lock
+        if (nsparse_last_error() != 0) return g_err = nsparse_last_error();
+        h->have_amb = true;
+    } else if (plan->isPlan == FALSE) {
+        init_plan(plan);
+    }
+    h->plan = *plan;
+    if (h->world > 1 && !h->equal_blocks) {
+        D_HIP(hipMalloc((void **)&h->staged, sizeof(real) * (size_t)h->world * (size_t)rpr));
+        D_HIP(hipMemset(h->staged, 0, sizeof(real) * (size_t)h->world * (size_t)rpr));
+        D_HIP(hipMalloc((void **)&h->d_cuts, sizeof(int) * ((size_t)h->world + 1)));
+        D_HIP(hipMemcpy(h->d_cuts, h->cuts.data(), sizeof(int) * ((size_t)h->world + 1), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+long long nsparse_dist_y_elems(nsparse_dist_t h)
+{
+    const long long need = (long long)h->world * h->rpr;
+    return need > h->M ? need : h->M;
+}
+
+int nsparse_dist_close_gaps(real *d_y, const real *d_staged, const int *d_cuts, int world, int rpr, int M, void *stream)
+{
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(k_close_gaps, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_y, d_staged, d_cuts,
+                       world, rpr, M);
+    D_HIP(hipGetLastError());
+    return 0;
+}
+
+int nsparse_dist_spmv(nsparse_dist_t h, real *d_y, const real *d_x, int gather)
+{
+    if (h->gexec && d_y == h->g_y && d_x == h->g_x && gather == h->g_gather) {
+        D_HIP(hipGraphLaunch(h->gexec, h->stream));
+        return 0;
+    }
+    return enqueue(h, d_y, d_x, gather);
+}
+
+int nsparse_dist_capture(nsparse_dist_t h, real *d_y, const real *d_x, int gather)
+{
+    g_err = 0;
+    if (h->gexec) {
+        (void)hipGraphExecDestroy(h->gexec);
+        (void)hipGraphDestroy(h->graph);
+        h->gexec = nullptr;
+        h->graph = nullptr;
+    }
+    // warm: first-use allocations of RCCL (channels, proxies) must not fall inside the capture
+    int rc = enqueue(h, d_y, d_x, gather);
+    if (rc) return rc;
+    D_HIP(hipStreamSynchronize(h->stream));
+    D_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    rc = enqueue(h, d_y, d_x, gather);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(h->stream, &g);
+    if (rc) {
+        if (g) (void)hipGraphDestroy(g);
+        return rc;
+    }
+    if (e != hipSuccess) return fail_hip(e, "hipStreamEndCapture", __LINE__);
+    hipGraphExec_t ge = nullptr;
+    e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        return fail_hip(e, "hipGraphInstantiate", __LINE__);
+    }
+    h->graph = g;
+    h->gexec = ge;
+    h->g_y = d_y;
+    h->g_x = d_x;
+    h->g_gather = gather;
+    return 0;
+}
+
+int nsparse_dist_sync(nsparse_dist_t h)
+{
+    D_HIP(hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+int nsparse_dist_spmv_loop(nsparse_dist_t h, real *d_y, const real *d_x, int gather, int iters,
+                           double *ms_wall, double *ms_events, double *us_host)
+{
+    using clk = std::chrono::steady_clock;
+    if (iters < 1) return g_err = -1;
+    D_HIP(hipStreamSynchronize(h->stream));
+    const auto t0 = clk::now();
+    D_HIP(hipEventRecord(h->ev[0], h->stream));
+    for (int i = 0; i < iters; i++) {
+        const int rc = nsparse_dist_spmv(h, d_y, d_x, gather);
+        if (rc) return rc;
+    }
+    D_HIP(hipEventRecord(h->ev[1], h->stream));
+    const auto t1 = clk::now();
+    D_HIP(hipStreamSynchronize(h->stream));
+    const auto t2 = clk::now();
+    float ms = 0;
+    D_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+    if (ms_wall) *ms_wall = std::chrono::duration<double, std::milli>(t2 - t0).count() / iters;
+    if (ms_events) *ms_events = (double)ms / iters;
+    if (us_host) *us_host = std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
+    return 0;
+}
+
+const sfAMB *nsparse_dist_amb(nsparse_dist_t h) { return &h->amb; }
+const sfPlan *nsparse_dist_plan(nsparse_dist_t h) { return &h->plan; }
+void *nsparse_dist_stream(nsparse_dist_t h) { return (void *)h->stream; }
+
+}  // extern "C"

@@ -35,6 +35,7 @@ void clear_error();
 void *dev_alloc(size_t bytes);
 void dev_free(void *p);
 void dev_cache_enable(bool on);
+void dev_cache_async(bool on);
 bool dev_cache_enabled();
 void dev_cache_trim();
 
@@ -63,7 +64,10 @@ struct Context {
     int *h_mapped = nullptr;            // 256 ints of mapped, coherent host memory (GPU writes, host polls)
     int *d_mapped = nullptr;            // device address of h_mapped
     int seq = 0;                        // publish sequence number
-    int num_cus = 0;                    // compute units of the device (grid barriers need every workgroup resident)
+    int num_cus = 0;                    // compute units of the device
+    int coresident = -1;                // 1024-thread workgroups resident together as this process sees the device
+                                        // (census on first use: CU masks, partitions); grid barriers need every one resident
+    bool fused_ok = true;               // false once a grid barrier has timed out: kernel chains from then on
     bool counters_clean = false;        // the SpGEMM counter blocks of d_scratch were zeroed behind the last call
     bool profiling = false;
     bool bin_timing = false;            // per-bin begin / end events in spgemm_kernel_hash (two API calls per bin)

@@ -99,6 +99,7 @@ struct BinState {
 
 struct Stats {
     nsparse_spgemm_stats s;
+    int fused_fallbacks = 0;  // calls repeated with the kernel chains after a grid barrier timed out
 };
 static Stats g_stats;
 
@@ -391,24 +392,115 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
     }
 }
 
+__device__ __forceinline__ int wave_incl_scan(int v);
+
+// Scratch of the flat walk below: the exclusive prefix of the chunk counts of one batch of A entries.
+template <int BS>
+struct FlatScratch {
+    int pref[BS];
+    int wsum[BS / 64];
+};
+
+// FLAT walk for rows whose B rows differ wildly in length (power-law inputs: hundreds of B rows of two or
+// three entries and a few of hundreds or thousands).  Whatever group width the group walk picks, such a row
+// is bound by its longest B row walked one chunk per round trip, or -- with the long rows parked for a pass of
+// the whole workgroup, the round-2 form -- by one dependent round trip PER PARKED ROW (R-MAT-22, 8192-slot
+// numeric bin: 36 of the 58 us of a row were this walk).  Here the products of a batch of BS entries of A are
+// ONE sequence of V-element chunks: every thread parks one A entry and its B extent, a workgroup scan of the
+// chunk counts gives every chunk its owner (binary search in LDS), thread t takes chunks t, t + BS, ... and
+// requests U of them before it consumes the first.  Three dependent round trips per batch (A entry -> B
+// extent -> B entries) whatever the lengths, and every lane busy.  Must be called by every thread.
+template <int BS, bool WITH_VAL, typename F>
+__device__ __forceinline__ void walk_products_flat(const int *__restrict__ acol, const real *__restrict__ aval,
+                                                   const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                   const real *__restrict__ bval, int bnnz, int a_beg, int a_end,
+                                                   int2 *s_ext, real *s_av, FlatScratch<BS> *fs, F &&consume)
+{
+    constexpr int V = VW, NW = BS / 64, U = 4;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int b0 = a_beg; b0 < a_end; b0 += BS) {
+        const int nb = a_end - b0 < BS ? a_end - b0 : BS;
+        int2 e = make_int2(0, 0);
+        real av = 0;
+        if ((int)threadIdx.x < nb) {
+            const int j = b0 + threadIdx.x;
+            const int c = __builtin_nontemporal_load(acol + j);
+            if (WITH_VAL) av = __builtin_nontemporal_load(aval + j);
+            struct __attribute__((aligned(4))) I2 {
+                int b, e;
+            };
+            const I2 r = *reinterpret_cast<const I2 *>(brpt + c);
+            e.x = r.b;
+            e.y = r.e;
+        }
+        const int nch = (e.y - e.x + V - 1) / V;
+        s_ext[threadIdx.x] = e;
+        if (WITH_VAL) s_av[threadIdx.x] = av;
+        const int incl = wave_incl_scan(nch);
+        if (lane == 63) fs->wsum[w] = incl;
+        __syncthreads();
+        int base = 0, total = 0;
+#pragma unroll
+        for (int u = 0; u < NW; u++) {
+            const int c = fs->wsum[u];
+            base += u < w ? c : 0;
+            total += c;
+        }
+        fs->pref[threadIdx.x] = base + incl - nch;
+        __syncthreads();
+        for (int c0 = threadIdx.x; c0 < total; c0 += BS * U) {
+            IVecT<V> pk[U];
+            RVecT<WITH_VAL ? V : 1> pv[U];
+            int pn[U];
+            real sc[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const int c = c0 + u * BS;
+                pn[u] = 0;
+                sc[u] = 0;
+                if (c < total) {
+                    int i = 0;  // the last entry whose first chunk is not beyond c
+#pragma unroll
+                    for (int step = BS / 2; step >= 1; step >>= 1) {
+                        const int j = i + step;
+                        if (j < nb && fs->pref[j] <= c) i = j;
+                    }
+                    const int2 x = s_ext[i];
+                    if (WITH_VAL) sc[u] = s_av[i];
+                    pn[u] = fetch_chunk<WITH_VAL, V>(bcol, bval, x.x + (c - fs->pref[i]) * V, x.y, bnnz, pk[u], pv[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (pn[u] > 0) consume(pk[u], pv[u], pn[u], sc[u]);
+        }
+        __syncthreads();  // the next batch overwrites the parked entries
+    }
+}
+
 // Rows of power-law matrices mix hundreds of B rows of two or three entries with one or two of
 // hundreds: whatever single group width is chosen, either the short rows pad 64 lanes or the long
 // row is walked 4 entries at a time by a narrow group (webbase class: 59 such rows held the whole
-// symbolic phase for 0.26 ms).  Here the width is chosen for the rows without the longest one,
-// B rows more than 8 steps long are parked in LDS, and after the group walk the whole workgroup
-// strides over each parked row.  Must be called by every thread of the workgroup; dl->n zeroed and
-// visible (barrier) beforehand.
+// symbolic phase for 0.26 ms).  Round 2: the width chosen for the rows without the longest one, B rows more
+// than 8 steps long parked in LDS and walked by the whole workgroup afterwards, one after the other.  Round 3:
+// such rows take the flat walk above (NSPARSE_FLAT=0 keeps the parked-rows form).  Must be called by every
+// thread of the workgroup; dl->n zeroed and visible (barrier) beforehand.
 template <int BS, bool WITH_VAL, typename F, int DCAP>
 __device__ __forceinline__ void walk_products_mixed(const int *__restrict__ acol, const real *__restrict__ aval,
                                                     const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                     const real *__restrict__ bval, int bnnz, int a_beg,
                                                     int a_end, int np, int maxb, int2 *s_ext, real *s_av,
-                                                    DeferList<WITH_VAL, DCAP> *dl, F &&consume)
+                                                    DeferList<WITH_VAL, DCAP> *dl, F &&consume,
+                                                    FlatScratch<BS> *fs = nullptr, bool flat_always = false)
 {
     const int alen = a_end - a_beg;
     // longest row > 8 x the average (workgroup-uniform): width for the others, the long ones parked
     const bool mixed = alen > 1 && (long long)maxb * alen > 8LL * np;
     constexpr int V = VW;
+    if ((mixed || flat_always) && fs != nullptr) {
+        walk_products_flat<BS, WITH_VAL, F &>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, s_ext, s_av, fs, consume);
+        return;
+    }
     const int g = group_width(mixed ? np - maxb : np, mixed ? alen - 1 : alen, BS, mixed ? 0 : maxb, V);  // once
     walk_products<BS, WITH_VAL, V, F &, DCAP>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, g, s_ext, s_av, consume,
                                               mixed ? dl : (DeferList<WITH_VAL, DCAP> *)nullptr, 8 * g * V);

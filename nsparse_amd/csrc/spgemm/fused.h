@@ -27,11 +27,12 @@ namespace spgemm {
 constexpr int kFusedMaxBlocks = 256;
 
 struct FusedSync {
-    int *arrive;    // grid barrier counter (zeroed by the per-call fill)
+    int *arrive;    // [0] grid barrier counter, [1] "a workgroup gave up" (both zeroed by the per-call fill)
     int *blk;       // per workgroup: [0] scan carry, [1 + q] rows it lists in bin q   (kFusedRec ints)
     int *pub_dst;   // mapped host copy of the counter block
     int *pub_flag;  // sequence flag the host polls
     int seq;
+    int *fail_flag; // mapped host word: = seq when the barrier timed out (the host then repeats the call unfused)
 };
 constexpr int kFusedRec = NB + 1;
 
@@ -40,20 +41,58 @@ __device__ __forceinline__ int ld_agent(const int *p)
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// every workgroup of the grid has arrived `round` times
-__device__ __forceinline__ void grid_barrier(int *ctr, int round)
+// Every workgroup of the grid has arrived.  The launch is an ordinary one, so that all workgroups are resident
+// at once is something the HOST has made sure of (Context::coresident: a census at context creation with this
+// block size, under whatever CU mask or partition the process runs in) -- but CUs can still be taken by another
+// tenant between the census and the call.  So the wait is bounded (~50 ms): a workgroup that gives up raises
+// fail_flag AND the publish flag, every workgroup (also one that only starts later) leaves without touching
+// anything behind the barrier, and the host repeats the call with the kernel chains (round 2 trapped here,
+// which poisons the process's HIP context).  Returns false when the barrier failed.
+__device__ __forceinline__ bool grid_barrier(const FusedSync &fs, int *s_ok)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const int target = round * (int)gridDim.x;
-        // (a workgroup that never arrives -- some tenant holding the CUs for good -- must not become a silent
-        //  hang: after some seconds of polling the kernel aborts and the host sees a launch failure)
+        __hip_atomic_fetch_add(fs.arrive, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const int target = (int)gridDim.x;
         unsigned int spins = 0;
-        while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        bool ok = true;
+        while (__hip_atomic_load(fs.arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 23)) __builtin_trap();
+            if (++spins > (1u << 20) || __hip_atomic_load(fs.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                ok = false;
+                break;
+            }
         }
+        if (ok && __hip_atomic_load(fs.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = false;
+        if (!ok) {
+            __hip_atomic_store(fs.arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(fs.fail_flag, fs.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();
+            __hip_atomic_store(fs.pub_flag, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        *s_ok = ok ? 1 : 0;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+// Census for the grid barrier: `grid` workgroups of 1024 threads; every one waits (bounded: ~0.2 ms) until all
+// have arrived and reports whether it saw that happen.  out[0] counts arrivals, out[1] the workgroups that
+// timed out: 0 means `grid` such workgroups are resident together on this device as this process sees it.
+__global__ __launch_bounds__(1024) void k_census(int *out, int limit_ticks)
+{
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(out, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = wall_clock64();
+        bool ok = true;
+        while (__hip_atomic_load(out, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (int)gridDim.x) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > (unsigned long long)limit_ticks) {
+                ok = false;
+                break;
+            }
+        }
+        if (!ok) __hip_atomic_fetch_add(out + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
 }
@@ -160,7 +199,7 @@ __global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict
     // desc != nullptr: a record per row listed in a window bin, in list order, for k_sym_dense (window.h):
     // {row, lo, span, longest B row | first A entry, end of the A row, products, bitmap offset | bitmap words}
     __shared__ unsigned long long s_acc[kPartialStride];
-    __shared__ int s_max, s_alen;
+    __shared__ int s_max, s_alen, s_ok;
     __shared__ int s_cnt[NB], s_base[NB], s_span[NB], s_w[16], s_pref[kFusedRec], s_h[NB];
     if (threadIdx.x < kPartialStride) s_acc[threadIdx.x] = 0;
     if (threadIdx.x < NB) s_cnt[threadIdx.x] = s_span[threadIdx.x] = 0;
@@ -217,7 +256,7 @@ __global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict
         if (s_alen) atomicMax((unsigned long long *)&bs->max_alen, (unsigned long long)s_alen);
         __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    grid_barrier(fs.arrive, 1);
+    if (!grid_barrier(fs, &s_ok)) return;
     const int pos = fused_tail(i, M, excl, bm_words ? bm_off : nullptr, bin, listed, rank, s_base, s_pref, s_h, bs,
                                perm, fs, false);
     if (desc && pos >= 0 && bin >= kDenseBin0) {
@@ -245,7 +284,7 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
     // (block.h): {row, lo, span, longest B row | bitmap offset, first A entry, A entries, rows in the group |
     // member rows}
     __shared__ int s_hist[NB], s_cnt[NB], s_base[NB], s_span[NB], s_w[16], s_pref[kFusedRec], s_h[NB];
-    __shared__ int s_max, s_far;
+    __shared__ int s_max, s_far, s_ok;
     __shared__ unsigned long long s_sum;
     if (threadIdx.x < NB) s_hist[threadIdx.x] = s_cnt[threadIdx.x] = s_span[threadIdx.x] = 0;
     if (threadIdx.x == 0) {
@@ -344,7 +383,7 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
         if (s_far) atomicAdd(&bs->far_twins, s_far);
         __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    grid_barrier(fs.arrive, 1);
+    if (!grid_barrier(fs, &s_ok)) return;
     const int pos = fused_tail(i, M, excl, crpt, bin, listed, rank, s_base, s_pref, s_h, bs, perm, fs, true);
     if (desc && pos >= 0 && bin >= kDenseBin0) {
         desc[3 * pos] = d0;

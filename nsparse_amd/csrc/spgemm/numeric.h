@@ -277,8 +277,24 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
                                                const int *__restrict__ row_perm,
                                                const int *__restrict__ row_prod,
                                                   const int *__restrict__ row_maxb, int bin_off,
-                                               int bin_size, int bnnz, int write_col)
+                                               int bin_size, int bnnz, int write_col,
+                                               unsigned long long *prof = nullptr)
 {
+    // prof (a build with -DNSPARSE_TB_PROF_BUILD and NSPARSE_TB_PROF=1; compiled out otherwise: the pointer and
+    // the clock cost three scalar registers, and with them the 256-thread bin loses a wavefront per SIMD),
+    // 100 MHz ticks of thread 0: 0 row record + clear, 1 walk, 2 compaction, 3 sort, 4 read-out; 5 rows
+#ifdef NSPARSE_TB_PROF_BUILD
+    unsigned long long tk = prof ? wall_clock64() : 0;
+    auto tick = [&](int phase) {
+        if (prof && threadIdx.x == 0) {
+            const unsigned long long now = wall_clock64();
+            atomicAdd(prof + phase, now - tk);
+            tk = now;
+        }
+    };
+#else
+    auto tick = [](int) {};
+#endif
     __shared__ __attribute__((aligned(16))) acc_t vals[TMAX];
     __shared__ __attribute__((aligned(16))) int keys[TMAX];
     // the scratch of the product walk and the sort buffer are never alive together: one block of LDS for
@@ -287,7 +303,11 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
         int2 ext[BS];
         real av[BS];
         DeferList<true, (PMAX / 16 > 32 ? PMAX / 16 : 32)> defer;
+        FlatScratch<(BS >= 512 ? BS : 64)> flat;
     };
+    // write_col bit 2: NSPARSE_FLAT=0.  The flat walk keeps U chunks in flight per lane (26 more registers): only where the LDS of a row bounds
+    // the occupancy anyway, not in the one-wavefront-per-row bins that live on rows in flight
+    constexpr bool FLAT = BS >= 512;
     union Overlay {
         WalkScratch w;
         int srt[PMAX];
@@ -316,6 +336,7 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
         s_defer.n = 0;
     }
     __syncthreads();
+    tick(0);
 
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
     walk_products_mixed<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, row_prod[rid], row_maxb[rid],
@@ -327,8 +348,10 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
 #pragma unroll
                                       for (int i = 0; i < VW; i++)
                                           if (i < n) unsafeAtomicAdd(vals + h[i], (acc_t)(sc * v.v[i]));
-                                  });
+                                  }, (FLAT && !(write_col & 4)) ? reinterpret_cast<FlatScratch<BS> *>(&s_ov.w.flat) : (FlatScratch<BS> *)nullptr,
+                                  (write_col & 8) != 0);
     __syncthreads();
+    tick(1);
 
     // compaction: ballot + popcount inside the wave, one LDS atomic per 64 slots
     const int lane = threadIdx.x & 63;
@@ -346,9 +369,11 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     const int P = pow2_ceil(n);
     for (int i = n + threadIdx.x; i < P; i += BS) srt[i] = 0x7fffffff;
     __syncthreads();
+    tick(2);
     // write_col bit 1: unsorted output requested (cuda-cpp template<bool sort>,
     // HashSpGEMM_volta.hpp:585-604): columns leave in compaction order
     if (P > 1 && !(write_col & 2)) bitonic_sort_lds<BS>(srt, P);
+    tick(3);
 
     for (int i = threadIdx.x; i < n; i += BS) {
         const int key = srt[i];
@@ -357,6 +382,10 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
         if (write_col & 1) ccol[off + i] = key;
         cval[off + i] = (real)vals[h];
     }
+    tick(4);
+#ifdef NSPARSE_TB_PROF_BUILD
+    if (prof && threadIdx.x == 0) atomicAdd(prof + 5, 1ull);
+#endif
 }
 
 // bin 5: persistent workgroups, private (keys, values) slices of global slabs; the row is

@@ -390,12 +390,15 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             row_lo[row] = hi >= lo ? lo : 0;
             row_span[row] = span;
             row_maxb[row] = mb;
+            bin = leader < 0 ? bin_of(ni, span, thr, ni) : -1;
             // words of the column bitmap the symbolic dense kernel hands to the numeric one (twins share
-            // their leader's and stay out of the symbolic bins)
-            const int bw = (leader < 0 && span > 0 && span <= bm_span_max) ? (span + 31) >> 5 : 0;
+            // their leader's and stay out of the symbolic bins).  Only k_sym_dense (bins 6-8) writes one, so
+            // only its rows reserve one: a row with a window of up to bm_span_max = 65536 columns that hashes
+            // (A^2 of a 7-point stencil on 64^3: 2 KB per row, 0.5 GB never written) reserves nothing
+            const bool dense_row = bin >= kDenseBin0 && bin < kDenseBin0 + 3;
+            const int bw = (dense_row && span > 0 && span <= bm_span_max) ? (span + 31) >> 5 : 0;
             bm_words[row] = bw;
             row_span_num[row] = 0;  // set by k_sym_dense when it hands a bitmap over
-            bin = leader < 0 ? bin_of(ni, span, thr, ni) : -1;
             const int al = arpt[row + 1] - arpt[row];
             if (W >= 16) {  // at most 4 rows per wave: direct LDS atomics are cheapest
                 if (bin >= 0) atomicAdd(&s_hist[bin], 1);

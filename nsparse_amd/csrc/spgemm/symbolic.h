@@ -93,11 +93,12 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                                const int *__restrict__ row_prod,
                                                   const int *__restrict__ row_maxb,
                                                int *__restrict__ row_nz, int bin_off, int bin_size,
-                                               int bnnz, BinState *bs, int *__restrict__ fail_list)
+                                               int bnnz, BinState *bs, int *__restrict__ fail_list, int flat_on = 1)
 {
     __shared__ __attribute__((aligned(16))) int tab[TMAX];
     __shared__ int2 s_ext[LARGE ? 1 : BS];
     __shared__ DeferList<false, (LARGE ? 32 : (TMAX / 32 > 32 ? TMAX / 32 : 32))> s_defer;
+    __shared__ FlatScratch<LARGE ? 64 : BS> s_flat;
     __shared__ int s_nz;
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
@@ -128,7 +129,8 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                            int h[VW];
                                            if (COOP) ht_insert_vec_coop(tab, mask, k, n, h, cnt, COOP);
                                            else ht_insert_vec(tab, mask, k, n, h, cnt);
-                                       });
+                                       }, (TMAX >= 8192 && flat_on) ? reinterpret_cast<FlatScratch<BS> *>(&s_flat) : (FlatScratch<BS> *)nullptr,
+                                       flat_on == 2);
     } else {
         // try-in-LDS: plain walk with early exit once the table holds kSymLargeLimit keys
         const int ngroups = BS / g;

@@ -100,6 +100,12 @@ static const Thr &num_ladder()
 // NSPARSE_COOP=1 / 2: wave-cooperative probing in the LDS hash bins (common.h: ht_insert_vec_coop), the
 // alternative BASELINE's north_star names; 0 (default): one lane per key.  Measured in DESIGN 4.1.
 static const int g_coop = getenv("NSPARSE_COOP") ? atoi(getenv("NSPARSE_COOP")) : 0;
+// The flat product walk (common.h: walk_products_flat) in the big-table hash bins (numeric 3 / 4, symbolic 3 / 4).
+// 2 (default): every row of those bins; 1: only rows whose longest B row is more than 8x their average (the
+// round-2 criterion for parking long rows); 0: the round-2 walk (group walk + parked long rows).  R-MAT-22
+// 86.5 / 86.3 / 72.8 ms for 0 / 1 / 2 -- its rows are all hubs, so their AVERAGE B row is long as well --
+// webbase-1M class 2.71 / 2.46 / 2.42.
+static const int g_flat = getenv("NSPARSE_FLAT") ? atoi(getenv("NSPARSE_FLAT")) : 2;
 
 static void *scan_exclusive(const int *in, int *out, int n, hipStream_t st)
 {
@@ -347,7 +353,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
 #define NSP_SYM_TB_GO(BS, TMAX, COOPX)                                                          \
     hipLaunchKernelGGL((k_sym_tb<BS, TMAX, false, COOPX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, \
                        st, arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], \
-                       hist[bin_], b->nnz, d_bs, (int *)nullptr)
+                       hist[bin_], b->nnz, d_bs, (int *)nullptr, g_flat)
 #define NSP_SYM_TB(BIN, BS, TMAX)                                                              \
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
@@ -501,6 +507,14 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
                            (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
     static const int tb_pad = getenv("NSPARSE_TB_PAD") ? atoi(getenv("NSPARSE_TB_PAD")) : 0;  // diagnostics: LDS padding of the numeric hash kernels
+    // NSPARSE_TB_PROF=1: in-kernel phase timers of the hash bins (thread 0 of every workgroup)
+    static const int tb_prof_on = getenv("NSPARSE_TB_PROF") ? atoi(getenv("NSPARSE_TB_PROF")) : 0;
+    unsigned long long *tb_prof = nullptr;
+    if (tb_prof_on) {
+        tb_prof = (unsigned long long *)dev_alloc(8 * NB * sizeof(unsigned long long));
+        NSP_CHECK(hipMemsetAsync(tb_prof, 0, 8 * NB * sizeof(unsigned long long), cx.stream[0]));
+        NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
+    }
     constexpr int kBlkU = 4;  // tasks in flight per lane in the node-block kernel
     // diagnostics: extra dynamic LDS per workgroup = fewer groups in flight per CU (what bounds the kernel?)
     static const int blk_pad = getenv("NSPARSE_BLK_PAD") ? atoi(getenv("NSPARSE_BLK_PAD")) : 0;
@@ -578,7 +592,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
 #define NSP_NUM_TB_GO(BS, TMAX, PMAX, COOPX)                                                    \
     hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX, COOPX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), tb_pad, st, arpt, \
                        acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm,    \
-                       row_prod, row_maxb, off[bin_], hist[bin_], b->nnz, write_col)
+                       row_prod, row_maxb, off[bin_], hist[bin_], b->nnz, write_col | (g_flat ? 0 : 4) | (g_flat == 2 ? 8 : 0), tb_prof ? tb_prof + 8 * bin_ : nullptr)
 #define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
@@ -745,6 +759,19 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         dev_free(kslab);
     }
     L.join();
+    if (tb_prof) {
+        NSP_CHECK(hipDeviceSynchronize());
+        unsigned long long h[8 * NB];
+        NSP_CHECK(hipMemcpy(h, tb_prof, sizeof(h), hipMemcpyDeviceToHost));
+        for (int q = 1; q <= 4; q++) {
+            const unsigned long long *r = h + 8 * q;
+            if (!r[5]) continue;
+            const double us = 0.01 / (double)r[5];
+            fprintf(stderr, "[tb] numeric bin %d rows %llu | us per row: record+clear %.2f walk %.2f compact %.2f sort %.2f read-out %.2f\n",
+                    q, r[5], r[0] * us, r[1] * us, r[2] * us, r[3] * us, r[4] * us);
+        }
+        dev_free(tb_prof);
+    }
     if (blk_prof) {
         NSP_CHECK(hipDeviceSynchronize());
         std::vector<unsigned long long> hb(8 * (size_t)(a->M + 8));
@@ -768,10 +795,29 @@ static inline sfCSR with_checked_hint(const sfCSR *m)
     return r;
 }
 
-static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
+// How many 1024-thread workgroups are resident together on this device as this process sees it (CU masks,
+// partitions, whatever else holds CUs right now): the fused tails put a grid barrier into an ordinary launch and
+// are used only for grids that passed this census.  hipDeviceAttributeMultiprocessorCount knows nothing of
+// HSA_CU_MASK / ROC_GLOBAL_CU_MASK.  One to a few launches of ~10 us, once per context.
+static int census_coresident(Context &cx, hipStream_t st)
 {
-    ApiLock api_lock;
-    clear_error();
+    int *d = cx.d_scratch + 8000;  // two ints behind the workgroup records of the fused tails
+    int grid = cx.num_cus < kFusedMaxBlocks ? cx.num_cus : kFusedMaxBlocks;
+    for (; grid >= 8; grid = grid * 3 / 4) {
+        NSP_CHECK(hipMemsetAsync(d, 0, 2 * sizeof(int), st));
+        hipLaunchKernelGGL(k_census, dim3(grid), dim3(1024), 0, st, d, 20000 /* 0.2 ms of 100 MHz ticks */);
+        NSP_LAUNCH_CHECK();
+        NSP_CHECK(hipMemcpyAsync(cx.h_pinned + 130, d, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+        NSP_CHECK(hipStreamSynchronize(st));
+        if (cx.h_pinned[130] == grid && cx.h_pinned[131] == 0) return grid;
+    }
+    return 0;
+}
+
+// returns true when the call has to be repeated with the kernel chains (a grid barrier of the fused tails
+// timed out: nothing of the call survives, the inputs are untouched)
+static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
+{
     Context &cx = ctx();
     sfCSR a_chk = with_checked_hint(a_in), b_chk = with_checked_hint(b_in);
     const sfCSR *a = &a_chk, *b = &b_chk;
@@ -791,7 +837,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
             NSP_CHECK(hipMemsetAsync(c->d_rpt, 0, sizeof(int) * (size_t)(M0 + 1), cx.stream[0]));
             NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
         }
-        return;
+        return false;
     }
     Timer tm(cx);
     hipStream_t s0 = cx.stream[0];
@@ -941,7 +987,12 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     const int fgrid = ceil_div(M + 1, 1024);
     // (one 1024-thread workgroup per CU at most: the grid barrier needs all of them resident, also on a
     //  partitioned or CU-masked device)
-    const bool fuse = fused_on && !numeric_only && fgrid <= kFusedMaxBlocks && fgrid <= cx.num_cus;
+    // NSPARSE_FUSED_FORCE=1 (tests): skip the census, so that a CU-masked device exercises the time-out path
+    static const bool fused_force = getenv("NSPARSE_FUSED_FORCE") && atoi(getenv("NSPARSE_FUSED_FORCE")) == 1;
+    if (fused_on && !numeric_only && cx.coresident < 0 && fgrid <= kFusedMaxBlocks)
+        cx.coresident = fused_force ? kFusedMaxBlocks : census_coresident(cx, s0);
+    const bool fuse = fused_on && cx.fused_ok && !numeric_only && fgrid <= kFusedMaxBlocks && fgrid <= cx.coresident;
+    bool retry = false, c_rpt_ours = false;
     const int nparts = launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
                         use_bm ? (num_thr.rank_span > num_thr.dense_span[2] ? num_thr.rank_span : num_thr.dense_span[2]) : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, tw, !fuse, s0);
     void *bm_scan_tmp = nullptr;
@@ -952,7 +1003,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         sym_desc = (int4 *)dev_alloc(sizeof(int4) * 3 * (size_t)M);
     if (fuse) {
         const int seq = ++cx.seq;
-        const FusedSync fs = {cx.d_scratch + 244, cx.d_scratch + 512, cx.d_mapped, cx.d_mapped + 120, seq};
+        const FusedSync fs = {cx.d_scratch + 244, cx.d_scratch + 512, cx.d_mapped, cx.d_mapped + 120, seq, cx.d_mapped + 123};
         hipLaunchKernelGGL(k_setup_tail, dim3(fgrid), dim3(1024), 0, s0, (const long long *)partial, nparts, d_sym,
                            use_bm ? (const int *)bm_words : (const int *)nullptr, bm_off, (const int *)row_prod,
                            (const int *)row_span, M, sym_thr, row_perm, (const unsigned char *)twin, fs, sym_desc,
@@ -969,6 +1020,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
             NSP_LAUNCH_CHECK();
         }
         wait_published(120, seq, s0);
+        retry = __atomic_load_n(cx.h_mapped + 123, __ATOMIC_ACQUIRE) == seq;
     } else {
     if (use_bm) bm_scan_tmp = scan_exclusive(bm_words, bm_off, M + 1, s0);
     if (!numeric_only) {
@@ -990,6 +1042,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         wait_published(120, seq, s0);
     }
     }
+    if (!retry) {
     S.n_prod = h_sym->total;
     S.max_prod_row = h_sym->maxv;
     for (int q = 0; q < NB; q++) S.sym_bin_size[q] = h_sym->hist[q];
@@ -1030,6 +1083,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
             }
         }
         c->d_rpt = (int *)dev_alloc(sizeof(int) * (size_t)(M + 1));
+        c_rpt_ours = true;
         if (!fuse) scan_tmp = scan_exclusive(row_nz, c->d_rpt, M + 1, s0);
     } else {
         // structure given: row_nz[i] = rpt[i+1] - rpt[i] is recovered inside the kernels
@@ -1049,7 +1103,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         // twins' results, groups, C.rpt, histogram, permutation and the publish in one launch (fused.h)
         const int seq = ++cx.seq;
         const FusedSync fs = {cx.d_scratch + 246, cx.d_scratch + 512 + kFusedMaxBlocks * kFusedRec,
-                              reinterpret_cast<int *>(h_num_dev), cx.d_mapped + 121, seq};
+                              reinterpret_cast<int *>(h_num_dev), cx.d_mapped + 121, seq, cx.d_mapped + 123};
         hipLaunchKernelGGL(k_numeric_setup, dim3(fgrid), dim3(1024), 0, s0,
                            S.twin_rows > 0 ? (const int *)twin_of : (const int *)nullptr, (const int *)members, row_nz,
                            row_span_num, bm ? bm_off : (int *)nullptr, (const int *)row_prod, M, num_thr, d_num,
@@ -1057,6 +1111,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                            (const int *)row_maxb);
         NSP_LAUNCH_CHECK();
         wait_published(121, seq, s0);
+        retry = __atomic_load_n(cx.h_mapped + 123, __ATOMIC_ACQUIRE) == seq;
     } else {
     hipLaunchKernelGGL(k_hist, dim3(grid_m < 128 ? grid_m : 128), dim3(1024), 0, s0, row_nz, num_span,
                        (const int *)row_prod, M, num_thr, d_num);
@@ -1075,6 +1130,21 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         wait_published(121, seq, s0);
     }
     }
+    }  // !retry (first barrier)
+    if (retry) {
+        // A grid barrier timed out (CUs taken away since the census): wait for the stragglers of that launch,
+        // drop everything this call has built -- the inputs are untouched -- and let the caller repeat it with
+        // the kernel chains.  From now on this context does not fuse.
+        NSP_CHECK(hipStreamSynchronize(s0));
+        cx.fused_ok = false;
+        sym_used.collect(S.ms_sym_bin);
+        if (c_rpt_ours) {
+            dev_free(c->d_rpt);
+            c->d_rpt = nullptr;
+        }
+        too_big = false;
+        cx.counters_clean = false;  // the next attempt starts from zeroed counter blocks
+    } else {
     for (int q = 0; q < NB; q++) S.num_bin_size[q] = h_num->hist[q];
     S.max_nnz_row = h_num->maxv;
     if (!numeric_only) {
@@ -1125,6 +1195,7 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         c->d_val = nullptr;
         c->nnz = 0;
     }
+    }  // !retry
 
     dev_free(scan_tmp);
     dev_free(bm);
@@ -1142,6 +1213,17 @@ static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         char msg[160];
         snprintf(msg, sizeof(msg), "nnz(C) = %lld does not fit the int row pointers of sfCSR", (long long)S.nnz_c);
         set_error(-40, msg, __FILE__, __LINE__);
+    }
+    return retry;
+}
+
+static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
+{
+    ApiLock api_lock;
+    clear_error();
+    if (run_once(a_in, b_in, c, numeric_only)) {
+        g_stats.fused_fallbacks++;
+        (void)run_once(a_in, b_in, c, numeric_only);  // fused_ok is false now: this one cannot ask again
     }
 }
 
@@ -1171,6 +1253,15 @@ void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out)
 {
     nsp::ApiLock lk;
     *out = nsp::spgemm::g_stats.s;
+}
+
+int nsparse_fused_state(int *coresident, int *fallbacks)
+{
+    nsp::ApiLock lk;
+    nsp::Context &cx = nsp::ctx();
+    if (coresident) *coresident = cx.coresident;
+    if (fallbacks) *fallbacks = nsp::spgemm::g_stats.fused_fallbacks;
+    return cx.fused_ok ? 1 : 0;
 }
 
 int nsparse_spgemm_set_sorted(int on)

@@ -157,10 +157,48 @@ void gen_powerlaw(sfCSR *mat, long long n, long long target_nnz, unsigned long l
 //     which brings nnz and the product count down to the SuiteSparse statistics of cant
 //     (62,451 rows, 4.0 M nnz, ~0.27 G products for 9 x 9 x 257 with drop = 0.074).
 // Values as in kind 0 (symmetric in the ORIGINAL numbering, so the matrix stays symmetric).
+//
+// kind 6 = kind 5 + SCALAR perturbations (`permille` of the nodes, chosen by hash): what boundary conditions
+// and mixed elements do to a real finite-element matrix, and what the all-3x3-at-once drops above leave
+// intact -- the rows of one node keep one column pattern.  A chosen node either gets one of its dof
+// CONSTRAINED (Dirichlet: the row keeps its diagonal only, the column disappears from every other row) or
+// loses ONE scalar coupling (d_a of the node, d_b of one neighbour node; symmetric), so that row no longer
+// has the pattern of its node mates.
+struct Perturb {
+    unsigned long long seed;
+    long long nx, ny, nz;
+    unsigned long long thr;  // 0: off
+    // what happens at `node`: kind 0 nothing, 1 constrained dof `da`, 2 coupling (da, nb:db) dropped
+    struct What { int kind, da, db; long long nb; };
+    What at(long long node) const
+    {
+        What w = {0, 0, 0, -1};
+        if (!thr) return w;
+        const unsigned long long h = mix64(seed ^ mix64(0xC0A5ull + (unsigned long long)node));
+        if (h >= thr) return w;
+        const unsigned long long g = mix64(h);
+        w.da = (int)((g >> 16) % 3);
+        if ((g >> 8) & 1) {
+            w.kind = 1;
+            return w;
+        }
+        const int k = (int)((g >> 20) % 26);
+        const int q = k < 13 ? k : k + 1;  // 0..26 without the centre (13)
+        const long long x = node % nx + (q % 3 - 1), y = (node / nx) % ny + ((q / 3) % 3 - 1), z = node / (nx * ny) + (q / 9 - 1);
+        if (x < 0 || x >= nx || y < 0 || y >= ny || z < 0 || z >= nz) return w;
+        w.kind = 2;
+        w.db = (int)((g >> 28) % 3);
+        w.nb = (z * ny + y) * nx + x;
+        return w;
+    }
+};
+
 void gen_brick_shuffled(sfCSR *mat, long long nx, long long ny, long long nz, unsigned long long seed,
-                        long long rb, long long re)
+                        long long rb, long long re, int permille = 0)
 {
     const int dof = 3;
+    const Perturb pert = {seed, nx, ny, nz,
+                          permille >= 1000 ? ~0ull : (unsigned long long)((double)permille / 1000.0 * 18446744073709551615.0)};
     const long long nodes = nx * ny * nz, Mfull = nodes * dof;
     if (re <= 0 || re > Mfull) re = Mfull;
     if (rb < 0) rb = 0;
@@ -193,6 +231,14 @@ void gen_brick_shuffled(sfCSR *mat, long long nx, long long ny, long long nz, un
         const long long node = r / dof;
         const long long x = node % nx, y = (node / nx) % ny, z = node / (nx * ny);
         row.clear();
+        const int d_row = (int)(r % dof);
+        const Perturb::What mine = pert.at(node);
+        if (mine.kind == 1 && mine.da == d_row) {  // constrained unknown: diagonal only
+            b.col.push_back((int)rn);
+            b.val.push_back(pair_value(seed, r, r));
+            if (b.nnz_max < 1) b.nnz_max = 1;
+            continue;
+        }
         for (long long dz = -1; dz <= 1; dz++) {
             const long long zz = z + dz;
             if (zz < 0 || zz >= nz) continue;
@@ -208,8 +254,12 @@ void gen_brick_shuffled(sfCSR *mat, long long nx, long long ny, long long nz, un
                         if (mix64(seed ^ mix64(0xD40Full + (unsigned long long)lo * 0x100000001B3ull + (unsigned long long)hi)) < drop_thr)
                             continue;
                     }
+                    const Perturb::What theirs = nb == node ? mine : pert.at(nb);
                     for (int d = 0; d < dof; d++) {
                         const long long c = nb * dof + d;
+                        if (theirs.kind == 1 && theirs.da == d) continue;                           // column of a constrained unknown
+                        if (mine.kind == 2 && mine.nb == nb && mine.da == d_row && mine.db == d) continue;      // dropped scalar coupling
+                        if (theirs.kind == 2 && theirs.nb == node && theirs.da == d && theirs.db == d_row) continue;  // ... seen from the other side
                         row.emplace_back(new_of[(size_t)c], pair_value(seed, r, c));
                     }
                 }
@@ -388,8 +438,70 @@ extern "C" void nsparse_synth_csr(sfCSR *mat, int kind, long long p0, long long 
         case 3: gen_rmat(mat, (int)p0, p1, p2, seed, row_begin, row_end); break;
         case 4: gen_webgraph(mat, p0, p1, seed, row_begin, row_end); break;
         case 5: gen_brick_shuffled(mat, p0, p1, p2, seed, row_begin, row_end); break;
+        // kind 6: p2 = nz + (permille of the nodes that get a scalar perturbation) * 2^32
+        case 6: gen_brick_shuffled(mat, p0, p1, p2 & 0xffffffffLL, seed, row_begin, row_end, (int)(p2 >> 32)); break;
         default:
             fprintf(stderr, "nsparse_synth_csr: unknown kind %d\n", kind);
             memset(mat, 0, sizeof(*mat));
     }
+}
+
+// A host CSR written as a Matrix Market file the way the SuiteSparse collection ships its matrices
+// (coordinate format, 1-based, entries sorted by column then row, `symmetric` files holding the lower
+// triangle only), so that the loader (init_csr_matrix_from_file, reference nsparse.cu:14-136) and the sample
+// drivers can be exercised at full size on a box without network.  flavour 0: real general, 1: real
+// symmetric (the matrix must be symmetric: only entries with row >= column are written), 2: pattern
+// general, 3: pattern symmetric.  Values are printed with enough digits to read back bit-identical.
+extern "C" int nsparse_write_mtx(const sfCSR *m, const char *path, int flavour)
+{
+    if (!m || !path || flavour < 0 || flavour > 3) return -1;
+    FILE *f = fopen(path, "w");
+    if (!f) return -2;
+    const bool sym = flavour == 1 || flavour == 3, pat = flavour >= 2;
+    std::vector<char> buf(1 << 22);
+    setvbuf(f, buf.data(), _IOFBF, buf.size());
+    const char *vfmt = sizeof(real) == 8 ? "%d %d %.17g\n" : "%d %d %.9g\n";
+    long long stored = 0;
+    if (sym) {
+        for (int i = 0; i < m->M; i++)
+            for (int j = m->rpt[i]; j < m->rpt[i + 1]; j++) stored += m->col[j] >= i;
+    } else {
+        stored = m->nnz;
+    }
+    fprintf(f, "%%%%MatrixMarket matrix coordinate %s %s\n", pat ? "pattern" : "real", sym ? "symmetric" : "general");
+    fprintf(f, "%%-------------------------------------------------------------------------------\n");
+    fprintf(f, "%% nsparse_write_mtx: stand-in written in SuiteSparse conventions (column-major sorted%s)\n",
+            sym ? ", lower triangle" : "");
+    fprintf(f, "%%-------------------------------------------------------------------------------\n");
+    fprintf(f, "%d %d %lld\n", m->M, m->N, stored);
+    if (sym) {
+        // column c of the lower triangle = the entries (r >= c, c) = by symmetry row c of the CSR from the
+        // diagonal on: rows of the CSR are walked in order, every entry (i, j >= i) leaves as "j i"
+        for (int i = 0; i < m->M; i++)
+            for (int j = m->rpt[i]; j < m->rpt[i + 1]; j++) {
+                if (m->col[j] < i) continue;
+                if (pat) fprintf(f, "%d %d\n", m->col[j] + 1, i + 1);
+                else fprintf(f, vfmt, m->col[j] + 1, i + 1, (double)m->val[j]);
+            }
+    } else {
+        // counting sort by column (stable: rows ascend inside a column)
+        std::vector<long long> start((size_t)m->N + 1, 0);
+        for (int j = 0; j < m->nnz; j++) start[(size_t)m->col[j] + 1]++;
+        for (int c = 0; c < m->N; c++) start[(size_t)c + 1] += start[(size_t)c];
+        std::vector<int> row_of((size_t)m->nnz), src((size_t)m->nnz);
+        for (int i = 0; i < m->M; i++)
+            for (int j = m->rpt[i]; j < m->rpt[i + 1]; j++) {
+                const long long p = start[(size_t)m->col[j]]++;
+                row_of[(size_t)p] = i;
+                src[(size_t)p] = j;
+            }
+        for (long long p = 0; p < m->nnz; p++) {
+            const int j = src[(size_t)p];
+            if (pat) fprintf(f, "%d %d\n", row_of[(size_t)p] + 1, m->col[j] + 1);
+            else fprintf(f, vfmt, row_of[(size_t)p] + 1, m->col[j] + 1, (double)m->val[j]);
+        }
+    }
+    const int rc = ferror(f) ? -3 : 0;
+    fclose(f);
+    return rc;
 }

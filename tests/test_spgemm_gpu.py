@@ -587,3 +587,52 @@ def test_keyed_runs_of_twin_b_rows(prec, lib_d, lib_s, oracle_d, oracle_s):
     assert moved > 100
     got, _ = spgemm(lib, A, B)
     assert_parity(orc, got, orc.spgemm(A, B))
+
+
+_MASK_SCRIPT = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, "tests")
+import numpy as np
+import nsparse_amd as ns
+from gpu_util import spgemm, synth
+lib = ns.load("d")
+A = synth(lib, 0, 9, 9, 800, seed=5)          # 194,400 rows: the fused tails want 190 co-resident workgroups
+got, st = spgemm(lib, A)
+co, fb = C.c_int(), C.c_int()
+ok = lib.nsparse_fused_state(C.byref(co), C.byref(fb))
+np.savez(sys.argv[1], rpt=got["rpt"], col=got["col"], val=got["val"])
+print(json.dumps(dict(coresident=co.value, fallbacks=fb.value, fused_ok=ok, err=lib.nsparse_last_error())))
+"""
+
+
+def test_fused_tails_under_a_cu_mask(tmp_path, oracle_d):
+    """A quarter of the CUs (HSA_CU_MASK): the census behind the fused tails must see fewer co-resident
+    workgroups than the grid barrier of a 194 K-row matrix needs, and the call must take the kernel chains --
+    same C, no trap.  With NSPARSE_FUSED_FORCE=1 (census skipped) the barrier really times out: the call is
+    repeated with the chains, the context stops fusing, the process stays usable."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    lib = ns.load("d")
+    A = synth(lib, 0, 9, 9, 800, seed=5)
+    ref = oracle_d.spgemm_omp(A, A)
+    outs = {}
+    for tag, extra in (("plain", {}), ("mask", {"HSA_CU_MASK": "0:0-31"}),
+                       ("mask_forced", {"HSA_CU_MASK": "0:0-31", "NSPARSE_FUSED_FORCE": "1"})):
+        npz = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", _MASK_SCRIPT, npz], cwd=ROOT, env=dict(os.environ, **extra),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (tag, r.stderr[-1500:])
+        info = json.loads(r.stdout.strip().splitlines()[-1])
+        z = np.load(npz)
+        assert np.array_equal(z["rpt"], ref["rpt"]) and np.array_equal(z["col"], ref["col"]), tag
+        assert oracle_d.check_spgemm(dict(M=A["M"], rpt=z["rpt"], col=z["col"], val=z["val"]), dict(ref, M=A["M"])) == 0
+        assert info["err"] == 0
+        outs[tag] = info
+    print("[cu mask]", outs)
+    assert outs["plain"]["coresident"] >= 190 and outs["plain"]["fallbacks"] == 0 and outs["plain"]["fused_ok"] == 1
+    if outs["mask"]["coresident"] >= 190:
+        pytest.skip("HSA_CU_MASK has no effect on this box: the census sees every CU")
+    assert outs["mask"]["fallbacks"] == 0 and outs["mask"]["fused_ok"] == 1      # chains by the census, no time-out
+    assert outs["mask_forced"]["fallbacks"] == 1 and outs["mask_forced"]["fused_ok"] == 0

@@ -8,6 +8,7 @@ from tools.run_configs import CASES
 prec, kind, p = CASES[sys.argv[1]]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 lib = ns.load(prec); lib.nsparse_set_profiling(int(os.environ.get("NSPARSE_SERIAL", "1"))); lib.nsparse_set_bin_timing(1)
+if os.environ.get("NSPARSE_UNSORTED"): lib.nsparse_spgemm_set_sorted(0)
 A = synth(lib, kind, *p, seed=0x5EED0022)
 a = lib.csr_from_numpy(A["rpt"], A["col"], A["val"], A["N"]); b = lib.csr_from_numpy(A["rpt"], A["col"], A["val"], A["N"])
 lib.csr_memcpy(C.byref(a)); lib.csr_memcpy(C.byref(b)); c = ns.sfCSR(); st = ns.SpgemmStats()
