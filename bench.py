@@ -14,11 +14,15 @@ step     one spgemm_kernel_hash call on this rank's batch.
 
 Workloads (SuiteSparse files cannot be fetched: no network; $NSPARSE_DATA/<name>.mtx is used when
 present, otherwise the deterministic stand-in of the same class, nsparse_synth_csr):
-  N = 1  configs[1]: cant class, fp64, C = A^2 and y = A x.  cant has 62,451 = 3 * 9 * 9 * 257 rows:
-         the stand-in is a 9 x 9 x 257 brick of 3-dof nodes, 27-point coupling (kind 0: 4.33 M nnz,
-         0.313 G products).  "irregular" in the line is the same brick renumbered inside bands with
-         7.4 % of the node couplings dropped (kind 5: 4.02 M nnz, 0.271 G products, 17.3 M nnz(C) --
-         within 1 % of cant's SuiteSparse statistics), through the same protocol.
+  N = 1  configs[1]: cant class, fp64, C = A^2 and y = A x.  cant has 62,451 = 3 * 9 * 9 * 257 rows.
+         `value` is measured on $NSPARSE_DATA/cant.mtx when that file exists, else on the stand-in that
+         matches cant's SuiteSparse STATISTICS within 1 %: a 9 x 9 x 257 brick of 3-dof nodes renumbered
+         inside bands of three mesh planes with 7.4 % of the node couplings dropped (kind 5: 4.02 M nnz,
+         0.271 G products, 17.3 M nnz(C)).  Round 2 put the REGULAR brick (kind 0: natural numbering,
+         16 % more products, every row in the narrowest window bin) there; it is now "regular_brick" in
+         the line, beside the headline.  "structure_sweep" bounds how much of the speed hangs on the
+         node structure: kind 6 = kind 5 with scalar perturbations (a dof constrained / one scalar
+         coupling dropped) on 0 / 10 / 30 / 100 % of the nodes, and the NSPARSE_TWINS=0 floor.
   N > 1  weak scaling by 1-D row partition: the brick is N times longer (9x9x257N),
          rank r owns row block r (62,451 rows) and computes C[rows_r,:] = A[rows_r,:] * A with
          B = A replicated -- no data-path collective.  SpMV: y[rows_r] = A[rows_r,:] x, then ONE
@@ -74,8 +78,8 @@ NUM_KERNEL = {0: ["k_num_small<256, 4, 32"], 1: ["k_num_tb<64, 256, 256"], 2: ["
               9: ["k_num_block<128, 65536, 1"]}
 
 STANDINS = {  # name -> (kind, params, seed)
-    "cant": (0, (9, 9, 257), 0x5EED0022),
-    "cant_irregular": (5, (9, 9, 257), 0x5EED0022),
+    "cant": (5, (9, 9, 257), 0x5EED0022),        # statistics of SuiteSparse cant within 1 % (the headline)
+    "cant_brick": (0, (9, 9, 257), 0x5EED0022),  # regular brick, natural numbering (round 2's headline)
     "nlpkkt120": (1, (160, 164, 135), 0x5EED0044),
 }
 
@@ -231,7 +235,7 @@ def main():
     ap.add_argument("--no-large", action="store_true", help="skip the nlpkkt-class SpMV")
     ap.add_argument("--no-vendor", action="store_true", help="skip the rocSPARSE baseline")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
-    ap.add_argument("--no-irregular", action="store_true", help="skip the irregular cant-class stand-in")
+    ap.add_argument("--no-irregular", action="store_true", help="skip the regular brick and the structure sweep")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -289,7 +293,8 @@ def main():
     rows = (rank * 62451, (rank + 1) * 62451)
     t0 = time.time()
     kind, _, seed = STANDINS["cant"]
-    A_full, src = load_or_synth(lib, "cant", kind, (9, 9, nz), seed)
+    A_full, src = load_or_synth(lib, "cant", kind, (9, 9, nz), seed) if world == 1 else \
+        (synth(lib, kind, 9, 9, nz, seed), "synthetic cant-class")
     A_loc = A_full if world == 1 else csr_row_block(A_full, rows[0], rows[1])
     log(f"[rank {rank}] workload {src}: local {A_loc['M']} x {A_full['N']}, nnz local {int(A_loc['rpt'][-1])}, "
         f"B nnz {int(A_full['rpt'][-1])} ({time.time() - t0:.1f}s)")
@@ -311,8 +316,12 @@ def main():
     # the same loop, allocating inside the call like the reference (block cache off)
     lib.nsparse_set_workspace_cache(0)
     el_ref, _, _, _, _ = spgemm_loop(lib, a, b, args.steps, 1, barrier)
+    # ... and with the runtime's stream-ordered allocator (hipMallocAsync / hipFreeAsync inside the call)
+    lib.nsparse_set_workspace_cache(2)
+    el_async, _, _, _, _ = spgemm_loop(lib, a, b, args.steps, 2, barrier)
     lib.nsparse_set_workspace_cache(1)
     ms_ref = max_over_ranks(el_ref) * 1e3 / args.steps
+    ms_async = max_over_ranks(el_async) * 1e3 / args.steps
 
     # ------------------------------------- roofline pass: per-bin events, separate loop ----
     lib.nsparse_set_bin_timing(1)
@@ -399,10 +408,9 @@ def main():
                 "instruction issue, not by HBM and not by the LDS atomics (ablations in DESIGN 4.1)",
     }
 
-    # ------------------------------------------------ irregular cant-class stand-in ----
-    irregular = None
-    if world == 1 and rank == 0 and not args.no_irregular:
-        kind_i, dims_i, seed_i = STANDINS["cant_irregular"]
+    # ------------------------------ regular brick (round 2's headline) + structure sweep ----
+    def one_matrix(kind_i, dims_i, seed_i, phases=True):
+        """The headline protocol on another matrix: warm loop, allocate-inside loop, phase pass."""
         Ai = synth(lib, kind_i, *dims_i, seed_i)
         ai = lib.csr_from_numpy(Ai["rpt"], Ai["col"], Ai["val"], Ai["N"])
         bi = lib.csr_from_numpy(Ai["rpt"], Ai["col"], Ai["val"], Ai["N"])
@@ -411,33 +419,86 @@ def main():
         fl_i = C.c_longlong()
         lib.get_spgemm_flop(C.byref(ai), C.byref(bi), ai.M, C.byref(fl_i))
         el_i, _, _, _, st_i = spgemm_loop(lib, ai, bi, args.steps, args.warmup, barrier)
-        lib.nsparse_set_workspace_cache(0)
-        el_ir, _, _, _, _ = spgemm_loop(lib, ai, bi, args.steps, 1, barrier)
-        lib.nsparse_set_workspace_cache(1)
-        lib.nsparse_set_bin_timing(1)
-        _, bin_i, sym_i, ph_i, st_i = spgemm_loop(lib, ai, bi, args.steps, 1, barrier, with_stats=True)
-        lib.nsparse_set_bin_timing(0)
         ms_i = el_i * 1e3 / args.steps
-        irregular = {
-            "workload": "synthetic cant-class, irregular: 9x9x257 brick of 3-dof nodes, unknowns renumbered inside "
-                        "729-unknown bands (three mesh planes), 7.4 % of node couplings dropped (nsparse_synth_csr kind 5)",
-            "M": int(Ai["M"]), "nnz_A": int(Ai["rpt"][-1]), "n_prod": int(fl_i.value // 2), "nnz_C": int(st_i.nnz_c),
-            "suitesparse_cant": {"M": 62451, "nnz_A": 4007383, "n_prod": "~269.5 M", "nnz_C": "~17.4 M"},
-            "value": round(fl_i.value / (ms_i * 1e6), 2), "unit": "GFLOPS", "ms_per_step": round(ms_i, 4),
-            "reference_compatible_ms": round(el_ir * 1e3 / args.steps, 4),
-            "reference_compatible_gflops": round(fl_i.value / (el_ir * 1e3 / args.steps * 1e6), 2),
-            "twin_rows": int(st_i.twin_rows),
-            "phase_ms": {"setup": round(float(ph_i[0]), 4), "symbolic": round(float(ph_i[1]), 4),
-                         "numeric": round(float(ph_i[2]), 4)},
-            "numeric_bins_ms": [round(float(v), 4) for v in bin_i[:11]],
-            "symbolic_bins_ms": [round(float(v), 4) for v in sym_i[:11]],
-            "sym_bin_rows": list(st_i.sym_bin_size)[:11], "num_bin_rows": list(st_i.num_bin_size)[:11],
-        }
+        rep = {"M": int(Ai["M"]), "nnz_A": int(Ai["rpt"][-1]), "n_prod": int(fl_i.value // 2), "nnz_C": int(st_i.nnz_c),
+               "value": round(fl_i.value / (ms_i * 1e6), 2), "unit": "GFLOPS", "ms_per_step": round(ms_i, 4),
+               "twin_rows": int(st_i.twin_rows)}
+        if phases:
+            lib.nsparse_set_workspace_cache(0)
+            el_ir, _, _, _, _ = spgemm_loop(lib, ai, bi, args.steps, 1, barrier)
+            lib.nsparse_set_workspace_cache(1)
+            lib.nsparse_set_bin_timing(1)
+            _, bin_i, sym_i, ph_i, st_i = spgemm_loop(lib, ai, bi, args.steps, 1, barrier, with_stats=True)
+            lib.nsparse_set_bin_timing(0)
+            rep.update({
+                "reference_compatible_ms": round(el_ir * 1e3 / args.steps, 4),
+                "reference_compatible_gflops": round(fl_i.value / (el_ir * 1e3 / args.steps * 1e6), 2),
+                "phase_ms": {"setup": round(float(ph_i[0]), 4), "symbolic": round(float(ph_i[1]), 4),
+                             "numeric": round(float(ph_i[2]), 4)},
+                "numeric_bins_ms": [round(float(v), 4) for v in bin_i[:11]],
+                "symbolic_bins_ms": [round(float(v), 4) for v in sym_i[:11]],
+                "sym_bin_rows": list(st_i.sym_bin_size)[:11], "num_bin_rows": list(st_i.num_bin_size)[:11]})
         lib.release_csr(ai)
         lib.release_csr(bi)
-        del Ai
+        return rep
+
+    regular = sweep = None
+    if world == 1 and rank == 0 and not args.no_irregular:
+        kind_b, dims_b, seed_b = STANDINS["cant_brick"]
+        regular = one_matrix(kind_b, dims_b, seed_b)
+        regular["workload"] = ("synthetic cant-class, REGULAR: 9x9x257 brick of 3-dof nodes, natural numbering "
+                               "(nsparse_synth_csr kind 0) -- round 2's headline matrix: every row in the narrowest "
+                               "window bin, twin rows neighbours")
+        regular["suitesparse_cant"] = {"M": 62451, "nnz_A": 4007383, "n_prod": "~269.5 M", "nnz_C": "~17.4 M"}
+        # how much of the speed hangs on rows that share a column pattern (the dof of a mesh node)
+        sweep = {"what": "nsparse_synth_csr kind 6 = the headline stand-in with SCALAR perturbations on a share p of "
+                         "the nodes (one dof constrained: row = diagonal, column gone; or one scalar coupling "
+                         "dropped), which break the node's common column pattern; twins_off = the headline matrix with "
+                         "NSPARSE_TWINS=0 (no twin detection, no node-block kernel: the floor)",
+                 "points": []}
+        for pm in (0, 100, 300, 1000):
+            r6 = one_matrix(6, (9, 9, 257 + (pm << 32)), 0x5EED0022, phases=False)
+            sweep["points"].append({"p": pm / 1000.0, "gflops": r6["value"], "ms": r6["ms_per_step"],
+                                    "twin_rows": r6["twin_rows"], "nnz_A": r6["nnz_A"], "n_prod": r6["n_prod"]})
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "one_gflops.py"), "5", "9", "9", "257",
+                                str(args.steps)], env=dict(os.environ, NSPARSE_TWINS="0"), capture_output=True,
+                               text=True, timeout=300, cwd=ROOT)
+            sweep["twins_off"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception as e:
+            sweep["twins_off"] = {"error": repr(e)[:160]}
 
     # ------------------------------------------------------------------- SpMV ----
+    # Row-sharded AMB SpMV through the NATIVE library (include/nsparse_dist.h, libnsparse_dist_d.so): partition,
+    # conversion, the per-iteration sequence [memset] -> kernel -> ncclAllGather -> [gap closing] and the timed loop
+    # itself are C; torch.distributed only carries the RCCL id to the ranks and provides the barriers around the
+    # loop.  (NSPARSE_BENCH_BACKEND=gloo -- ranks sharing a GPU, which RCCL refuses -- keeps round 2's Python
+    # driver, nsparse_amd/dist.py, as the smoke-test path.)
+    dl = ns.load_dist("d") if backend == "nccl" else None
+
+    def native_handle():
+        idb = C.create_string_buffer(ns.DIST_ID_BYTES)
+        if rank == 0:
+            assert dl.nsparse_dist_unique_id(idb) == 0, "ncclGetUniqueId failed"
+        if world > 1:
+            t = torch.tensor(list(idb.raw), dtype=torch.uint8, device=red_dev)
+            dist.broadcast(t, 0)
+            idb = C.create_string_buffer(bytes(t.cpu().tolist()), ns.DIST_ID_BYTES)
+        h = C.c_void_p()
+        rc = dl.nsparse_dist_init(C.byref(h), idb, rank, world)
+        assert rc == 0, f"nsparse_dist_init -> {rc}"
+        return h
+
+    def native_loop(h, d_y, d_x, gather, steps):
+        assert dl.nsparse_dist_spmv_loop(h, d_y, d_x, gather, 2, None, None, None) == 0  # warm-up
+        mw, me, us = C.c_double(), C.c_double(), C.c_double()
+        barrier()
+        t = time.perf_counter()
+        rc = dl.nsparse_dist_spmv_loop(h, d_y, d_x, gather, steps, C.byref(mw), C.byref(me), C.byref(us))
+        barrier()
+        assert rc == 0, f"nsparse_dist_spmv_loop -> {rc}"
+        return max_over_ranks(time.perf_counter() - t) * 1e3 / steps, max_over_ranks(me.value), max_over_ranks(us.value)
+
     def time_spmv(op, x, steps, gather):
         for _ in range(2):
             op(x, gather=gather)
@@ -453,23 +514,65 @@ def main():
         return max_over_ranks(time.perf_counter() - t) * 1e3 / steps, e0.elapsed_time(e1) / steps
 
     def spmv_report(A_rows, M_global, nnz_global, label, N_cols, blocks, traffic=None):
-        op = make_gpu_sharded_spmv(lib, A_rows, M_global, rank, world, dev, blocks=blocks)
-        x = torch.rand(N_cols + 20, dtype=torch.float64, device=dev)
-        fp = int(lib.nsparse_amb_footprint_bytes(C.byref(op.amb)))
+        xh = np.random.default_rng(1).random(N_cols + 20)
+        cuts = np.array([blocks[0][0]] + [e for _, e in blocks], dtype=np.int32)
+        extra = {}
+        if dl is not None:
+            h = native_handle()
+            csr = lib.csr_from_numpy(A_rows["rpt"], A_rows["col"], A_rows["val"], N_cols)
+            lib.csr_memcpy(C.byref(csr))
+            d_x = lib.dmalloc(xh.nbytes)
+            lib.h2d(d_x, xh)
+            plan = ns.sfPlan()
+            lib.init_plan(C.byref(plan))
+            rc = dl.nsparse_dist_spmv_setup(h, C.byref(csr), cuts.ctypes.data_as(ns.capi.c_int_p), d_x, C.byref(plan))
+            assert rc == 0, f"nsparse_dist_spmv_setup -> {rc}"
+            ny = int(dl.nsparse_dist_y_elems(h))
+            d_y = lib.dmalloc((ny + 64) * w)
+            lib.hip.hipMemset(d_y, 0, (ny + 64) * w)
+            amb = dl.nsparse_dist_amb(h).contents
+            fp = int(lib.nsparse_amb_footprint_bytes(C.byref(amb))) if A_rows["M"] > 0 else 0
+            ms_c, ms_c_ev, us_c = native_loop(h, d_y, d_x, 0, args.spmv_steps)
+            ms_g, ms_g_ev, us_g = native_loop(h, d_y, d_x, 1, args.spmv_steps) if world > 1 else (ms_c, ms_c_ev, us_c)
+            extra = {"driver": "native: libnsparse_dist_d.so (C loop, RCCL all-gather, no Python per iteration)",
+                     "host_us_per_spmv": round(us_g, 2), "ms_events_with_gather": round(ms_g_ev, 5)}
+            # the same sequence replayed from a hipGraph (one hipGraphLaunch per SpMV)
+            if world == 1 or os.environ.get("NSPARSE_DIST_GRAPH") == "1":
+                if dl.nsparse_dist_capture(h, d_y, d_x, 1 if world > 1 else 0) == 0:
+                    ms_gr, ms_gr_ev, us_gr = native_loop(h, d_y, d_x, 1 if world > 1 else 0, args.spmv_steps)
+                    extra["hipgraph"] = {"ms_per_spmv": round(ms_gr, 5), "ms_events": round(ms_gr_ev, 5),
+                                         "host_us_per_spmv": round(us_gr, 2)}
+                else:
+                    extra["hipgraph"] = {"error": int(dl.nsparse_dist_last_error())}
+
+            def local_rows():
+                assert dl.nsparse_dist_spmv(h, d_y, d_x, 0) == 0 and dl.nsparse_dist_sync(h) == 0
+                return lib.d2h(C.c_void_p(d_y.value + int(cuts[rank]) * w), (A_rows["M"],), np.float64)
+            plan_o, amb_o = plan, amb
+        else:
+            op = make_gpu_sharded_spmv(lib, A_rows, M_global, rank, world, dev, blocks=blocks)
+            x = torch.from_numpy(xh).to(dev)
+            fp = int(lib.nsparse_amb_footprint_bytes(C.byref(op.amb)))
+            ms_c, ms_c_ev = time_spmv(op, x, args.spmv_steps, gather=False)
+            ms_g = time_spmv(op, x, args.spmv_steps, gather=True)[0] if world > 1 else ms_c
+            extra = {"driver": "python (nsparse_amd/dist.py): smoke-test backend only"}
+            csr, d_x = op.csr, C.c_void_p(x.data_ptr())
+
+            def local_rows():
+                return op(x, gather=False)[:A_rows["M"]].cpu().numpy()
+            plan_o, amb_o = op.plan, op.amb
         # x is counted once over N instead of the reference's second M*w term
         b_amb = fp - A_rows["M"] * w + N_cols * w
         fp_all = sum_over_ranks(b_amb)
-        ms_c, ms_c_ev = time_spmv(op, x, args.spmv_steps, gather=False)
-        ms_g = time_spmv(op, x, args.spmv_steps, gather=True)[0] if world > 1 else ms_c
         b_csr = nnz_global * (w + 4) + 4 * (M_global + 1) + N_cols * w + M_global * w
-        atom = "true" if op.amb.seg_num > 1 else "false"
-        _, tr_s = find_kernel(traffic, [f"k_spmv_amb_row<{int(op.plan.block_size)}, {atom}", f"k_spmv_amb_pipe<{int(op.plan.block_size)}, {atom}",
-                                        f"k_spmv_amb<{int(op.plan.block_size)}, {int(op.amb.chunk)}, {atom}"])
+        atom = "true" if amb_o.seg_num > 1 else "false"
+        _, tr_s = find_kernel(traffic, [f"k_spmv_amb_row<{int(plan_o.block_size)}, {atom}", f"k_spmv_amb_pipe<{int(plan_o.block_size)}, {atom}",
+                                        f"k_spmv_amb<{int(plan_o.block_size)}, {int(amb_o.chunk)}, {atom}"])
         rep = {
             "workload": label, "M": M_global, "nnz": int(nnz_global),
-            "plan": {"seg_size": int(op.plan.seg_size), "block_size": int(op.plan.block_size),
-                     "thread_block": int(op.plan.thread_block), "chunk": int(op.amb.chunk),
-                     "seg_num": int(op.amb.seg_num)},
+            "plan": {"seg_size": int(plan_o.seg_size), "block_size": int(plan_o.block_size),
+                     "thread_block": int(plan_o.thread_block), "chunk": int(amb_o.chunk),
+                     "seg_num": int(amb_o.seg_num)},
             "ms_per_spmv": round(ms_g, 5), "ms_compute_only": round(ms_c, 5),
             "ms_kernel_events": round(ms_c_ev, 5),
             "value": round(fp_all / (ms_g * 1e-3) / 1e9, 1), "unit": "GB/s",
@@ -480,14 +583,15 @@ def main():
             "gflops_ref": round(2.0 * nnz_global / (ms_g * 1e6), 2),
             "bytes_amb_model": int(fp_all),
             "traffic": int(tr_s["hbm_bytes"]) if tr_s else None,
+            **extra,
         }
         # parity spot check against the library's own CPU path (csr_kernel) on rank rows
         if A_rows["M"] > 0:
-            y = op(x, gather=False)[:A_rows["M"]].cpu().numpy()
+            y = local_rows()
             m = lib.csr_from_numpy(A_rows["rpt"], A_rows["col"], A_rows["val"], N_cols)
-            xh = x[:N_cols].cpu().numpy()
+            xs = np.ascontiguousarray(xh[:N_cols])
             yr = np.zeros(A_rows["M"])
-            lib.csr_kernel(yr.ctypes.data_as(C.c_void_p), C.byref(m), xh.ctypes.data_as(C.c_void_p))
+            lib.csr_kernel(yr.ctypes.data_as(C.c_void_p), C.byref(m), xs.ctypes.data_as(C.c_void_p))
             rep["ans_check_fails"] = int(lib.nsparse_ans_check_count(
                 yr.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), A_rows["M"]))
             assert rep["ans_check_fails"] == 0 or os.environ.get("NSPARSE_SPMV_ABL"), "AMB SpMV differs from csr_kernel beyond the reference tolerance"
@@ -495,17 +599,22 @@ def main():
         if world == 1 and not args.no_vendor:
             try:
                 vl = ns.load_vendor("d")
-                yv = torch.zeros(A_rows["M"] + 64, dtype=torch.float64, device=dev)
-                torch.cuda.synchronize()
-                ms_v = float(vl.nsparse_vendor_spmv_csr(C.c_void_p(yv.data_ptr()), C.byref(op.csr),
-                                                        C.c_void_p(x.data_ptr()), 50))
+                d_yv = lib.dmalloc((A_rows["M"] + 64) * w)
+                ms_v = float(vl.nsparse_vendor_spmv_csr(d_yv, C.byref(csr), d_x, 50))
+                lib.dfree(d_yv)
                 rep["vendor_csrmv"] = {"library": "rocSPARSE csrmv (adaptive), C API", "ms": round(ms_v, 5),
                                        "gbs_csr_model": round(b_csr / (ms_v * 1e-3) / 1e9, 1),
                                        "err": int(vl.nsparse_vendor_last_error())}
             except Exception as e:
                 rep["vendor_csrmv"] = {"error": repr(e)[:160]}
-        lib.release_amb(op.amb)
-        lib.release_csr(op.csr)
+        if dl is not None:
+            dl.nsparse_dist_destroy(h)  # releases the AMB arrays and the communicator
+            lib.release_csr(csr)
+            lib.dfree(d_x)
+            lib.dfree(d_y)
+        else:
+            lib.release_amb(op.amb)
+            lib.release_csr(op.csr)
         return rep
 
     nnz_glob = int(A_full["rpt"][-1])
@@ -621,12 +730,18 @@ def main():
                                    if "synthetic" in src else src,
                        "rows_per_gpu": int(a.M), "nnz_A_per_gpu": nnz_a, "n_prod_per_gpu": n_prod,
                        "nnz_C_per_gpu": int(nnz_c), "parallelism": f"row-partition x{world}, B replicated",
-                       "timing": "whole spgemm_kernel_hash call, workspace from the library's block cache, per-bin events off"},
+                       "timing": "whole spgemm_kernel_hash call, workspace from the library's block cache, per-bin events off",
+                       "reference_compatible_gflops": round(flops_all / (ms_ref * 1e6), 2),
+                       "reference_compatible_ms": round(ms_ref, 4)},
             "timing": {"warm_ms": round(ms_per_step, 4), "warm_gflops": round(gflops, 2),
                        "reference_compatible_ms": round(ms_ref, 4),
                        "reference_compatible_gflops": round(flops_all / (ms_ref * 1e6), 2),
                        "reference_compatible": "nsparse_set_workspace_cache(0): every call hipMalloc / hipFree's its "
-                                               "workspaces and C like spgemm_hash.cu:35-54"},
+                                               "workspaces and C like spgemm_hash.cu:35-54",
+                       "alloc_async_ms": round(ms_async, 4),
+                       "alloc_async_gflops": round(flops_all / (ms_async * 1e6), 2),
+                       "alloc_async": "nsparse_set_workspace_cache(2): no cache either; every array of the call comes from "
+                                      "hipMallocAsync and goes back with hipFreeAsync (default pool keeps freed memory)"},
             "phase_ms": {"setup": round(float(phase[0]), 4), "symbolic": round(float(phase[1]), 4),
                          "numeric": round(float(phase[2]), 4), "total_events": round(float(phase[3]), 4),
                          "numeric_bins": [round(float(v), 4) for v in bin_ms[:11]],
@@ -634,7 +749,8 @@ def main():
                          "sym_bin_rows": list(st.sym_bin_size)[:11], "num_bin_rows": list(st.num_bin_size)[:11],
                          "note": "separate pass with per-bin events on"},
             "roofline": roofline,
-            "irregular": irregular,
+            "regular_brick": regular,
+            "structure_sweep": sweep,
             "cpu_baseline": cpu,
             "vendor_baseline": vendor,
             "spmv": spmv,

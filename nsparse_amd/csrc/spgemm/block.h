@@ -353,11 +353,18 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                     }
                     const int idx = col[i] - lo;
                     const int rank = s_pre[idx >> 5] + __popc(s_bits[idx >> 5] & ((1u << (idx & 31)) - 1u));
+                    // a run shorter than kBlkRun must not pick up the values of the NEXT parked entries: with v = 0
+                    // a finite neighbour is harmless, an Inf or NaN neighbour would turn this product into NaN
+                    // (the reference yields NaN / Inf only in the columns the offending entry touches)
+                    const int nb_i = (meta[i] >> 21) & 3;
                     real a[kBlkRun][kBlkRows];
 #pragma unroll
                     for (int dd = 0; dd < kBlkRun; dd++)
 #pragma unroll
-                        for (int r = 0; r < kBlkRows; r++) a[dd][r] = s_a[e[dd] * kBlkRows + r];
+                        for (int r = 0; r < kBlkRows; r++) {
+                            const real t = s_a[e[dd] * kBlkRows + r];
+                            a[dd][r] = (dd == 0 || dd < nb_i) ? t : (real)0;
+                        }
 #pragma unroll
                     for (int r = 0; r < kBlkRows; r++) {
                         if (r < RA) {

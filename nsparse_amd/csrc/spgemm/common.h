@@ -73,7 +73,7 @@ constexpr int kBitsBin0 = 9;
 constexpr int kSetupMaxGrid = 16384;
 constexpr int kGroupMembers = 2;  // twins of a leader that are recorded as its numeric group (block.h: 3 rows)
 constexpr int kTwinEager = 8;     // rows this long claim their map slot / sign up without looking first (twin_probe)
-constexpr int kPartialStride = 16;  // long longs per block: hist[NB], max, total, bm, alen
+constexpr int kPartialStride = 32;  // long longs per block: hist[NB], max, total, bm, alen, list (17 used)
 constexpr int kSymLargeT = 32768;
 constexpr int kSymLargeLimit = 24576;
 static int g_dense_enabled = -1;  // -1: read NSPARSE_DENSE on first use
@@ -95,7 +95,13 @@ struct BinState {
     int max_span[NB];    // widest column window among the rows of each bin (sizes the LDS of the window kernels)
     int far_twins;       // twin rows more than two rows away from their pattern leader (k_numeric_setup)
     int ab_differ;       // the structure of B is not that of A (k_b_info, when asked to compare)
+    // column lists of the bit-window rows (symbolic bins 9 / 10), handed to the numeric listed kernel:
+    long long list_total;            // sum of min(products, window) over those rows: capacity of the list slab
+    unsigned long long list_cursor;  // bump allocator of the symbolic kernels (one returning atomic per row)
+    int queue_head3;                 // row queue of the listed numeric kernel
+    int pad_;
 };
+static_assert(sizeof(BinState) <= 64 * sizeof(int), "k_publish and the fused tails copy one word per lane");
 
 struct Stats {
     nsparse_spgemm_stats s;
@@ -655,6 +661,79 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 __device__ __forceinline__ void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- column lists (round 3) -----------------------------------------------------------------------------
+// The bit-window symbolic kernels hold the exact column set of (a piece of) a C row as a bitmap in LDS.  Until
+// round 2 they only counted it; now they also WRITE it out, ascending, into a slab (`tcol`, room for
+// min(products, window) entries per row, bump-allocated with one returning atomic per row), and the numeric
+// phase accumulates such a row against its list (listed.h) instead of finding the structure a second time:
+// no bitmap tiles whose number grows with the WIDTH of the window (R-MAT-22: 8.6 tiles of 2^19 columns per
+// 16 K-entry row, each two cursor walks, a scan and an emission), no hash probing, no sort.
+//
+// Which rows get a list: more non-zeros than the largest LDS hash table takes (n = the exact count where the
+// kernel knows it, else the bound min(products, window)), at most kListMaxSlices slices of kListSlice entries,
+// and slices x products -- what the listed kernel reads -- within `work_max`: a hub row with millions of
+// products stays with the cursor kernels, which see every product once.
+constexpr int kListSlice = 10240;
+constexpr int kListMaxSlices = 4;
+constexpr int kListMinNnz = 5461;  // = kNumThr.hash_t[3]
+__host__ __device__ __forceinline__ bool list_wanted(int n, int products, long long work_max)
+{
+    const int S = (n + kListSlice - 1) / kListSlice;
+    return n > kListMinNnz && S <= kListMaxSlices && (long long)S * products <= work_max;
+}
+
+// bits: `words` bitmap words in LDS.  Returns the number of set bits (uniform).  dst != nullptr: the columns
+// col0 + (bit index) leave in ascending order to dst[0 .. count).  CLEAR: the words are zeroed on the way.
+// Wavefront w owns a contiguous range of 64-word blocks; inside a block lane l holds word l, so the lanes' runs
+// of output are ADJACENT in memory and a store instruction of a sparse stretch covers one or two cache lines
+// (the first version gave every thread 16-32 consecutive words: 64 far-apart runs per store instruction, and
+// the symbolic bit-window kernel of R-MAT-18 went from 6.8 to 12.7 ms).  Two workgroup barriers; s_wsum: BS / 64 ints.
+template <int BS, bool CLEAR>
+__device__ __forceinline__ int bits_to_list(unsigned int *bits, int words, int col0, int *__restrict__ dst, int *s_wsum)
+{
+    constexpr int NW = BS / 64;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nblk = (words + 63) >> 6;
+    const int per = (nblk + NW - 1) / NW;
+    const int b0 = wv * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    int mine = 0;
+    for (int b = b0; b < b1; b++) {
+        const int w = b * 64 + lane;
+        mine += w < words ? __popc(bits[w]) : 0;
+    }
+    mine = wave_sum(mine);
+    if (lane == 0) s_wsum[wv] = mine;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int u = 0; u < NW; u++) {
+        const int c = s_wsum[u];
+        base += u < wv ? c : 0;
+        total += c;
+    }
+    if (dst != nullptr || CLEAR) {
+        int running = base;
+        for (int b = b0; b < b1; b++) {
+            const int w = b * 64 + lane;
+            unsigned int m = w < words ? bits[w] : 0u;
+            if (CLEAR && w < words) bits[w] = 0u;
+            if (dst != nullptr) {
+                const int c = __popc(m);
+                const int incl = wave_incl_scan(c);
+                int p = running + incl - c;
+                const int cb = col0 + 32 * w;
+                while (m) {
+                    dst[p++] = cb + __builtin_ctz(m);
+                    m &= m - 1;
+                }
+                running += __builtin_amdgcn_readlane(incl, 63);
+            }
+        }
+    }
+    __syncthreads();
+    return total;
 }
 
 // Rows with more than 5461 non-zeros do not fit an LDS hash table, and on power-law inputs

@@ -209,10 +209,10 @@ __global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict
     {
         const int per = (nparts + (int)gridDim.x - 1) / (int)gridDim.x;
         const int b0 = blockIdx.x * per, b1 = b0 + per < nparts ? b0 + per : nparts;
-        const int f = threadIdx.x & 15;
-        if (f < NB + 4 && b0 < b1) {
+        const int f = threadIdx.x & 31;
+        if (f < NB + 5 && b0 < b1) {
             long long acc = 0;
-            for (int b = b0 + ((int)threadIdx.x >> 4); b < b1; b += 64) {
+            for (int b = b0 + ((int)threadIdx.x >> 5); b < b1; b += 32) {
                 const long long v = partial[(long long)b * kPartialStride + f];
                 acc = (f == NB || f == NB + 3) ? (v > acc ? v : acc) : acc + v;
             }
@@ -253,6 +253,7 @@ __global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict
         if (s_max) atomicMax(&bs->maxv, s_max);
         if (s_acc[NB + 1]) atomicAdd((unsigned long long *)&bs->total, s_acc[NB + 1]);
         if (s_acc[NB + 2]) atomicAdd((unsigned long long *)&bs->bm_total, s_acc[NB + 2]);
+        if (s_acc[NB + 4]) atomicAdd((unsigned long long *)&bs->list_total, s_acc[NB + 4]);
         if (s_alen) atomicMax((unsigned long long *)&bs->max_alen, (unsigned long long)s_alen);
         __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }

@@ -40,8 +40,15 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                                                    const int *__restrict__ row_span, int *__restrict__ slab,
                                                    long long stride_ints, int amax, int write_col,
                                                    int LONG_LEN, int dens, int tiled_w,
-                                                   unsigned long long *prof, int *__restrict__ row_nz_out = nullptr)
+                                                   unsigned long long *prof, int *__restrict__ row_nz_out = nullptr,
+                                                   int *__restrict__ tcol = nullptr,
+                                                   long long *__restrict__ list_off = nullptr,
+                                                   long long list_work = 0, const int *__restrict__ row_prod = nullptr)
 {
+    // SYM with tcol != nullptr: the columns of every tile are also written out as the row's sorted list
+    // (common.h: bits_to_list) when common.h: list_wanted says so.  Numeric with list_work > 0: rows that
+    // list_wanted picks and that have a list (list_off == nullptr: every such row, the list is C.col itself)
+    // belong to k_num_listed.
     // prof (NSPARSE_TILED_PROF=1), 100 MHz ticks of thread 0: 0 set-up, 1 pass 1, 2 scan, 3 pass 2,
     // 4 emission; 5 tiles, 6 rows
     unsigned long long tk = prof ? wall_clock64() : 0;
@@ -67,6 +74,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
     __shared__ real l_av[LCAP];
     __shared__ int s_row, s_nlong, s_cut, s_ntile;
     __shared__ int s_wsum[NW];
+    __shared__ long long s_off;
     int *st_cur = slab + (long long)blockIdx.x * stride_ints;
     int *st_end = st_cur + amax;
     int *st_next = st_end + amax;
@@ -91,6 +99,19 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
         // dens > 0: only rows thinner than one non-zero per `dens` columns or wider than 32 dense
         // tiles (the rest belong to k_num_tiled); dens <= 0: every row
         if (!SYM && dens > 0 && (long long)row_nnz * dens >= span && span <= 32 * tiled_w) continue;
+        if (!SYM && list_work > 0 && list_wanted(row_nnz, row_prod[rid], list_work) &&
+            (list_off == nullptr || list_off[rid] >= 0))
+            continue;
+        bool listing = false;
+        if (SYM && tcol != nullptr) {
+            const int np = row_prod[rid];
+            const int lcap = np < span ? np : span;
+            listing = list_wanted(lcap, np, list_work);
+            if (listing && threadIdx.x == 0) {
+                s_off = (long long)atomicAdd(&bs->list_cursor, (unsigned long long)lcap);
+                list_off[rid] = s_off;
+            }
+        }
         const int a_beg = arpt[rid], alen = arpt[rid + 1] - a_beg;
         const int split = 64 * ((span + W - 1) / W + row_nnz / CAP + 1);
         auto init_entry = [&](int e, int &cur, int &end, real &av) -> bool {
@@ -302,16 +323,11 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                     }
                 }
             };
-            if (SYM) {  // one committing walk that only sets bits, then count and clear
+            if (SYM) {  // one committing walk that only sets bits, then count (list) and clear
                 walk(std::true_type{}, t_max);
                 lds_barrier();
-#pragma unroll
-                for (int j = 0; j < WPT; j++) {
-                    sym_cnt += __popc(bits[threadIdx.x + j * BS]);
-                    bits[threadIdx.x + j * BS] = 0;
-                }
+                sym_cnt += bits_to_list<BS, true>(bits, NWORD, t_lo, listing ? tcol + s_off + sym_cnt : (int *)nullptr, s_wsum);
                 t_lo = t_max;
-                lds_barrier();
                 continue;
             }
             walk(std::false_type{}, t_max);
@@ -407,16 +423,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             tick(4);
             if (prof) t_acc[5]++;
         }
-        if (SYM) {  // nnz of the row = bits seen over all tiles
-            sym_cnt = wave_sum(sym_cnt);
-            if (lane == 0) s_wsum[w] = sym_cnt;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                int tot = 0;
-                for (int u = 0; u < NW; u++) tot += s_wsum[u];
-                row_nz_out[rid] = tot;
-            }
-        }
+        if (SYM && threadIdx.x == 0) row_nz_out[rid] = sym_cnt;  // nnz of the row = bits seen over all tiles (uniform)
     }
     if (prof && threadIdx.x == 0)
         for (int i = 0; i < 13; i++) atomicAdd(prof + 16 + i, t_acc[i]);

@@ -20,7 +20,9 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                                                   BinState *bs, const int *__restrict__ row_lo,
                                                   const int *__restrict__ row_span, int *__restrict__ slab,
                                                   long long stride_ints, int amax, int write_col,
-                                                  int LONG_LEN, unsigned long long *prof, int dens)
+                                                  int LONG_LEN, unsigned long long *prof, int dens,
+                                                  const long long *__restrict__ list_off = nullptr,
+                                                  long long list_work = 0, const int *__restrict__ row_prod = nullptr)
 {
     // prof (NSPARSE_TILED_PROF=1): thread 0 adds 100 MHz ticks per phase -- 0 cursor set-up,
     // 2 register-fed accumulation, 3 overflow paths, 4 emission, 5 tiles, 6 rows
@@ -76,6 +78,10 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
         // dens > 0: rows thinner than one non-zero per `dens` columns, or wider than 32 tiles, are
         // left to k_num_ranked
         if (dens > 0 && ((long long)(crpt[rid + 1] - crpt[rid]) * dens < span || span > 32 * W)) continue;
+        // rows that have a column list and that common.h: list_wanted picks belong to k_num_listed (listed.h)
+        if (list_work > 0 && list_wanted(crpt[rid + 1] - crpt[rid], row_prod[rid], list_work) &&
+            (list_off == nullptr || list_off[rid] >= 0))
+            continue;
         const int a_beg = arpt[rid], alen = arpt[rid + 1] - a_beg;
         // ---- cursor set-up ------------------------------------------------------------
         // Entry e of the A row is always handled by thread e % BS.  Its cursor into B row

@@ -303,11 +303,14 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
         int2 ext[BS];
         real av[BS];
         DeferList<true, (PMAX / 16 > 32 ? PMAX / 16 : 32)> defer;
-        FlatScratch<(BS >= 512 ? BS : 64)> flat;
+        FlatScratch<(BS >= 256 ? BS : 64)> flat;
     };
     // write_col bit 2: NSPARSE_FLAT=0.  The flat walk keeps U chunks in flight per lane (26 more registers): only where the LDS of a row bounds
     // the occupancy anyway, not in the one-wavefront-per-row bins that live on rows in flight
-    constexpr bool FLAT = BS >= 512;
+#ifndef NSP_FLAT_NUM_MIN_BS
+#define NSP_FLAT_NUM_MIN_BS 512
+#endif
+    constexpr bool FLAT = BS >= NSP_FLAT_NUM_MIN_BS;
     union Overlay {
         WalkScratch w;
         int srt[PMAX];
@@ -318,8 +321,15 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     real *s_av = s_ov.w.av;
     auto &s_defer = s_ov.w.defer;
     __shared__ int s_cnt;
-    const int slot = xcd_row_slot(bin_size);
-    if (slot < 0) return;
+    // Big-table bins (BS >= 512): the launch may hold FEWER workgroups than rows (a multiple of 8: write_col bit 4
+    // says so) and every workgroup strides over the rows of its XCD's eighth of the bin.  A workgroup per row is a
+    // dispatch, a drain of the row's stores and a fresh LDS allocation per row, with one or two rows per CU and
+    // nothing to hide them behind: R-MAT-22, 8192-slot bin, 41 us per row of which 27 are the kernel's own phases.
+    const int nb8 = (bin_size + 7) >> 3;
+    const bool persist = FLAT && (write_col & 16);
+    for (int j8 = (int)(blockIdx.x >> 3);; j8 += (int)(gridDim.x >> 3)) {
+    const int slot = persist ? (j8 < nb8 ? (int)(blockIdx.x & 7) * nb8 + j8 : bin_size) : xcd_row_slot(bin_size);
+    if (slot < 0 || slot >= bin_size) return;
     const int rid = row_perm[bin_off + slot];
     const int off = crpt[rid];
     const int n = crpt[rid + 1] - off;
@@ -386,6 +396,9 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
 #ifdef NSPARSE_TB_PROF_BUILD
     if (prof && threadIdx.x == 0) atomicAdd(prof + 5, 1ull);
 #endif
+    if (!persist) return;
+    __syncthreads();  // the next row clears the tables this one has just read
+    }
 }
 
 // bin 5: persistent workgroups, private (keys, values) slices of global slabs; the row is

@@ -303,16 +303,17 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
     __shared__ int s_max;
     __shared__ unsigned long long s_total;
     __shared__ unsigned long long s_bm;
+    __shared__ unsigned long long s_list;
     __shared__ int s_alen;
     if (threadIdx.x < NB) s_hist[threadIdx.x] = 0;
-    if (threadIdx.x == 0) { s_max = 0; s_total = 0; s_bm = 0; s_alen = 0; }
+    if (threadIdx.x == 0) { s_max = 0; s_total = 0; s_bm = 0; s_alen = 0; s_list = 0; }
     __syncthreads();
     const int lane = threadIdx.x % W;
     constexpr int RPB = 256 / W;
     // per-thread statistics, folded once per wave at the end: one LDS atomic per row would
     // serialise when (almost) every row falls into the same bin (1 M-row power-law inputs)
     int t_max = 0, t_alen = 0;
-    unsigned long long t_total = 0, t_bm = 0;
+    unsigned long long t_total = 0, t_bm = 0, t_list = 0;
     // grid-stride over rows
     for (int base = blockIdx.x * RPB; base < nrows; base += gridDim.x * RPB) {
         const int q = base + (int)threadIdx.x / W;
@@ -399,6 +400,8 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             const int bw = (dense_row && span > 0 && span <= bm_span_max) ? (span + 31) >> 5 : 0;
             bm_words[row] = bw;
             row_span_num[row] = 0;  // set by k_sym_dense when it hands a bitmap over
+            // bit-window rows can hand their sorted column list to the numeric phase: room for it
+            const int lcap = ((bin == kBitsBin0 || bin == kBitsBin0 + 1) && ni > kListMinNnz) ? (ni < span ? ni : span) : 0;
             const int al = arpt[row + 1] - arpt[row];
             if (W >= 16) {  // at most 4 rows per wave: direct LDS atomics are cheapest
                 if (bin >= 0) atomicAdd(&s_hist[bin], 1);
@@ -406,11 +409,13 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
                 atomicMax(&s_alen, al);
                 atomicAdd(&s_total, (unsigned long long)n);
                 if (bw) atomicAdd(&s_bm, (unsigned long long)bw);
+                if (lcap) atomicAdd(&s_list, (unsigned long long)lcap);
             } else {
                 t_max = ni > t_max ? ni : t_max;
                 t_alen = al > t_alen ? al : t_alen;
                 t_total += (unsigned long long)n;
                 t_bm += (unsigned long long)bw;
+                t_list += (unsigned long long)lcap;
             }
         }
         if (W < 16) {
@@ -433,12 +438,14 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             t_alen = m2 > t_alen ? m2 : t_alen;
             t_total += __shfl_xor(t_total, o);
             t_bm += __shfl_xor(t_bm, o);
+            t_list += __shfl_xor(t_list, o);
         }
         if ((threadIdx.x & 63) == 0) {
             atomicMax(&s_max, t_max);
             atomicMax(&s_alen, t_alen);
             atomicAdd(&s_total, t_total);
             atomicAdd(&s_bm, t_bm);
+            if (t_list) atomicAdd(&s_list, t_list);
         }
     }
     __syncthreads();
@@ -452,6 +459,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
         out[NB + 1] = (long long)s_total;
         out[NB + 2] = (long long)s_bm;
         out[NB + 3] = s_alen;
+        out[NB + 4] = (long long)s_list;
     }
 }
 
@@ -465,13 +473,14 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const long long *__rest
     if (threadIdx.x == 0) { s_max = 0; s_alen = 0; }
     __syncthreads();
     // a few dozen workgroups, each folds a slice of the partials and issues one global atomic
-    // per field: thread t handles field (t % 16) of partials t/16, t/16 + 16, ... of its slice
+    // per field: thread t handles field (t % 32) of partials t/32, t/32 + 8, ... of its slice
     const int per = (nblocks + gridDim.x - 1) / gridDim.x;
     const int b0 = blockIdx.x * per, b1 = b0 + per < nblocks ? b0 + per : nblocks;
-    const int f = threadIdx.x & 15;
-    if (f < NB + 4) {
+    static_assert(kPartialStride == 32, "field = thread & 31");
+    const int f = threadIdx.x & 31;
+    if (f < NB + 5) {
         long long acc = 0;
-        for (int b = b0 + (threadIdx.x >> 4); b < b1; b += 16) {
+        for (int b = b0 + (threadIdx.x >> 5); b < b1; b += 8) {
             const long long v = partial[(long long)b * kPartialStride + f];
             acc = (f == NB || f == NB + 3) ? (v > acc ? v : acc) : acc + v;
         }
@@ -485,6 +494,7 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const long long *__rest
         if (s_max) atomicMax(&bs->maxv, s_max);
         if (s_acc[NB + 1]) atomicAdd((unsigned long long *)&bs->total, s_acc[NB + 1]);
         if (s_acc[NB + 2]) atomicAdd((unsigned long long *)&bs->bm_total, s_acc[NB + 2]);
+        if (s_acc[NB + 4]) atomicAdd((unsigned long long *)&bs->list_total, s_acc[NB + 4]);
         if (s_alen) atomicMax((unsigned long long *)&bs->max_alen, (unsigned long long)s_alen);
     }
 }

@@ -84,6 +84,9 @@ __global__ __launch_bounds__(BS) void k_sym_small(const int *__restrict__ arpt,
 
 // bins 1..5: one workgroup per row (set_row_nz_bin_each_tb :399-472; LARGE = the try-in-LDS
 // kernel with a fail list, set_row_nz_bin_each_tb_large :474-554).
+#ifndef NSP_FLAT_SYM_MIN_T
+#define NSP_FLAT_SYM_MIN_T 8192
+#endif
 template <int BS, int TMAX, bool LARGE, int COOP = 0>
 __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                                const int *__restrict__ acol,
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                            int h[VW];
                                            if (COOP) ht_insert_vec_coop(tab, mask, k, n, h, cnt, COOP);
                                            else ht_insert_vec(tab, mask, k, n, h, cnt);
-                                       }, (TMAX >= 8192 && flat_on) ? reinterpret_cast<FlatScratch<BS> *>(&s_flat) : (FlatScratch<BS> *)nullptr,
+                                       }, (TMAX >= NSP_FLAT_SYM_MIN_T && flat_on) ? reinterpret_cast<FlatScratch<BS> *>(&s_flat) : (FlatScratch<BS> *)nullptr,
                                        flat_on == 2);
     } else {
         // try-in-LDS: plain walk with early exit once the table holds kSymLargeLimit keys

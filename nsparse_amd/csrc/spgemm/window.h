@@ -121,17 +121,30 @@ __global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, c
                                                  const int *__restrict__ row_lo,
                                                  const int *__restrict__ row_span,
                                                  int *__restrict__ row_nz, int bin_off, int bin_size,
-                                                 int bnnz)
+                                                 int bnnz, BinState *bs = nullptr, int *__restrict__ tcol = nullptr,
+                                                 long long *__restrict__ list_off = nullptr, long long list_work = 0)
 {
+    // tcol != nullptr: the row's columns are written out as a sorted list for the numeric phase (common.h:
+    // bits_to_list), list_off[rid] = where
     __shared__ __attribute__((aligned(16))) unsigned int bits[WORDS_MAX];
     __shared__ int2 s_ext[BS];
-    __shared__ int s_nz;
+    __shared__ int s_wsum[BS / 64];
+    __shared__ long long s_off;
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
     const int rid = row_perm[bin_off + slot];
     const int a_beg = arpt[rid], a_end = arpt[rid + 1];
     const int g = group_width(row_prod[rid], a_end - a_beg, BS, row_maxb[rid]);
-    if (threadIdx.x == 0) s_nz = 0;
+    // a list for the numeric listed kernel?  One piece: decided with the exact count, once it is known; several
+    // pieces: up front, with the bound (common.h: list_wanted)
+    const int np = row_prod[rid], sp = row_span[rid];
+    const int lcap = np < sp ? np : sp;
+    const bool one_piece = sp <= WORDS_MAX * 32;
+    bool listing = tcol != nullptr && !one_piece && list_wanted(lcap, np, list_work);
+    if (listing && threadIdx.x == 0) {
+        s_off = (long long)atomicAdd(&bs->list_cursor, (unsigned long long)lcap);
+        list_off[rid] = s_off;
+    }
     int cnt = 0;
     // A window wider than the bitmap is covered in pieces: every piece walks all products again
     // and keeps the columns that fall into it (no cursors: the walk is a fraction of what a hash
@@ -156,14 +169,23 @@ __global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, c
                                              if (idx < (unsigned int)cols) atomicOr(bits + (idx >> 5), 1u << (idx & 31));
                                          }
                                  });
-        __syncthreads();
-        for (int i = threadIdx.x; i < words; i += BS) cnt += __popc(bits[i]);
-        __syncthreads();
+        __syncthreads();  // (also orders s_off)
+        if (tcol != nullptr && one_piece) {
+            const int n1 = bits_to_list<BS, false>(bits, words, lo, (int *)nullptr, s_wsum);  // count first
+            if (list_wanted(n1, np, list_work)) {
+                if (threadIdx.x == 0) {
+                    s_off = (long long)atomicAdd(&bs->list_cursor, (unsigned long long)n1);
+                    list_off[rid] = s_off;
+                }
+                __syncthreads();
+                bits_to_list<BS, false>(bits, words, lo, tcol + s_off, s_wsum);
+            }
+            cnt += n1;
+        } else {
+            cnt += bits_to_list<BS, false>(bits, words, lo, listing ? tcol + s_off + cnt : (int *)nullptr, s_wsum);
+        }
     }
-    cnt = wave_sum(cnt);
-    if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(&s_nz, cnt);
-    __syncthreads();
-    if (threadIdx.x == 0) row_nz[rid] = s_nz;
+    if (threadIdx.x == 0) row_nz[rid] = cnt;
 }
 
 // lanes per B row for the one-entry-per-lane walk of the node-block kernel (block.h): the smallest power

@@ -49,6 +49,7 @@
 //   spgemm/block.h         k_num_block, k_twin_groups                     (numeric bins 6-9: node blocks)
 //   spgemm/heavy_tiled.h   k_num_tiled                                    (bin 5, dense tiles)
 //   spgemm/heavy_ranked.h  k_num_ranked                                   (bin 5, thin rows)
+//   spgemm/listed.h        k_num_listed                                   (bin 5, rows with a column list from the symbolic phase)
 //
 // Results: C.rpt / C.col are bit-identical to the reference by construction (distinct
 // columns per row, ascending); C.val differs only by floating-point summation order
@@ -71,6 +72,7 @@
 #include "spgemm/fused.h"
 #include "spgemm/heavy_tiled.h"
 #include "spgemm/heavy_ranked.h"
+#include "spgemm/listed.h"
 
 namespace nsp {
 namespace spgemm {
@@ -106,6 +108,14 @@ static const int g_coop = getenv("NSPARSE_COOP") ? atoi(getenv("NSPARSE_COOP")) 
 // 86.5 / 86.3 / 72.8 ms for 0 / 1 / 2 -- its rows are all hubs, so their AVERAGE B row is long as well --
 // webbase-1M class 2.71 / 2.46 / 2.42.
 static const int g_flat = getenv("NSPARSE_FLAT") ? atoi(getenv("NSPARSE_FLAT")) : 2;
+
+// Column lists (common.h: list_wanted): a heavy row goes to the listed kernel while slices x products stays within
+// this (NSPARSE_LIST_WORK); beyond it the cursor kernels, which see every product once, are cheaper.
+static long long list_work()
+{
+    static const long long w = getenv("NSPARSE_LIST_WORK") ? atoll(getenv("NSPARSE_LIST_WORK")) : 150000LL;
+    return w;
+}
 
 static void *scan_exclusive(const int *in, int *out, int n, hipStream_t st)
 {
@@ -341,7 +351,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
                                   int max_prod, BinState *d_bs, Context &cx, float *ms_bin,
                                   int *fail_rows, const int *bm_off, unsigned int *bm,
                                   int *row_span_num, const int *max_span, int max_alen, bool b_sorted,
-                                  const unsigned char *btwin, const int4 *sdesc)
+                                  const unsigned char *btwin, const int4 *sdesc, int *tcol, long long *list_off)
 {
     int hist[NB], off[NB + 1];
     fold_small_hash_bins(hist_in, hist, off);
@@ -382,7 +392,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_bits<BS, WORDS>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
                            arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_lo, row_span, row_nz, \
-                           off[BIN], hist[BIN], b->nnz);                                       \
+                           off[BIN], hist[BIN], b->nnz, d_bs, tcol, list_off, list_work());    \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -412,7 +422,8 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         hipLaunchKernelGGL((k_num_ranked<1024, 1048576, 8, 1024, true>), dim3(groups), dim3(1024), 0, st, arpt, acol,
                            (const real *)nullptr, brpt, bcol, (const real *)nullptr, (const int *)nullptr,
                            (int *)nullptr, (real *)nullptr, row_perm, off[10], rows, d_bs, row_lo, row_span, slab,
-                           stride_ints, amax, 0, sym_long_len, -1, 0, (unsigned long long *)nullptr, row_nz);
+                           stride_ints, amax, 0, sym_long_len, -1, 0, (unsigned long long *)nullptr, row_nz, tcol, list_off,
+                           list_work(), (const int *)row_prod);
         NSP_LAUNCH_CHECK();
         L.end(10);
         L.free_later(slab);
@@ -483,7 +494,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                                  float *ms_bin, int write_col, const int *bm_off,
                                  const unsigned int *bm, int max_alen, bool b_sorted,
                                  const int *max_span, const unsigned char *grp, const unsigned char *btwin,
-                                 const int *listed, const int *members, const int4 *desc, const int *bkey)
+                                 const int *listed, const int *members, const int4 *desc, const int *bkey,
+                                 const int *tcol, const long long *list_off, long long list_w)
 {
     int hist[NB], off[NB + 1];
     fold_small_hash_bins(hist_in, hist, off);
@@ -515,6 +527,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         NSP_CHECK(hipMemsetAsync(tb_prof, 0, 8 * NB * sizeof(unsigned long long), cx.stream[0]));
         NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
     }
+    // workgroups per CU of the persistent form of the big-table hash bins (0: one workgroup per row)
+    static const int tb_persist = getenv("NSPARSE_TB_PERSIST") ? atoi(getenv("NSPARSE_TB_PERSIST")) : 0;  // measured: no gain (R-MAT-22 76.1 / 76.5 / 75.3 / 76.4 ms for 0 / 1 / 2 / 4)
     constexpr int kBlkU = 4;  // tasks in flight per lane in the node-block kernel
     // diagnostics: extra dynamic LDS per workgroup = fewer groups in flight per CU (what bounds the kernel?)
     static const int blk_pad = getenv("NSPARSE_BLK_PAD") ? atoi(getenv("NSPARSE_BLK_PAD")) : 0;
@@ -545,10 +559,19 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
             d_prof = (unsigned long long *)dev_alloc(32 * sizeof(unsigned long long));
             NSP_CHECK(hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), st));
         }
+        // rows with a column list from the symbolic phase (listed.h) first: most of the heavy rows of a
+        // power-law matrix; the cursor kernels below skip them
+        if (list_w > 0) {
+            hipLaunchKernelGGL((k_num_listed<1024>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval, brpt, bcol, bval,
+                               c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows, d_bs, tcol, list_off,
+                               list_w, row_prod, b->nnz, write_col);
+            NSP_LAUNCH_CHECK();
+        }
 #define NSP_TILED(BSX, WX)                                                                     \
     hipLaunchKernelGGL((k_num_tiled<BSX, WX>), dim3(groups), dim3(BSX), 0, st, arpt, acol, aval, brpt, \
                        bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows,   \
-                       d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len, d_prof, ranked_dens)
+                       d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len, d_prof, ranked_dens, \
+                       list_off, list_w, row_prod)
         if (ranked_dens >= 0) {
             if (tile_sel == 1) { NSP_TILED(1024, kTileW / 2); }
             else if (tile_sel == 2) { NSP_TILED(512, kTileW / 2); }
@@ -569,7 +592,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     hipLaunchKernelGGL((k_num_ranked<1024, WX, CAPX, LCAPX>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval,  \
                        brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows, d_bs,   \
                        row_lo, row_span, slab, stride_ints, amax, write_col, long_len, ranked_dens,                 \
-                       tile_sel == 0 ? kTileW : (tile_sel == 3 ? kTileW / 4 : kTileW / 2), d_prof)
+                       tile_sel == 0 ? kTileW : (tile_sel == 3 ? kTileW / 4 : kTileW / 2), d_prof, (int *)nullptr,  \
+                       (int *)nullptr, const_cast<long long *>(list_off), list_w, row_prod)
             if (ranked_sel == 1) { NSP_RANKED(524288, 6144, 512); }
             else { NSP_RANKED(262144, kRankCap, 1024); }
 #undef NSP_RANKED
@@ -590,9 +614,17 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         L.free_later(slab);
     }
 #define NSP_NUM_TB_GO(BS, TMAX, PMAX, COOPX)                                                    \
-    hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX, COOPX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), tb_pad, st, arpt, \
-                       acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm,    \
-                       row_prod, row_maxb, off[bin_], hist[bin_], b->nnz, write_col | (g_flat ? 0 : 4) | (g_flat == 2 ? 8 : 0), tb_prof ? tb_prof + 8 * bin_ : nullptr)
+    do {                                                                                       \
+        /* big-table bins: a few workgroups per CU that stride over the rows (numeric.h) */     \
+        const int full_ = 8 * ceil_div(hist[bin_], 8);                                         \
+        const int pers_ = BS >= 512 ? 8 * ceil_div(cx.num_cus * tb_persist, 8) : 0;            \
+        const bool per_ = pers_ > 0 && pers_ < full_;                                          \
+        hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX, COOPX>), dim3(per_ ? pers_ : full_), dim3(BS), tb_pad, st, arpt, \
+                           acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, \
+                           row_prod, row_maxb, off[bin_], hist[bin_], b->nnz,                    \
+                           write_col | (g_flat ? 0 : 4) | (g_flat == 2 ? 8 : 0) | (per_ ? 16 : 0), \
+                           tb_prof ? tb_prof + 8 * bin_ : nullptr);                             \
+    } while (0)
 #define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
@@ -855,6 +887,8 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     static_assert(2 * sizeof(BinState) <= 120 * sizeof(int), "scratch layout");
 
     void *scan_tmp = nullptr;
+    int *tcol = nullptr;            // column lists of the bit-window rows (symbolic -> numeric, listed.h)
+    long long *list_off = nullptr;  // per row: where its list starts in tcol, -1: none
     unsigned int *bm = nullptr;
     unsigned char *grp = nullptr;
     int4 *blk_desc = nullptr;  // row records of the node-block kernel, in list order (k_numeric_setup)
@@ -1055,10 +1089,24 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         // used by the symbolic phase alone and the numeric phase hashes
         if (use_bm && h_sym->bm_total > 0 && h_sym->bm_total < (1LL << 30))
             bm = (unsigned int *)dev_alloc(sizeof(unsigned int) * (size_t)h_sym->bm_total);
+        // column lists of the bit-window rows for the numeric listed kernel (listed.h): a slab with room for
+        // min(products, window) entries per such row, when that fits comfortably (NSPARSE_LIST=0: off)
+        static const bool list_on = getenv("NSPARSE_LIST") && atoi(getenv("NSPARSE_LIST")) == 1;  // opt-in: see listed.h
+        if (list_on && h_sym->list_total > 0 && h_sym->b_unsorted == 0 && h_sym->hist[kBitsBin0] + h_sym->hist[kBitsBin0 + 1] > 0) {
+            size_t free_b = 0, total_b = 0;
+            const size_t want = sizeof(int) * (size_t)h_sym->list_total + sizeof(long long) * (size_t)M;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want <= free_b / 3 + (pooled ? (64u << 20) : 0u) &&
+                want <= ((size_t)64 << 30)) {
+                tcol = (int *)dev_alloc(sizeof(int) * (size_t)h_sym->list_total);
+                list_off = (long long *)dev_alloc(sizeof(long long) * (size_t)M);
+                NSP_CHECK(hipMemsetAsync(list_off, 0xff, sizeof(long long) * (size_t)M, s0));
+            }
+        }
         BinLauncher LS = symbolic_phase(a, b, row_prod, row_maxb, row_lo, row_span, row_nz, row_perm, h_sym->hist,
                                         h_sym->maxv, d_sym, cx, S.ms_sym_bin, &S.sym_fail_rows,
                                         bm_off, bm, row_span_num, h_sym->max_span, (int)h_sym->max_alen,
-                                        h_sym->b_unsorted == 0, btwin, bm ? (const int4 *)sym_desc : (const int4 *)nullptr);
+                                        h_sym->b_unsorted == 0, btwin, bm ? (const int4 *)sym_desc : (const int4 *)nullptr,
+                                        tcol, list_off);
         sym_used = LS;
         {
             long long binned = 0;
@@ -1167,11 +1215,15 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                           ? (const int *)twin_of
                           : (const int *)nullptr;
     // ---- numeric --------------------------------------------------------------------
+    // (a numeric-only re-run has the list of every row: C.col itself)
+    static const bool list_rerun_on = getenv("NSPARSE_LIST") && atoi(getenv("NSPARSE_LIST")) == 1;
     if (!too_big) {
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_maxb, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
-                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor, members, blk_desc, bkey);
+                                   (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor, members, blk_desc, bkey,
+                                   numeric_only ? (const int *)c->d_col : (const int *)tcol, list_off,
+                                   (numeric_only ? list_rerun_on : tcol != nullptr) ? list_work() : 0LL);
     tm.mark(3, s0);
     {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
         const int seq = ++cx.seq;
@@ -1198,6 +1250,8 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     }  // !retry
 
     dev_free(scan_tmp);
+    dev_free(tcol);
+    dev_free(list_off);
     dev_free(bm);
     dev_free(bm_scan_tmp);
     if (grp) dev_free(grp);
