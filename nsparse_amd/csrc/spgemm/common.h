@@ -691,21 +691,28 @@ __host__ __device__ __forceinline__ bool list_wanted(int n, int products, long l
 // (the first version gave every thread 16-32 consecutive words: 64 far-apart runs per store instruction, and
 // the symbolic bit-window kernel of R-MAT-18 went from 6.8 to 12.7 ms).  Two workgroup barriers; s_wsum: BS / 64 ints.
 template <int BS, bool CLEAR>
-__device__ __forceinline__ int bits_to_list(unsigned int *bits, int words, int col0, int *__restrict__ dst, int *s_wsum)
+__device__ __forceinline__ int bits_to_list(unsigned int *bits, int words, int col0, int *__restrict__ dst, int *s_wsum,
+                                            bool dry = false)
 {
+    // (Staging the columns in LDS so that a store instruction writes 64 consecutive entries was tried: the symbolic
+    //  cursor kernel of R-MAT-22 took 16.9 ms with it as without; with the stores left out altogether -- `dry` --
+    //  11.1, without lists 9.4.  The stores cost by their volume and their acknowledgements, which the next tile's
+    //  first load waits for, not by their shape.)
+    // (blocks of 128 words, lane l holds the 64-bit pair 2l, 2l + 1: one wave scan per 4096 columns)
     constexpr int NW = BS / 64;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nblk = (words + 63) >> 6;
+    const int nblk = (words + 127) >> 7;
     const int per = (nblk + NW - 1) / NW;
     const int b0 = wv * per, b1 = b0 + per < nblk ? b0 + per : nblk;
+    auto pair_at = [&](int w) -> unsigned long long {  // words w, w + 1 (w even), zero beyond the bitmap
+        const unsigned long long lo = w < words ? bits[w] : 0u, hi = w + 1 < words ? bits[w + 1] : 0u;
+        return lo | (hi << 32);
+    };
     int mine = 0;
-    for (int b = b0; b < b1; b++) {
-        const int w = b * 64 + lane;
-        mine += w < words ? __popc(bits[w]) : 0;
-    }
+    for (int b = b0; b < b1; b++) mine += __popcll(pair_at(b * 128 + 2 * lane));
     mine = wave_sum(mine);
     if (lane == 0) s_wsum[wv] = mine;
-    __syncthreads();
+    lds_barrier();  // (LDS only: a __syncthreads() would also wait for the list stores of the previous piece)
     int base = 0, total = 0;
 #pragma unroll
     for (int u = 0; u < NW; u++) {
@@ -716,23 +723,26 @@ __device__ __forceinline__ int bits_to_list(unsigned int *bits, int words, int c
     if (dst != nullptr || CLEAR) {
         int running = base;
         for (int b = b0; b < b1; b++) {
-            const int w = b * 64 + lane;
-            unsigned int m = w < words ? bits[w] : 0u;
-            if (CLEAR && w < words) bits[w] = 0u;
+            const int w = b * 128 + 2 * lane;
+            unsigned long long m = pair_at(w);
+            if (CLEAR) {
+                if (w < words) bits[w] = 0u;
+                if (w + 1 < words) bits[w + 1] = 0u;
+            }
             if (dst != nullptr) {
-                const int c = __popc(m);
+                const int c = __popcll(m);
                 const int incl = wave_incl_scan(c);
                 int p = running + incl - c;
                 const int cb = col0 + 32 * w;
-                while (m) {
-                    dst[p++] = cb + __builtin_ctz(m);
+                while (m && !dry) {  // (dry: diagnostics, everything but the stores)
+                    dst[p++] = cb + __builtin_ctzll(m);  // (nontemporal stores: 16.9 -> 22.6 ms)
                     m &= m - 1;
                 }
                 running += __builtin_amdgcn_readlane(incl, 63);
             }
         }
     }
-    __syncthreads();
+    lds_barrier();  // not __syncthreads(): nobody in the workgroup reads the list back, why wait for its stores
     return total;
 }
 

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
     __shared__ __attribute__((aligned(16))) unsigned short pref[SYM ? 8 : NWORD];
     __shared__ __attribute__((aligned(16))) acc_t vals[SYM ? 8 : CAP];
     __shared__ int4 l_meta[LCAP];
-    __shared__ real l_av[LCAP];
+    __shared__ real l_av[SYM ? 8 : LCAP];  // (the symbolic twin carries no values)
     __shared__ int s_row, s_nlong, s_cut, s_ntile;
     __shared__ int s_wsum[NW];
     __shared__ long long s_off;
@@ -102,14 +102,22 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
         if (!SYM && list_work > 0 && list_wanted(row_nnz, row_prod[rid], list_work) &&
             (list_off == nullptr || list_off[rid] >= 0))
             continue;
+        // numeric, tcol != nullptr and a list for this row: LIST-DRIVEN tiles (below)
+        const int *__restrict__ rlist = nullptr;
+        if (!SYM && tcol != nullptr) {  // (list_off == nullptr: a numeric-only re-run, the list is C.col itself)
+            if (list_off == nullptr) rlist = tcol + pos;
+            else if (list_off[rid] >= 0) rlist = tcol + list_off[rid];
+        }
         bool listing = false;
         if (SYM && tcol != nullptr) {
             const int np = row_prod[rid];
             const int lcap = np < span ? np : span;
-            listing = list_wanted(lcap, np, list_work);
+            // list_work < 0: a list for every row that can be heavy in the numeric phase (the list-driven tiles of
+            // this kernel's numeric twin); > 0: only the rows the listed kernel will take (common.h: list_wanted)
+            listing = list_work < 0 ? np > kListMinNnz : list_wanted(lcap, np, list_work);  // (-2: diagnostics, no stores)
             if (listing && threadIdx.x == 0) {
                 s_off = (long long)atomicAdd(&bs->list_cursor, (unsigned long long)lcap);
-                list_off[rid] = s_off;
+                list_off[rid] = list_work == -2 ? -1 : s_off;
             }
         }
         const int a_beg = arpt[rid], alen = arpt[rid + 1] - a_beg;
@@ -127,7 +135,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             const bool fits = li + V <= LCAP;
             for (int v = 0; v < V && li + v < LCAP; v++) {
                 l_meta[li + v] = fits ? make_int4(cur + 64 * v, end, 64 * V, 0) : make_int4(0, 0, 64, 0);
-                l_av[li + v] = av;
+                if (!SYM) l_av[li + v] = av;
             }
             return !fits;  // true: lane-serial
         };
@@ -163,11 +171,28 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             t_acc[11] += alen;
             t_acc[12] += s_nlong > LCAP;
         }
-        while (t_lo < row_end) {
+        // LIST-DRIVEN tiles (round 3): the symbolic phase has written the row's sorted columns (common.h:
+        // bits_to_list), so a tile needs neither pass 1 nor the scan nor the cut: its bitmap is set from the
+        // next <= CAP entries of the list (coalesced), the prefix of a bitmap word is the list position of the
+        // word's first entry (a plain store by the thread that holds it: every word that is ever looked up has
+        // one), the tile starts AT the next listed column and its columns leave as a copy of the list.  One
+        // cursor walk per tile instead of two: 14.7 -> 7.9 us per tile, R-MAT-22 numeric heavy bin 41 -> 30 ms.
+        //
+        // Tiles BY ENTRIES were tried as well: the next ~11 K entries of the list whatever width they span -- a thin
+        // R-MAT-22 row is 2 tiles instead of 8.6 -- as columns + accumulators in the same LDS, a product's
+        // accumulator found by a bucket table over 2048 column ranges and a short binary search.  360 K tiles instead
+        // of 726 K, and the heavy bin took 36.5 ms against 34.1 on the same box: a tile of four times the products
+        // is four times the dependent steps of the cursor walk, the search diverges in the dense low-column stretch
+        // of a power-law row -- and the second code path cost the WHOLE kernel its registers (50 scratch
+        // instructions: the rows without a list went from 41 to 57 ms).  Removed.
+        if (!SYM && rlist != nullptr) t_lo = rlist[0];
+        while (SYM || rlist == nullptr ? t_lo < row_end : pos - pos0 < row_nnz) {
             // Pass 1 runs to t_max and everything beyond the cut is walked again by the next tile,
             // so t_max aims at ~7/8 of CAP columns at the density of what is left of the row.
             int t_max;
-            if (SYM) {
+            if (!SYM && rlist != nullptr) {
+                t_max = row_end - t_lo <= W ? row_end : t_lo + W;
+            } else if (SYM) {
                 t_max = row_end - t_lo <= W ? row_end : t_lo + W;
             } else {
                 const long long rem_nnz = row_nnz - (pos - pos0), rem_span = row_end - t_lo;
@@ -251,7 +276,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                     for (int j = 0; j < SB; j++) {
                         const int i = i0 + j * NW;
                         if (i >= nlong) continue;
-                        const real av = l_av[i];
+                        const real av = SYM ? (real)0 : l_av[i];
                         int k = mt[j].x, c = col[j];
                         real x = bv[j];
                         while (true) {
@@ -326,10 +351,37 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             if (SYM) {  // one committing walk that only sets bits, then count (list) and clear
                 walk(std::true_type{}, t_max);
                 lds_barrier();
-                sym_cnt += bits_to_list<BS, true>(bits, NWORD, t_lo, listing ? tcol + s_off + sym_cnt : (int *)nullptr, s_wsum);
+                sym_cnt += bits_to_list<BS, true>(bits, NWORD, t_lo, listing ? tcol + s_off + sym_cnt : (int *)nullptr, s_wsum,
+                                                  list_work == -2);
                 t_lo = t_max;
                 continue;
             }
+            int t_hi_l = 0, ntile_l = 0;
+            if (rlist != nullptr) {
+                const int k0 = pos - pos0;
+                const int cnt = row_nnz - k0 < CAP ? row_nnz - k0 : CAP;
+                if (threadIdx.x == 0) {
+                    s_ntile = cnt;  // unless an entry beyond the window says otherwise (below)
+                    s_cut = k0 + cnt < row_nnz ? rlist[k0 + cnt] : row_end;
+                }
+                lds_barrier();
+                for (int k = threadIdx.x; k < cnt; k += BS) {
+                    const int c = rlist[k0 + k];
+                    if (c < t_max) {
+                        const unsigned int idx = (unsigned int)(c - t_lo);
+                        atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+                        const int cp = k > 0 ? rlist[k0 + k - 1] : -1;
+                        if (k == 0 || ((unsigned int)(cp - t_lo) >> 5) != (idx >> 5)) pref[idx >> 5] = (unsigned short)k;
+                    } else if (k == 0 || rlist[k0 + k - 1] < t_max) {
+                        s_ntile = k;   // the first entry beyond the window ends the tile (one thread sees it)
+                        s_cut = t_max;
+                    }
+                }
+                lds_barrier();
+                t_hi_l = s_cut;
+                ntile_l = s_ntile;
+                tick(t_lo == lo ? 7 : 1);
+            } else {
             walk(std::false_type{}, t_max);
             lds_barrier();
             tick(t_lo == lo ? 7 : 1);
@@ -390,14 +442,18 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                 s_ntile = total;
             }
             lds_barrier();
-            const int t_hi = s_cut, ntile = s_ntile;
+            }  // pass 1 + scan (rows without a list)
+            const int t_hi = rlist ? t_hi_l : s_cut, ntile = rlist ? ntile_l : s_ntile;
             tick(2);
             if (prof && t_hi != t_max) t_acc[9]++;
             walk(std::true_type{}, t_hi);
             lds_barrier();
             tick(t_lo == lo ? 8 : 3);
             // ---- emission (words and prefixes are read back: not kept live across pass 2) ------
-            if (write_col & 1) {
+            if ((write_col & 1) && rlist != nullptr) {
+                const int k0 = pos - pos0;
+                for (int r = threadIdx.x; r < ntile; r += BS) ccol[pos + r] = rlist[k0 + r];
+            } else if (write_col & 1) {
 #pragma unroll
                 for (int j = 0; j < WPT; j++) {
                     unsigned int m = bits[threadIdx.x + j * BS];
@@ -418,7 +474,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
 #pragma unroll
             for (int j = 0; j < WPT; j++) bits[threadIdx.x + j * BS] = 0;
             pos += ntile;
-            t_lo = t_hi;
+            t_lo = (rlist != nullptr && pos - pos0 < row_nnz) ? rlist[pos - pos0] : t_hi;
             lds_barrier();
             tick(4);
             if (prof) t_acc[5]++;

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(BS) void k_sym_small(const int *__restrict__ arpt,
 // bins 1..5: one workgroup per row (set_row_nz_bin_each_tb :399-472; LARGE = the try-in-LDS
 // kernel with a fail list, set_row_nz_bin_each_tb_large :474-554).
 #ifndef NSP_FLAT_SYM_MIN_T
-#define NSP_FLAT_SYM_MIN_T 8192
+#define NSP_FLAT_SYM_MIN_T 512
 #endif
 template <int BS, int TMAX, bool LARGE, int COOP = 0>
 __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,

@@ -122,7 +122,8 @@ __global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, c
                                                  const int *__restrict__ row_span,
                                                  int *__restrict__ row_nz, int bin_off, int bin_size,
                                                  int bnnz, BinState *bs = nullptr, int *__restrict__ tcol = nullptr,
-                                                 long long *__restrict__ list_off = nullptr, long long list_work = 0)
+                                                 long long *__restrict__ list_off = nullptr, long long list_work = 0,
+                                                 int dens = 0, int tiled_w = 0)
 {
     // tcol != nullptr: the row's columns are written out as a sorted list for the numeric phase (common.h:
     // bits_to_list), list_off[rid] = where
@@ -140,7 +141,15 @@ __global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, c
     const int np = row_prod[rid], sp = row_span[rid];
     const int lcap = np < sp ? np : sp;
     const bool one_piece = sp <= WORDS_MAX * 32;
-    bool listing = tcol != nullptr && !one_piece && list_wanted(lcap, np, list_work);
+    // list_work < 0: every row that the numeric ranked kernel will take (more non-zeros than the hash bins hold,
+    // not dense enough for the dense tiles: the rule of k_num_tiled / k_num_ranked); > 0: the listed kernel's rows
+    auto wanted = [&](int n, bool exact) {
+        if (list_work >= 0) return list_wanted(n, np, list_work);
+        if (n <= kListMinNnz) return false;
+        const bool to_tiled = exact && dens > 0 && (long long)n * dens >= sp && sp <= 32 * tiled_w;
+        return !to_tiled;
+    };
+    bool listing = tcol != nullptr && !one_piece && wanted(lcap, false);
     if (listing && threadIdx.x == 0) {
         s_off = (long long)atomicAdd(&bs->list_cursor, (unsigned long long)lcap);
         list_off[rid] = s_off;
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(BS) void k_sym_bits(const int *__restrict__ arpt, c
         __syncthreads();  // (also orders s_off)
         if (tcol != nullptr && one_piece) {
             const int n1 = bits_to_list<BS, false>(bits, words, lo, (int *)nullptr, s_wsum);  // count first
-            if (list_wanted(n1, np, list_work)) {
+            if (wanted(n1, true)) {
                 if (threadIdx.x == 0) {
                     s_off = (long long)atomicAdd(&bs->list_cursor, (unsigned long long)n1);
                     list_off[rid] = s_off;

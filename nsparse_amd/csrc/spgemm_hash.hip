@@ -116,6 +116,16 @@ static long long list_work()
     static const long long w = getenv("NSPARSE_LIST_WORK") ? atoll(getenv("NSPARSE_LIST_WORK")) : 150000LL;
     return w;
 }
+// NSPARSE_LIST: 0 no column lists; 1 (default) lists from the symbolic CURSOR kernel only -- matrices wider than
+// 2^20 columns, where the ranked numeric tiles are bound by the width of their bitmap -- for the list-driven tiles
+// of the ranked kernel (heavy_ranked.h): R-MAT-22 numeric heavy bin 41 -> 30 ms for 5-7 ms more in the symbolic
+// kernel; 2: lists from the one-piece bit-window kernel as well (R-MAT-18: a wash) and the listed kernel
+// (listed.h) for the rows list_wanted picks
+static int list_mode()
+{
+    static const int m = getenv("NSPARSE_LIST") ? atoi(getenv("NSPARSE_LIST")) : 1;
+    return m;
+}
 
 static void *scan_exclusive(const int *in, int *out, int n, hipStream_t st)
 {
@@ -392,7 +402,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_bits<BS, WORDS>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
                            arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_lo, row_span, row_nz, \
-                           off[BIN], hist[BIN], b->nnz, d_bs, tcol, list_off, list_work());    \
+                           off[BIN], hist[BIN], b->nnz, d_bs, list_mode() == 2 ? tcol : (int *)nullptr, list_off, -1LL, 12, 12288); \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -423,7 +433,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
                            (const real *)nullptr, brpt, bcol, (const real *)nullptr, (const int *)nullptr,
                            (int *)nullptr, (real *)nullptr, row_perm, off[10], rows, d_bs, row_lo, row_span, slab,
                            stride_ints, amax, 0, sym_long_len, -1, 0, (unsigned long long *)nullptr, row_nz, tcol, list_off,
-                           list_work(), (const int *)row_prod);
+                           getenv("NSPARSE_LIST_DRY") ? -2LL : -1LL, (const int *)row_prod);
         NSP_LAUNCH_CHECK();
         L.end(10);
         L.free_later(slab);
@@ -593,7 +603,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                        brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows, d_bs,   \
                        row_lo, row_span, slab, stride_ints, amax, write_col, long_len, ranked_dens,                 \
                        tile_sel == 0 ? kTileW : (tile_sel == 3 ? kTileW / 4 : kTileW / 2), d_prof, (int *)nullptr,  \
-                       (int *)nullptr, const_cast<long long *>(list_off), list_w, row_prod)
+                       const_cast<int *>(tcol), const_cast<long long *>(list_off), list_w, row_prod)
             if (ranked_sel == 1) { NSP_RANKED(524288, 6144, 512); }
             else { NSP_RANKED(262144, kRankCap, 1024); }
 #undef NSP_RANKED
@@ -1091,8 +1101,10 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
             bm = (unsigned int *)dev_alloc(sizeof(unsigned int) * (size_t)h_sym->bm_total);
         // column lists of the bit-window rows for the numeric listed kernel (listed.h): a slab with room for
         // min(products, window) entries per such row, when that fits comfortably (NSPARSE_LIST=0: off)
-        static const bool list_on = getenv("NSPARSE_LIST") && atoi(getenv("NSPARSE_LIST")) == 1;  // opt-in: see listed.h
-        if (list_on && h_sym->list_total > 0 && h_sym->b_unsorted == 0 && h_sym->hist[kBitsBin0] + h_sym->hist[kBitsBin0 + 1] > 0) {
+        const bool list_on = list_mode() > 0;
+        const bool cursor_sym = h_sym->hist[kBitsBin0 + 1] > 0 && h_sym->max_span[kBitsBin0 + 1] > (1 << 20);  // symbolic_phase's rule
+        if (list_on && h_sym->list_total > 0 && h_sym->b_unsorted == 0 &&
+            (list_mode() == 2 ? h_sym->hist[kBitsBin0] + h_sym->hist[kBitsBin0 + 1] > 0 : cursor_sym)) {
             size_t free_b = 0, total_b = 0;
             const size_t want = sizeof(int) * (size_t)h_sym->list_total + sizeof(long long) * (size_t)M;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want <= free_b / 3 + (pooled ? (64u << 20) : 0u) &&
@@ -1216,14 +1228,14 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                           : (const int *)nullptr;
     // ---- numeric --------------------------------------------------------------------
     // (a numeric-only re-run has the list of every row: C.col itself)
-    static const bool list_rerun_on = getenv("NSPARSE_LIST") && atoi(getenv("NSPARSE_LIST")) == 1;
+    const bool list_rerun_on = list_mode() == 2;
     if (!too_big) {
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_maxb, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
                                    (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor, members, blk_desc, bkey,
-                                   numeric_only ? (const int *)c->d_col : (const int *)tcol, list_off,
-                                   (numeric_only ? list_rerun_on : tcol != nullptr) ? list_work() : 0LL);
+                                   numeric_only ? (list_mode() > 0 ? (const int *)c->d_col : (const int *)nullptr) : (const int *)tcol, list_off,
+                                   (numeric_only ? list_rerun_on : (tcol != nullptr && list_mode() == 2)) ? list_work() : 0LL);
     tm.mark(3, s0);
     {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
         const int seq = ++cx.seq;

@@ -90,6 +90,30 @@ def test_config2_cant_class(kind, label, lib_d, oracle_d):
     d.close()
 
 
+@pytest.mark.parametrize("permille", [300, 1000])
+def test_config2_cant_class_perturbed(permille, lib_d, oracle_d):
+    """The cant-class stand-in with SCALAR perturbations (kind 6): a share of the nodes gets one dof constrained
+    (row = diagonal, column gone) or loses one scalar coupling, so the rows of a node no longer share one column
+    pattern -- what boundary conditions and mixed elements do to a real FEM matrix, and what the node-block path
+    must survive: twin groups of two, look-alike rows, one-entry rows.  Structure exact, values by the reference
+    rule, numeric-only re-run, unsorted-structure invariants as for the other config-2 matrices."""
+    A = synth(lib_d, 6, 9, 9, 257 + (permille << 32), seed=0x5EED0022)
+    got, st = spgemm(lib_d, A, numeric_again=True)
+    _report(f"config2 perturbed p={permille / 1000}", "synthetic cant class (kind 6)", A, st)
+    ref = oracle_d.spgemm(A, A)
+    _structure_exact(got, ref)
+    assert oracle_d.check_spgemm(got, ref) == 0
+    assert st.n_prod * 2 == got["flop"]
+    assert np.array_equal(got["col_again"], got["col"])
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9)
+    assert 0 < st.twin_rows < 41634, "the perturbation must break some twin groups and leave others"
+    assert int((np.diff(A["rpt"]) == 1).sum()) > 0  # constrained unknowns
+    d = DeviceAMB(lib_d, A)
+    x = _spmv_x(lib_d, A["N"])
+    assert oracle_d.ans_check(oracle_d.csr_spmv(A["rpt"], A["col"], A["val"], x), d.spmv(x)) == 0
+    d.close()
+
+
 # ------------------------------------------------------------------------------ config 3
 def test_config3_webbase_class_fp32(lib_s, oracle_s, oracle_d):
     """webbase-1M: 1,000,005 rows, 3,105,536 nnz, ~69.5 M products, ~51.1 M nnz(C), power law,

@@ -393,7 +393,7 @@ def test_twin_rows_take_their_leaders_structure(prec, lib_d, lib_s, oracle_d, or
     assert sum(st.sym_bin_size) + st.twin_rows == m and sum(st.num_bin_size) == m
     assert_parity(orc, got, ref)
     assert np.array_equal(got["col_again"], got["col"])
-    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9 if prec == "d" else 2e-5)
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9 if prec == "d" else 2e-6)
     got0, st0 = spgemm_subprocess(A, {"NSPARSE_TWINS": "0"}, prec=prec, B=B)
     assert sum(st0["sym"]) == m
     assert np.array_equal(got0["rpt"], got["rpt"]) and np.array_equal(got0["col"], got["col"])
@@ -574,7 +574,7 @@ def test_keyed_runs_of_twin_b_rows(prec, lib_d, lib_s, oracle_d, oracle_s):
     assert_parity(orc, got, orc.spgemm(A, A))
     got0, _ = spgemm_subprocess(A, {"NSPARSE_KEYED": "0"}, prec=prec)
     assert np.array_equal(got0["rpt"], got["rpt"]) and np.array_equal(got0["col"], got["col"])
-    np.testing.assert_allclose(got0["val"], got["val"], rtol=1e-9 if prec == "d" else 2e-5)
+    np.testing.assert_allclose(got0["val"], got["val"], rtol=1e-9 if prec == "d" else 2e-6)
     # same shape, same nnz, other structure: last column of every 7th row moved to a free place
     B = dict(A, col=A["col"].copy())
     rpt, n = A["rpt"], A["N"]

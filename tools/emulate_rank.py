@@ -17,6 +17,7 @@ from gpu_util import synth  # noqa: E402
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rank = int(sys.argv[2]) if len(sys.argv) > 2 else world // 2
 lib = ns.load("d")
+lib.nsparse_set_bin_timing(1)  # the phase times of the statistics are recorded only on request
 rows = 62451
 nz = 257 * world
 B = synth(lib, 0, 9, 9, nz, seed=0x5EED0022)

@@ -1,0 +1,10 @@
+#!/bin/bash
+export TMPDIR=/tmp
+for c in rmat22 rmat18 webbase1m; do
+  for l in 0 1; do
+    echo "=== $c LIST=$l"; NSPARSE_LIST=$l timeout 300 python tools/run_configs.py $c 2>&1 | tail -1 | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print({k:d.get(k) for k in ('ms','gflops','rpt_ok','col_ok','val_fails')})"
+  done
+done
+NSPARSE_LIST=1 timeout 300 python tools/one_call_cfg.py rmat22 3 2>&1 | tail -1 | cut -c1-700
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -vE "^Read mtx" | tail -5
