@@ -108,161 +108,7 @@ __global__ __launch_bounds__(BS) void k_num_small(const int *__restrict__ arpt,
     }
 }
 
-// Value of lane (l ^ J): upper / lower half exchange by v_permlane32_swap (VALU), smaller
-// distances by ds_swizzle (LDS crossbar, no memory access).
-template <int J>
-__device__ __forceinline__ int lane_xor(int v)
-{
-    if constexpr (J == 32) {
-        const auto r = __builtin_amdgcn_permlane32_swap((unsigned int)v, (unsigned int)v, false, false);
-        return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
-    } else {
-        return __builtin_amdgcn_ds_swizzle(v, (J << 10) | 0x1f);  // bit-mask mode: and 0x1f, xor J
-    }
-}
-
-// The compare-exchange stages at partner distances J, J/2, ..., 1 of merge size k on the 128
-// elements of one wavefront's segment, held two per lane: r0 = element e0 = seg*128 + lane,
-// r1 = element e0 + 64.
-template <int J>
-__device__ __forceinline__ void bitonic_stages_reg(int &r0, int &r1, int e0, int k, int lane)
-{
-    if constexpr (J == 64) {
-        const bool up = (e0 & k) == 0;
-        const int lo = r0 < r1 ? r0 : r1, hi = r0 < r1 ? r1 : r0;
-        r0 = up ? lo : hi;
-        r1 = up ? hi : lo;
-    } else {
-        const bool lower = (lane & J) == 0;
-        const int q0 = lane_xor<J>(r0), q1 = lane_xor<J>(r1);
-        const bool min0 = lower == ((e0 & k) == 0), min1 = lower == (((e0 + 64) & k) == 0);
-        r0 = min0 ? (r0 < q0 ? r0 : q0) : (r0 < q0 ? q0 : r0);
-        r1 = min1 ? (r1 < q1 ? r1 : q1) : (r1 < q1 ? q1 : r1);
-    }
-    if constexpr (J > 1) bitonic_stages_reg<J / 2>(r0, r1, e0, k, lane);
-}
-
-// The same for big sorts: 512 elements per wavefront, eight consecutive ones per lane
-// (element = seg*512 + lane*8 + i).  Distances 4, 2, 1 are inside the thread, 8 ... 256 are lane
-// exchanges (lane ^ J/8): only distances of 512 and more cross wavefronts.
-template <int J>
-__device__ __forceinline__ void bitonic_stages_reg8(int (&r)[8], int ebase, int k, int lane)
-{
-    if constexpr (J >= 8) {
-        constexpr int L = J / 8;
-        const bool lower = (lane & L) == 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int q = lane_xor<L>(r[i]);
-            const bool mn = lower == (((ebase + i) & k) == 0);
-            r[i] = mn ? (r[i] < q ? r[i] : q) : (r[i] < q ? q : r[i]);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            if ((i & J) == 0) {
-                const bool up = ((ebase + i) & k) == 0;
-                const int a = r[i], b = r[i | J];
-                const int lo = a < b ? a : b, hi = a < b ? b : a;
-                r[i] = up ? lo : hi;
-                r[i | J] = up ? hi : lo;
-            }
-        }
-    }
-    if constexpr (J > 1) bitonic_stages_reg8<J / 2>(r, ebase, k, lane);
-}
-
-// In-LDS bitonic sort of P (power of two) ints, ascending.  Stages whose partner distance is below
-// 128 stay inside one wavefront's 128-element segment: the segment is taken into registers (two
-// elements per lane), the stages run on lane exchanges, and it is written back -- the first
-// version did every one of them as two LDS reads and two conditional LDS writes.  Only the wider
-// stages go through LDS with a workgroup barrier.
-template <int BS>
-__device__ __forceinline__ void bitonic_sort_lds(int *s, int P)
-{
-    const int lane = threadIdx.x & 63;
-    const int wid = threadIdx.x >> 6;
-    constexpr int NW = BS / 64;
-    // compare-exchange of pair number t at partner distance j inside merge size k
-    auto cex = [&](int t, int j, int k) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int p = i | j;
-        const int a = s[i], b = s[p];
-        const bool up = (i & k) == 0;
-        if ((a > b) == up) { s[i] = b; s[p] = a; }
-    };
-    if (P >= 1024) {  // big sorts: 512-element register segments, LDS only for distances >= 512
-        auto load8 = [&](int ebase, int(&r)[8]) {
-            const int4 a = *reinterpret_cast<const int4 *>(s + ebase), b = *reinterpret_cast<const int4 *>(s + ebase + 4);
-            r[0] = a.x, r[1] = a.y, r[2] = a.z, r[3] = a.w, r[4] = b.x, r[5] = b.y, r[6] = b.z, r[7] = b.w;
-        };
-        auto store8 = [&](int ebase, const int(&r)[8]) {
-            *reinterpret_cast<int4 *>(s + ebase) = make_int4(r[0], r[1], r[2], r[3]);
-            *reinterpret_cast<int4 *>(s + ebase + 4) = make_int4(r[4], r[5], r[6], r[7]);
-        };
-        for (int seg = wid; seg * 512 < P; seg += NW) {
-            const int ebase = seg * 512 + lane * 8;
-            int r[8];
-            load8(ebase, r);
-            bitonic_stages_reg8<1>(r, ebase, 2, lane);
-            bitonic_stages_reg8<2>(r, ebase, 4, lane);
-            bitonic_stages_reg8<4>(r, ebase, 8, lane);
-            bitonic_stages_reg8<8>(r, ebase, 16, lane);
-            bitonic_stages_reg8<16>(r, ebase, 32, lane);
-            bitonic_stages_reg8<32>(r, ebase, 64, lane);
-            bitonic_stages_reg8<64>(r, ebase, 128, lane);
-            bitonic_stages_reg8<128>(r, ebase, 256, lane);
-            bitonic_stages_reg8<256>(r, ebase, 512, lane);
-            store8(ebase, r);
-        }
-        __syncthreads();
-        for (int k = 1024; k <= P; k <<= 1) {
-            for (int j = k >> 1; j >= 512; j >>= 1) {
-                for (int t = threadIdx.x; t < P / 2; t += BS) cex(t, j, k);
-                __syncthreads();
-            }
-            for (int seg = wid; seg * 512 < P; seg += NW) {
-                const int ebase = seg * 512 + lane * 8;
-                int r[8];
-                load8(ebase, r);
-                bitonic_stages_reg8<256>(r, ebase, k, lane);
-                store8(ebase, r);
-            }
-            __syncthreads();
-        }
-        return;
-    }
-    // phase 1: every merge size up to 128 stays inside a 128-element segment
-    for (int seg = wid; seg * 128 < P; seg += NW) {
-        const int e0 = seg * 128 + lane;
-        int r0 = e0 < P ? s[e0] : 0x7fffffff, r1 = e0 + 64 < P ? s[e0 + 64] : 0x7fffffff;
-        if (P >= 2) bitonic_stages_reg<1>(r0, r1, e0, 2, lane);
-        if (P >= 4) bitonic_stages_reg<2>(r0, r1, e0, 4, lane);
-        if (P >= 8) bitonic_stages_reg<4>(r0, r1, e0, 8, lane);
-        if (P >= 16) bitonic_stages_reg<8>(r0, r1, e0, 16, lane);
-        if (P >= 32) bitonic_stages_reg<16>(r0, r1, e0, 32, lane);
-        if (P >= 64) bitonic_stages_reg<32>(r0, r1, e0, 64, lane);
-        if (P >= 128) bitonic_stages_reg<64>(r0, r1, e0, 128, lane);
-        if (e0 < P) s[e0] = r0;
-        if (e0 + 64 < P) s[e0 + 64] = r1;
-    }
-    __syncthreads();
-    // phase 2: wide stages with workgroup barriers, then the sub-segment tail of each merge
-    for (int k = 256; k <= P; k <<= 1) {
-        for (int j = k >> 1; j >= 128; j >>= 1) {
-            for (int t = threadIdx.x; t < P / 2; t += BS) cex(t, j, k);
-            __syncthreads();
-        }
-        for (int seg = wid; seg * 128 < P; seg += NW) {
-            const int e0 = seg * 128 + lane;
-            int r0 = s[e0], r1 = s[e0 + 64];
-            bitonic_stages_reg<64>(r0, r1, e0, k, lane);
-            s[e0] = r0;
-            s[e0 + 64] = r1;
-        }
-        __syncthreads();
-    }
-}
+// (lane_xor, bitonic_stages_reg*, bitonic_sort_lds: common.h -- the symbolic hash kernels sort their lists with them too)
 
 // bins 1..4: one workgroup per row (calculate_value_col_bin_each_tb :829-927).
 template <int BS, int TMAX, int PMAX, int COOP = 0>

@@ -401,7 +401,9 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             bm_words[row] = bw;
             row_span_num[row] = 0;  // set by k_sym_dense when it hands a bitmap over
             // bit-window rows can hand their sorted column list to the numeric phase: room for it
-            const int lcap = ((bin == kBitsBin0 || bin == kBitsBin0 + 1) && ni > kListMinNnz) ? (ni < span ? ni : span) : 0;
+            // (also the rows of the two big-table hash bins that can be heavy in the numeric phase: symbolic.h)
+            const int lcap = ((bin == kBitsBin0 || bin == kBitsBin0 + 1 || bin == 3 || bin == 4) && ni > kListMinNnz)
+                                 ? (ni < span ? ni : span) : 0;
             const int al = arpt[row + 1] - arpt[row];
             if (W >= 16) {  // at most 4 rows per wave: direct LDS atomics are cheapest
                 if (bin >= 0) atomicAdd(&s_hist[bin], 1);

@@ -96,8 +96,14 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                                const int *__restrict__ row_prod,
                                                   const int *__restrict__ row_maxb,
                                                int *__restrict__ row_nz, int bin_off, int bin_size,
-                                               int bnnz, BinState *bs, int *__restrict__ fail_list, int flat_on = 1)
+                                               int bnnz, BinState *bs, int *__restrict__ fail_list, int flat_on = 1,
+                                               int *__restrict__ tcol = nullptr, long long *__restrict__ list_off = nullptr,
+                                               const int *__restrict__ row_span = nullptr, int dens = 0, int tiled_w = 0)
 {
+    // tcol != nullptr (big-table bins only): a row that will be heavy in the numeric phase -- more non-zeros than
+    // the LDS hash bins take, not dense enough for the dense tiles -- also leaves its columns as a sorted list for
+    // the list-driven tiles of the ranked kernel (heavy_ranked.h): compacted in place, sorted by the bitonic
+    // network of the numeric bins, one returning atomic for its place in the slab.
     __shared__ __attribute__((aligned(16))) int tab[TMAX];
     __shared__ int2 s_ext[LARGE ? 1 : BS];
     __shared__ DeferList<false, (LARGE ? 32 : (TMAX / 32 > 32 ? TMAX / 32 : 32))> s_defer;
@@ -161,6 +167,45 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
             fail_list[atomicAdd(&bs->fail_count, 1)] = rid;
         } else {
             row_nz[rid] = nz;
+        }
+    }
+    if constexpr (!LARGE && TMAX >= 8192) {
+        const int nz = s_nz;
+        bool want = tcol != nullptr && nz > kListMinNnz;
+        if (want) {
+            const int sp = row_span[rid];
+            want = !(dens > 0 && (long long)nz * dens >= sp && sp <= 32 * tiled_w);  // k_num_tiled's rows need no list
+        }
+        if (want) {
+            constexpr int SPT = TMAX / BS, NWV = BS / 64;
+            __shared__ int s_ws[NWV];
+            __shared__ long long s_off;
+            int keys[SPT], mine = 0;
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                const int i = (int)threadIdx.x * SPT + j;
+                keys[j] = i < T ? tab[i] : -1;
+                mine += keys[j] != -1;
+            }
+            const int incl = wave_incl_scan(mine);
+            if ((threadIdx.x & 63) == 63) s_ws[threadIdx.x >> 6] = incl;
+            if (threadIdx.x == 0) {
+                s_off = (long long)atomicAdd(&bs->list_cursor, (unsigned long long)nz);
+                list_off[rid] = s_off;
+            }
+            __syncthreads();  // every slot has been read: the table may be overwritten
+            int at = incl - mine;
+#pragma unroll
+            for (int u = 0; u < NWV; u++) at += u < (int)(threadIdx.x >> 6) ? s_ws[u] : 0;
+#pragma unroll
+            for (int j = 0; j < SPT; j++)
+                if (keys[j] != -1) tab[at++] = keys[j];
+            const int P = pow2_ceil(nz);  // <= T: the table was sized for the products
+            for (int i = nz + threadIdx.x; i < P; i += BS) tab[i] = 0x7fffffff;
+            __syncthreads();
+            bitonic_sort_lds<BS>(tab, P);
+            int *dst = tcol + s_off;
+            for (int i = threadIdx.x; i < nz; i += BS) dst[i] = tab[i];
         }
     }
 }

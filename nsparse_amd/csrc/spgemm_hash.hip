@@ -373,7 +373,8 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
 #define NSP_SYM_TB_GO(BS, TMAX, COOPX)                                                          \
     hipLaunchKernelGGL((k_sym_tb<BS, TMAX, false, COOPX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, \
                        st, arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], \
-                       hist[bin_], b->nnz, d_bs, (int *)nullptr, g_flat)
+                       hist[bin_], b->nnz, d_bs, (int *)nullptr, g_flat, TMAX >= 8192 ? tcol : (int *)nullptr, list_off,   \
+                       row_span, 12, 12288)
 #define NSP_SYM_TB(BIN, BS, TMAX)                                                              \
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
