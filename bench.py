@@ -517,19 +517,36 @@ def main():
         xh = np.random.default_rng(1).random(N_cols + 20)
         cuts = np.array([blocks[0][0]] + [e for _, e in blocks], dtype=np.int32)
         extra = {}
-        if dl is not None:
-            h = native_handle()
-            csr = lib.csr_from_numpy(A_rows["rpt"], A_rows["col"], A_rows["val"], N_cols)
-            lib.csr_memcpy(C.byref(csr))
-            d_x = lib.dmalloc(xh.nbytes)
-            lib.h2d(d_x, xh)
-            plan = ns.sfPlan()
-            lib.init_plan(C.byref(plan))
-            rc = dl.nsparse_dist_spmv_setup(h, C.byref(csr), cuts.ctypes.data_as(ns.capi.c_int_p), d_x, C.byref(plan))
-            assert rc == 0, f"nsparse_dist_spmv_setup -> {rc}"
-            ny = int(dl.nsparse_dist_y_elems(h))
-            d_y = lib.dmalloc((ny + 64) * w)
-            lib.hip.hipMemset(d_y, 0, (ny + 64) * w)
+        native = dl is not None
+        if native:
+            # communicator, conversion and one gathered SpMV; the ranks then AGREE that all of them got that far
+            # (at N > 1 this is the first time the RCCL path runs on real links): if any rank failed, every rank
+            # takes the Python driver for this leg and the line says so -- a launch-mode fallback, never a CPU one
+            err = ""
+            try:
+                h = native_handle()
+                csr = lib.csr_from_numpy(A_rows["rpt"], A_rows["col"], A_rows["val"], N_cols)
+                lib.csr_memcpy(C.byref(csr))
+                d_x = lib.dmalloc(xh.nbytes)
+                lib.h2d(d_x, xh)
+                plan = ns.sfPlan()
+                lib.init_plan(C.byref(plan))
+                rc = dl.nsparse_dist_spmv_setup(h, C.byref(csr), cuts.ctypes.data_as(ns.capi.c_int_p), d_x, C.byref(plan))
+                assert rc == 0, f"nsparse_dist_spmv_setup -> {rc}"
+                ny = int(dl.nsparse_dist_y_elems(h))
+                d_y = lib.dmalloc((ny + 64) * w)
+                lib.hip.hipMemset(d_y, 0, (ny + 64) * w)
+                assert dl.nsparse_dist_spmv(h, d_y, d_x, 1) == 0 and dl.nsparse_dist_sync(h) == 0, \
+                    f"first gathered SpMV -> {dl.nsparse_dist_last_error()}"
+            except Exception as e:
+                if world == 1:
+                    raise
+                err = repr(e)[:200]
+            if world > 1 and max_over_ranks(1.0 if err else 0.0) > 0:
+                log(f"[rank {rank}] native multi-GPU SpMV unavailable ({err or 'another rank failed'}): Python driver for this leg")
+                native = False
+                extra_note = {"native_driver_error": err or "another rank failed"}
+        if native:
             amb = dl.nsparse_dist_amb(h).contents
             fp = int(lib.nsparse_amb_footprint_bytes(C.byref(amb))) if A_rows["M"] > 0 else 0
             ms_c, ms_c_ev, us_c = native_loop(h, d_y, d_x, 0, args.spmv_steps)
@@ -555,7 +572,8 @@ def main():
             fp = int(lib.nsparse_amb_footprint_bytes(C.byref(op.amb)))
             ms_c, ms_c_ev = time_spmv(op, x, args.spmv_steps, gather=False)
             ms_g = time_spmv(op, x, args.spmv_steps, gather=True)[0] if world > 1 else ms_c
-            extra = {"driver": "python (nsparse_amd/dist.py): smoke-test backend only"}
+            extra = {"driver": "python (nsparse_amd/dist.py)" + ("" if dl is not None else ": smoke-test backend only"),
+                     **(extra_note if dl is not None else {})}
             csr, d_x = op.csr, C.c_void_p(x.data_ptr())
 
             def local_rows():
@@ -607,7 +625,7 @@ def main():
                                        "err": int(vl.nsparse_vendor_last_error())}
             except Exception as e:
                 rep["vendor_csrmv"] = {"error": repr(e)[:160]}
-        if dl is not None:
+        if native:
             dl.nsparse_dist_destroy(h)  # releases the AMB arrays and the communicator
             lib.release_csr(csr)
             lib.dfree(d_x)

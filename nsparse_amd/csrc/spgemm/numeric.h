@@ -167,6 +167,8 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     real *s_av = s_ov.w.av;
     auto &s_defer = s_ov.w.defer;
     __shared__ int s_cnt;
+    constexpr int NBK = 512;
+    __shared__ int s_bk[FLAT ? 2 * NBK + 8 : 1];  // bucket sort of the big-table bins (common.h: table_to_sorted)
     // Big-table bins (BS >= 512): the launch may hold FEWER workgroups than rows (a multiple of 8: write_col bit 4
     // says so) and every workgroup strides over the rows of its XCD's eighth of the bin.  A workgroup per row is a
     // dispatch, a drain of the row's stores and a fresh LDS allocation per row, with one or two rows per CU and
@@ -209,8 +211,24 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     __syncthreads();
     tick(1);
 
-    // compaction: ballot + popcount inside the wave, one LDS atomic per 64 slots
     const int lane = threadIdx.x & 63;
+    const int P = pow2_ceil(n);
+    bool sorted_already = false;
+    if constexpr (FLAT) {
+        // big-table bins: the table's keys go straight into srt, sorted bucket by bucket (write_col bit 6: off)
+        if (!(write_col & 2) && !(write_col & 64)) {
+            sorted_already = table_to_sorted<BS, NBK, TMAX / BS>(keys, T, srt, s_bk);
+            if (!sorted_already) {
+                for (int i = n + threadIdx.x; i < P; i += BS) srt[i] = 0x7fffffff;
+                __syncthreads();
+                bitonic_sort_lds<BS>(srt, P);
+                sorted_already = true;
+            }
+            tick(2);
+        }
+    }
+    if (!sorted_already) {
+    // compaction: ballot + popcount inside the wave, one LDS atomic per 64 slots
     for (int base = (threadIdx.x >> 6) * 64; base < T; base += BS) {
         const int key = keys[base + lane];
         const bool occ = key != -1;
@@ -222,13 +240,13 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
             if (occ) srt[start + __popcll(m & ((1ull << lane) - 1ull))] = key;
         }
     }
-    const int P = pow2_ceil(n);
     for (int i = n + threadIdx.x; i < P; i += BS) srt[i] = 0x7fffffff;
     __syncthreads();
     tick(2);
     // write_col bit 1: unsorted output requested (cuda-cpp template<bool sort>,
     // HashSpGEMM_volta.hpp:585-604): columns leave in compaction order
     if (P > 1 && !(write_col & 2)) bitonic_sort_lds<BS>(srt, P);
+    }
     tick(3);
 
     for (int i = threadIdx.x; i < n; i += BS) {

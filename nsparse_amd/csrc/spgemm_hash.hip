@@ -538,6 +538,11 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         NSP_CHECK(hipMemsetAsync(tb_prof, 0, 8 * NB * sizeof(unsigned long long), cx.stream[0]));
         NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
     }
+    // NSPARSE_TB_BUCKET=1: the big-table hash bins sort bucket by bucket (common.h: table_to_sorted) instead of
+    // compacting and running the full bitonic network.  Measured slower on power-law rows -- R-MAT-22 bins 3 / 4:
+    // 12.7 / 11.5 ms against 8.2 / 10.8 (the buckets whose index is a power of two hold hundreds of keys each and
+    // take a wavefront 5 us apiece) -- so off by default.
+    static const int tb_bucket = getenv("NSPARSE_TB_BUCKET") ? atoi(getenv("NSPARSE_TB_BUCKET")) : 0;
     // workgroups per CU of the persistent form of the big-table hash bins (0: one workgroup per row)
     static const int tb_persist = getenv("NSPARSE_TB_PERSIST") ? atoi(getenv("NSPARSE_TB_PERSIST")) : 0;  // measured: no gain (R-MAT-22 76.1 / 76.5 / 75.3 / 76.4 ms for 0 / 1 / 2 / 4)
     constexpr int kBlkU = 4;  // tasks in flight per lane in the node-block kernel
@@ -633,7 +638,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX, COOPX>), dim3(per_ ? pers_ : full_), dim3(BS), tb_pad, st, arpt, \
                            acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, \
                            row_prod, row_maxb, off[bin_], hist[bin_], b->nnz,                    \
-                           write_col | (g_flat ? 0 : 4) | (g_flat == 2 ? 8 : 0) | (per_ ? 16 : 0), \
+                           write_col | (g_flat ? 0 : 4) | (g_flat == 2 ? 8 : 0) | (per_ ? 16 : 0) | (tb_bucket ? 0 : 64), \
                            tb_prof ? tb_prof + 8 * bin_ : nullptr);                             \
     } while (0)
 #define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \

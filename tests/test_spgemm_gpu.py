@@ -659,3 +659,31 @@ def test_non_finite_values_stay_in_their_columns(kind, dims, oracle_d):
     assert bad_ref.sum() > 0 and np.array_equal(bad_got, bad_ref), (int(bad_got.sum()), int(bad_ref.sum()))
     ok = ~bad_ref
     np.testing.assert_allclose(got["val"][ok], ref["val"][ok], rtol=1e-9)
+
+
+@pytest.mark.parametrize("bucket", ["0", "1"])
+def test_bucket_sort_of_the_big_table_bins(bucket, oracle_d):
+    """Rows of the two big-table numeric bins (683 .. 5461 non-zeros): NSPARSE_TB_BUCKET=1 sorts them bucket by
+    bucket (common.h: table_to_sorted; measured slower than the bitonic network on power-law rows, so off by default):
+    buckets of <= 64 keys by counting, <= 128 and <= 512 by the register networks, anything beyond falls back to the
+    full bitonic sort.  B is a diagonal matrix, so a row of C has exactly the columns of its
+    row of A: every path is hit by construction -- a uniform row, rows with 100 / 400 consecutive columns inside one
+    bucket, and a cluster of 3,000 columns plus one far outlier (one bucket holds nearly everything)."""
+    lib = ns.load("d")
+    N = 1 << 20
+    rng = np.random.default_rng(17)
+    rows = []
+    rows.append(np.sort(rng.choice(N, 3000, replace=False)))                                        # uniform
+    rows.append(np.unique(np.concatenate([rng.choice(N, 2500, replace=False), 40960 + np.arange(100)])))   # 128-path
+    rows.append(np.unique(np.concatenate([rng.choice(N, 4000, replace=False), 614400 + np.arange(400)])))  # 512-path
+    rows.append(np.concatenate([np.arange(3000), [N - 1]]))                                          # fallback
+    rows.append(np.sort(rng.choice(N, 900, replace=False)))                                          # 4096-slot bin
+    rows.append(np.concatenate([np.arange(5, 2005), [N - 7]]))                                       # fallback, other bin
+    rpt = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
+    A = dict(M=len(rows), N=N, rpt=rpt, col=np.concatenate(rows).astype(np.int32), val=rng.random(int(rpt[-1])) + 0.5)
+    B = dict(M=N, N=N, rpt=np.arange(N + 1, dtype=np.int32), col=np.arange(N, dtype=np.int32), val=rng.random(N) + 0.5)
+    got, st = spgemm_subprocess(A, {"NSPARSE_TB_BUCKET": bucket}, "d", B=B)
+    ref = oracle_d.spgemm(A, B)
+    assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
+    assert oracle_d.check_spgemm(got, ref) == 0
+    assert st["num"][3] + st["num"][4] == len(rows), st["num"][:8]
