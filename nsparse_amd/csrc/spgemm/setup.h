@@ -273,6 +273,39 @@ __device__ __forceinline__ int twin_probe(const int *__restrict__ arpt, const in
     return leader;
 }
 
+// Pattern leaders of the rows of B (round 3).  The keyed runs of the node-block kernel (block.h) group the
+// entries of an A row by the pattern leader of their row of B.  For C = A * A those are A's own leaders
+// (k_row_products); for a general B -- a row block of a partitioned C = A * A is that case: A has fewer rows
+// than B -- the rows of B that A reaches get their own pattern map here: W lanes sum the order-independent key
+// of a row's columns and probe the map exactly as k_row_products does for A.  tm.twin_of starts as all -1
+// (rows outside the reach keep that), table / fcnt / members as all ones.
+template <int W>
+__global__ __launch_bounds__(256) void k_b_twins(const int *__restrict__ brpt, const int *__restrict__ bcol, int K,
+                                                 const unsigned int *__restrict__ range, TwinMap tm)
+{
+    constexpr int RPB = 256 / W;
+    const int lane = threadIdx.x % W;
+    int r0 = 0, r1 = K;
+    if (range) {
+        r0 = (int)(0x7fffffffu - range[0]);
+        r1 = (int)range[1] < K ? (int)range[1] : K;
+        if (r1 <= r0) return;
+    }
+    const int nrows = r1 - r0;
+    for (int base = blockIdx.x * RPB; base < nrows; base += gridDim.x * RPB) {
+        const int q = base + (int)threadIdx.x / W;
+        const int r = q < nrows ? r0 + q : -1;
+        unsigned long long key = 0;
+        if (r >= 0) {
+            const int e = brpt[r + 1];
+            for (int k = brpt[r] + lane; k < e; k += W) key += col_key(bcol[k]);
+        }
+#pragma unroll
+        for (int o = W / 2; o >= 1; o >>= 1) key += __shfl_xor(key, o);
+        if (r >= 0) (void)twin_probe<W>(brpt, bcol, r, key, tm, lane);
+    }
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ arpt,
                                                       const int *__restrict__ acol,

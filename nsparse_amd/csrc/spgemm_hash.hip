@@ -1043,6 +1043,9 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         cx.coresident = fused_force ? kFusedMaxBlocks : census_coresident(cx, s0);
     const bool fuse = fused_on && cx.fused_ok && !numeric_only && fgrid <= kFusedMaxBlocks && fgrid <= cx.coresident;
     bool retry = false, c_rpt_ours = false;
+    char *btw_block = nullptr;     // pattern map of the rows of B (k_b_twins), general B only
+    int *b_twin_of = nullptr;
+    bool b_twins_pending = false;
     const int nparts = launch_row_products(a, b, binfo, row_prod, row_lo, row_span, bm_words,
                         use_bm ? (num_thr.rank_span > num_thr.dense_span[2] ? num_thr.rank_span : num_thr.dense_span[2]) : 0, sym_thr, d_sym, partial, row_span_num, row_nz, row_maxb, long_list, long_cnt + 1, tw, !fuse, s0);
     void *bm_scan_tmp = nullptr;
@@ -1105,6 +1108,46 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         // used by the symbolic phase alone and the numeric phase hashes
         if (use_bm && h_sym->bm_total > 0 && h_sym->bm_total < (1LL << 30))
             bm = (unsigned int *)dev_alloc(sizeof(unsigned int) * (size_t)h_sym->bm_total);
+        // A * B with B != A on a matrix whose rows share column patterns (a row block of a partitioned C = A * A):
+        // pattern leaders of the rows of B for the keyed runs of the node-block kernel, on a side stream beside
+        // the symbolic phase (setup.h: k_b_twins)
+        {
+            long long binned0 = 0;
+            for (int q = 0; q < NB; q++) binned0 += h_sym->hist[q];
+            static const bool keyed_b_on = !(getenv("NSPARSE_KEYED") && atoi(getenv("NSPARSE_KEYED")) == 0) &&
+                                           !(getenv("NSPARSE_KEYED_B") && atoi(getenv("NSPARSE_KEYED_B")) == 0);
+            if (keyed_b_on && find_twins && lean_on && fuse && !same_shape && K > 1 && (M - binned0) * 8 >= M) {
+                unsigned int tsb = 1024;
+                while (tsb < 2u * (unsigned int)K) tsb <<= 1;
+                const size_t words64 = (size_t)tsb + ((size_t)K * (1 + kGroupMembers) + 1) / 2;  // table | fcnt | members
+                const size_t bytes = sizeof(unsigned long long) * words64 + sizeof(int) * (size_t)K + (size_t)K;
+                btw_block = (char *)dev_alloc(bytes);
+                unsigned long long *tb = (unsigned long long *)btw_block;
+                int *fc = (int *)(tb + tsb);
+                b_twin_of = (int *)(btw_block + sizeof(unsigned long long) * words64);
+                const TwinMap tmb = {tb, tsb - 1, b->nnz, b_twin_of, (unsigned char *)(b_twin_of + K), fc, fc + K};
+                hipStream_t sb = cx.stream[kMaxBins - 1];  // (no bin of either ladder runs there)
+                NSP_CHECK(hipEventRecord(cx.ev_fork, s0));
+                NSP_CHECK(hipStreamWaitEvent(sb, cx.ev_fork, 0));
+                NSP_CHECK(hipMemsetAsync(btw_block, 0xff, bytes, sb));
+                const unsigned int *rg = (M < K && a->nnz > 0) ? reinterpret_cast<const unsigned int *>(long_cnt + 2)
+                                                               : (const unsigned int *)nullptr;
+                const int wb = pick_w_regular(b->nnz, K, b->nnz_max);
+                int gb = ceil_div((long long)(M < K ? M + 4096 : K) * wb, 256);
+                gb = gb < 1 ? 1 : (gb > 16384 ? 16384 : gb);
+#define NSP_BT(W)                                                                              \
+    case W:                                                                                    \
+        hipLaunchKernelGGL(k_b_twins<W>, dim3(gb), dim3(256), 0, sb, b->d_rpt, b->d_col, K, rg, tmb); \
+        break;
+                switch (wb) {
+                    NSP_BT(1) NSP_BT(2) NSP_BT(4) NSP_BT(8) NSP_BT(16) NSP_BT(32) NSP_BT(64)
+                }
+#undef NSP_BT
+                NSP_LAUNCH_CHECK();
+                NSP_CHECK(hipEventRecord(cx.ev_join[kMaxBins - 1], sb));
+                b_twins_pending = true;
+            }
+        }
         // column lists of the bit-window rows for the numeric listed kernel (listed.h): a slab with room for
         // min(products, window) entries per such row, when that fits comfortably (NSPARSE_LIST=0: off)
         const bool list_on = list_mode() > 0;
@@ -1228,10 +1271,12 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // C = A * A on a matrix whose twin rows are mostly NOT neighbours (k_numeric_setup counted them): the
     // node-block kernel builds its runs of B rows from the pattern leaders instead of from neighbouring entries
     static const bool keyed_on = !(getenv("NSPARSE_KEYED") && atoi(getenv("NSPARSE_KEYED")) == 0);
-    const int *bkey = (keyed_on && fuse && grp && twin_of && same_shape && h_num->ab_differ == 0 &&
-                       (long long)h_num->far_twins * 4 > (long long)S.twin_rows)
-                          ? (const int *)twin_of
-                          : (const int *)nullptr;
+    const int *bkey = nullptr;
+    if (keyed_on && fuse && grp && twin_of && (long long)h_num->far_twins * 4 > (long long)S.twin_rows) {
+        if (same_shape && h_num->ab_differ == 0) bkey = twin_of;  // B is A: A's own pattern leaders
+        else if (b_twin_of) bkey = b_twin_of;                     // general B: its own (k_b_twins)
+    }
+    if (b_twins_pending) NSP_CHECK(hipStreamWaitEvent(s0, cx.ev_join[kMaxBins - 1], 0));
     // ---- numeric --------------------------------------------------------------------
     // (a numeric-only re-run has the list of every row: C.col itself)
     const bool list_rerun_on = list_mode() == 2;
@@ -1268,6 +1313,10 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     }  // !retry
 
     dev_free(scan_tmp);
+    if (btw_block) {
+        if (retry || too_big) NSP_CHECK(hipStreamSynchronize(cx.stream[kMaxBins - 1]));  // (else the call drained behind the join)
+        dev_free(btw_block);
+    }
     dev_free(tcol);
     dev_free(list_off);
     dev_free(bm);

@@ -687,3 +687,24 @@ def test_bucket_sort_of_the_big_table_bins(bucket, oracle_d):
     assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
     assert oracle_d.check_spgemm(got, ref) == 0
     assert st["num"][3] + st["num"][4] == len(rows), st["num"][:8]
+
+
+def test_keyed_runs_for_a_general_b(oracle_d):
+    """A * B with B != A, both finite-element matrices whose twin rows are scattered (kind 5, different
+    renumberings): the node-block kernel gets the pattern leaders of B's rows from k_b_twins (setup.h) instead of
+    from A's own map; and a row block of A times the whole A (what a rank of the partitioned product computes)."""
+    lib = ns.load("d")
+    A = synth(lib, 5, 6, 6, 40, seed=11)
+    B = synth(lib, 5, 6, 6, 40, seed=12)
+    assert A["M"] == B["M"] and not np.array_equal(A["col"][:200], B["col"][:200])
+    got, st = spgemm(lib, A, B)
+    ref = oracle_d.spgemm(A, B)
+    assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
+    assert oracle_d.check_spgemm(got, ref) == 0
+    from nsparse_amd.dist import csr_row_block
+    blk = csr_row_block(A, 1024, 3000)
+    got, st = spgemm(lib, dict(blk, N=A["M"]), A)
+    ref = oracle_d.spgemm(dict(blk, N=A["M"]), A)
+    assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
+    assert oracle_d.check_spgemm(got, ref) == 0
+    assert st.twin_rows > 0
