@@ -267,7 +267,20 @@ struct BinLauncher {
             side_bins = true;
         }
     }
-    hipStream_t stream_of(int b) const { return (serial || b == main_bin) ? cx->stream[0] : cx->stream[b]; }
+    // bin b runs on stream[b], the main bin on stream[0] -- which IS bin 0's own stream: when a big-LDS bin of a few
+    // rows is the main one, bin 0's kernel queues behind it (webbase-1M class: the 549 K rows of k_num_small wait
+    // 1.46 ms for the heavy kernel and then run alone for 0.15 ms).  NSPARSE_BIN0_SWAP=1 gives bin 0 the main bin's
+    // stream instead.  Measured on that matrix, same box, three runs each: 2.40 / 2.40 / 2.41 ms as is, 2.52 / 2.46 /
+    // 2.46 swapped -- the call is bound by the dependent-load chain of its longest heavy row (0.36 ms alone, 1.46 ms
+    // beside the other bins: memory latency under load), and a million more small rows in flight stretch it
+    // further.  So the queueing stays.
+    hipStream_t stream_of(int b) const
+    {
+        static const bool swap0 = getenv("NSPARSE_BIN0_SWAP") && atoi(getenv("NSPARSE_BIN0_SWAP")) == 1;
+        if (serial || b == main_bin) return cx->stream[0];
+        if (b == 0 && main_bin > 0 && swap0) return cx->stream[main_bin];
+        return cx->stream[b];
+    }
     void fork()
     {
         if (!serial && side_bins) NSP_CHECK(hipEventRecord(cx->ev_fork, cx->stream[0]));
@@ -290,7 +303,7 @@ struct BinLauncher {
     {
         for (int b = 0; b < NB; b++) {
             if (!used[b] || stream_of(b) == cx->stream[0]) continue;
-            NSP_CHECK(hipEventRecord(cx->ev_join[b], cx->stream[b]));
+            NSP_CHECK(hipEventRecord(cx->ev_join[b], stream_of(b)));
             NSP_CHECK(hipStreamWaitEvent(cx->stream[0], cx->ev_join[b], 0));
         }
     }
