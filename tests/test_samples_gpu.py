@@ -142,3 +142,17 @@ def test_webbase_class_general_and_pattern_files(tmp_path, oracle_s):
     gotb = lib.csr_host_to_numpy(m)
     lib.release_cpu_csr(m)
     assert np.array_equal(gotb["rpt"], B["rpt"]) and np.array_equal(gotb["col"], B["col"]) and (gotb["val"] == 1.0).all()
+
+
+@pytest.mark.parametrize("prec", ["d", "s"])
+def test_amb_dist_cli_on_one_gpu(prec, tmp_path):
+    """amb_dist_{d,s}: the multi-GPU twin of amb_{d,s} (one thread per GPU, include/nsparse_dist.h) with one GPU:
+    partition, row block, conversion, the native timed loops, 'Correct' from ans_check against csr_kernel."""
+    lib = ns.load(prec)
+    A, path = _write_standin(tmp_path, lib, 0, (6, 6, 30), 0, "brick_general.mtx")
+    out = run(f"amb_dist_{prec}", path, "1")
+    assert f"rank 0: rows [0, {A['M']})  nnz {A['nnz']}" in out
+    assert re.search(r"SpMV using AMB format on 1 GPUs: .*brick_general\.mtx, [\d.]+\[GFLOPS\], [\d.]+\[ms\]", out)
+    assert "Calculation Result is Correct" in out
+    out = run(f"amb_dist_{prec}", MTX, "1", "65536", "1")
+    assert "Calculation Result is Correct" in out
