@@ -92,8 +92,11 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                                                   unsigned long long *__restrict__ prof,
                                                   const int *__restrict__ members,
                                                   const int4 *__restrict__ desc,
-                                                  const int *__restrict__ bkey)
+                                                  const int *__restrict__ bkey, int seg1 = 0x7fffffff,
+                                                  int bin_off2 = 0)
 {
+    // seg1 / bin_off2: the launch covers TWO stretches of the row list -- the first seg1 rows at bin_off, the rest
+    // at bin_off2 (two neighbouring window bins folded into one launch: spgemm_hash.hip, NSPARSE_FOLD_WIN).
     // KEYED (C = A * A with twin rows that are NOT neighbours): bkey[c] = pattern leader of row c of B or
     // -1; the entries of an A row whose rows of B share a pattern form a run wherever they sit in the row
     // (grouped by counting among the parked entries), instead of only when they are neighbours.
@@ -136,13 +139,13 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
     __shared__ unsigned int s_ent[KEYED ? PARK : 1];
     __shared__ int s_key[KEYED ? PARK : 1];  // later: the run an entry's leader opened
     int *s_runof = s_key;
-    const int slot = xcd_row_slot(bin_size);
-    if (slot < 0) return;
+    const int slot0 = xcd_row_slot(bin_size);
+    if (slot0 < 0) return;
+    const int slot = slot0 < seg1 ? bin_off + slot0 : bin_off2 + (slot0 - seg1);  // position in the row list
     int rid, RA, lo, span, maxb, bmo = 0, alen;
     int off[kBlkRows], a_beg[kBlkRows];
     if (desc) {
-        const int4 d0 = desc[3 * (bin_off + slot)], d1 = desc[3 * (bin_off + slot) + 1],
-                   d2 = desc[3 * (bin_off + slot) + 2];
+        const int4 d0 = desc[3 * slot], d1 = desc[3 * slot + 1], d2 = desc[3 * slot + 2];
         rid = d0.x, lo = d0.y, span = d0.z, maxb = d0.w;
         bmo = d1.x, a_beg[0] = d1.y, alen = d1.z, RA = d1.w;
         off[0] = crpt[rid];
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
         a_beg[1] = RA > 1 ? arpt[d2.x] : 0;
         a_beg[2] = RA > 2 ? arpt[d2.y] : 0;
     } else {
-        rid = row_perm[bin_off + slot];
+        rid = row_perm[slot];
         const int gcode = grp ? (int)grp[rid] : (1 << 2);
         if (gcode & 3) return;  // a follower: its group head computes this row
         RA = gcode >> 2;

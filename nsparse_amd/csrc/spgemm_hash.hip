@@ -681,10 +681,13 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         allow_big_lds(k_num_block<BS, SPAN, MODEX, kBlkU, KEYEDX>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
         /* followers of a group head are not listed (k_bin_scatter): listed[bin] heads */        \
         const int heads = grp ? listed[bin_] : hist[bin_];                                     \
-        hipLaunchKernelGGL((k_num_block<BS, SPAN, MODEX, kBlkU, KEYEDX>), dim3(8 * ceil_div(heads, 8)), dim3(BS), \
+        /* fold6_: the rows of bin 6 ride along (their stretch of the list first) */             \
+        const int heads6 = fold6_ ? (grp ? listed[6] : hist[6]) : 0;                            \
+        hipLaunchKernelGGL((k_num_block<BS, SPAN, MODEX, kBlkU, KEYEDX>), dim3(8 * ceil_div(heads + heads6, 8)), dim3(BS), \
                            lds_blk, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
-                           c->d_val, row_perm, row_maxb, row_lo, row_span, off[bin_],            \
-                           heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members, desc, bkey); \
+                           c->d_val, row_perm, row_maxb, row_lo, row_span, fold6_ ? off[6] : off[bin_], \
+                           heads + heads6, b->nnz, bm_off, bm, grp, btwin, blk_prof, members, desc, bkey, \
+                           fold6_ ? heads6 : 0x7fffffff, off[bin_]);                           \
     }
 // keyed runs (twin rows of B that are not neighbours): the default 128-thread, full-call form only
 #define NSP_NUM_BLOCK_GO(BS, SPAN, MODEX)                                                       \
@@ -693,8 +696,9 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         else NSP_NUM_BLOCK_GO2(BS, SPAN, MODEX, false)                                         \
     }
 #define NSP_NUM_DENSE(BIN, BS, SPAN)                                                            \
-    if (hist[BIN] > 0 && now(BIN)) {                                                           \
+    if (hist[BIN] > 0 && now(BIN) && !(BIN == 6 && fold6)) {                                   \
         constexpr int bin_ = BIN;                                                              \
+        const bool fold6_ = BIN == 7 && fold6;                                                 \
         hipStream_t st = L.begin(BIN);                                                         \
         const int span_b = max_span[BIN] < SPAN ? max_span[BIN] : SPAN;                        \
         const int stride_b = (span_b + 63) / 64 * 64 + 8;                                      \
@@ -731,6 +735,14 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     const int tune_nd6 = env_nd6 ? env_nd6 : (blk ? 128 : 256);
     const int tune_nd7 = env_nd7 ? env_nd7 : (blk ? 128 : 256);
     const int tune_nd8 = env_nd8 ? env_nd8 : (blk ? 128 : 512);
+    // Two window bins of a finite-element matrix in ONE launch (NSPARSE_FOLD_WIN=1; off by default): when the
+    // node-block kernel serves both bin 6 (windows up to 1536 columns) and bin 7 (up to 4096), the 4096 instance can
+    // take the rows of bin 6 as well (the kernel sizes everything by the row's own window): one fork / join and one
+    // ramp-up less.  Measured on the irregular cant-class stand-in (42 K + 20 K rows), same box, three runs each:
+    // 0.377-0.384 ms with two launches side by side, 0.393-0.402 folded.  Two kernels that overlap hide each
+    // other's tails better than one.
+    static const bool fold_win = getenv("NSPARSE_FOLD_WIN") && atoi(getenv("NSPARSE_FOLD_WIN")) == 1;
+    const bool fold6 = fold_win && blk && tune_nd7 == 128 && tune_nd6 == 128 && hist[6] > 0 && hist[7] > 0;
     // ranked-window rows (numeric bin 9): always the node-block kernel, windows up to 65536 columns
     if (hist[kRankBin] > 0 && now(kRankBin)) {
         constexpr int bin_ = kRankBin;
