@@ -109,3 +109,36 @@ def test_random_node_block_squares(seed, lib_d, oracle_d, lib_s, oracle_s):
     assert np.array_equal(got["col_again"], got["col"])
     np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9 if lib_d.real == np.float64 else 2e-6)
     assert sum(st.sym_bin_size) + st.twin_rows == A["M"] and sum(st.num_bin_size) == A["M"]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NSPARSE_FUZZ_AB_SEEDS", "16"))))
+def test_random_node_block_products_with_another_b(seed, lib_d, oracle_d, lib_s, oracle_s):
+    """A * B on node-block matrices with B != A: a row block of A times the whole A (what a rank of the partitioned
+    product computes) and A times a second node-block matrix of the same size -- the keyed runs of the node-block
+    kernel then take the pattern leaders of B's rows from k_b_twins (setup.h), not from A's own map."""
+    if os.environ.get("NSPARSE_FUZZ_PREC", "d") == "s":
+        lib_d, oracle_d = lib_s, oracle_s
+    rng = np.random.default_rng(int(os.environ.get("NSPARSE_FUZZ_BASE", "1000")) + 104729 * seed)
+    A = _node_block_square(rng)
+    A["val"] = A["val"].astype(lib_d.real)
+    n = A["M"]
+    lo = int(rng.integers(0, max(1, n // 2)))
+    hi = int(rng.integers(lo + 1, n + 1))
+    z0, z1 = int(A["rpt"][lo]), int(A["rpt"][hi])
+    blk = dict(M=hi - lo, N=n, rpt=(A["rpt"][lo:hi + 1] - z0).astype(np.int32), col=A["col"][z0:z1], val=A["val"][z0:z1])
+    # a second matrix with the same number of unknowns: the node graph of A under another renumbering and with
+    # other values (so that its rows come in pattern classes too, in other places)
+    perm = rng.permutation(n)
+    S = sp.csr_matrix((A["val"].astype(np.float64), A["col"], A["rpt"]), shape=(n, n))[perm][:, perm].tocsr()
+    S.sort_indices()
+    B = dict(M=n, N=n, rpt=S.indptr.astype(np.int32), col=S.indices.astype(np.int32),
+             val=(rng.random(S.data.size) + 0.1).astype(lib_d.real))
+    for X, Y in ((blk, A), (A, B)):
+        ref = oracle_d.spgemm(X, Y)
+        got, st = spgemm(lib_d, X, Y)
+        assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
+        if lib_d.real == np.float32:
+            from oracle.oracle import Oracle
+            assert oracle_d.check_spgemm(got, oracle_fp64_accumulated(Oracle("d"), X, Y)) == 0
+        else:
+            assert oracle_d.check_spgemm(got, ref) == 0
