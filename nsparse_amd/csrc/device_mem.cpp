@@ -206,7 +206,9 @@ Context &ctx()
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         const bool prio_on = !(getenv("NSPARSE_STREAM_PRIO") && atoi(getenv("NSPARSE_STREAM_PRIO")) == 0);
         for (int i = 0; i < kMaxBins; i++) {
-            const bool big = prio_on && (i == 4 || i == 5 || i == 10);
+            // NSPARSE_PRIO_BINS=<bit mask of bins>: which bins' streams get it (default: 4, 5, 10)
+            static const unsigned prio_mask = getenv("NSPARSE_PRIO_BINS") ? (unsigned)strtoul(getenv("NSPARSE_PRIO_BINS"), nullptr, 0) : 0x430u;
+            const bool big = prio_on && ((prio_mask >> i) & 1u);
             if (big) {
                 NSP_CHECK(hipStreamCreateWithPriority(&c.stream[i], hipStreamNonBlocking, prio_hi));
                 NSP_CHECK(hipEventCreateWithFlags(&c.ev_join[i], hipEventDisableTiming));

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
     // (structure = C.col, the bitmap is rebuilt from it).
     // prof != nullptr (NSPARSE_BLK_PROF=1): thread 0 of every group head adds the shader-clock cycles of
     // its phases to its slots prof[8 * block + 0..4] (meta, park loads, run building, walk, emission;
-    // [6] = 1 per group, [7] = rows)
+    // [5], [6] = start and end of the group on the 100 MHz clock, [7] = rows)
     unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0;
     auto stamp = [&](int phase) {
         if (prof && threadIdx.x == 0) {
@@ -127,18 +127,17 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
     acc_t *acc = reinterpret_cast<acc_t *>(nsp_dyn_lds);  // RA rows of nzs accumulators
     __shared__ unsigned int s_bits[NWORDS];
     __shared__ int s_pre[NWORDS];
-    // run records: x, y, z = first entry of the (up to 3) rows of B, w = length | rows << 21 | leader entry << 23
-    __shared__ int4 s_rec[PARK];
-    // A values of the parked entries, [entry][row of the group]: the 3 x 3 values of a run are 9 consecutive
-    // words, read back to back without conditions (the values of B are zero for the rows a run lacks)
-    __shared__ real s_a[(PARK + 2) * kBlkRows];
+    // Runs of one pass (at most RUNCAP; a batch whose entries form more runs is walked in two passes).
+    // s_rec: x, y, z = first entry of the (up to 3) rows of B, w = length | rows << 21.
+    // s_a: the 3 x 3 block of A values of a run, [row of B in the run][row of the group] -- 9 consecutive
+    // words written by the entries themselves once they know (run, place in the run), ZERO where the run has
+    // fewer rows of B: the walk reads them back to back without conditions, and neither the values of a
+    // neighbouring run nor an Inf / NaN of it can leak into this one (the reference yields NaN / Inf only
+    // in the columns the offending entry touches).
+    constexpr int RUNCAP = PARK / 2;
+    __shared__ int4 s_rec[RUNCAP];
+    __shared__ real s_a[RUNCAP * kBlkRun * kBlkRows];
     __shared__ int s_wcnt[NW];
-    // the parked entries of a run (bytes 0..2; PARK = the zero entry behind the last one) and, keyed runs
-    // only, the key of every parked entry and the run its leader opened
-    static_assert(!KEYED || PARK < 255, "parked entries are named by a byte");
-    __shared__ unsigned int s_ent[KEYED ? PARK : 1];
-    __shared__ int s_key[KEYED ? PARK : 1];  // later: the run an entry's leader opened
-    int *s_runof = s_key;
     const int slot0 = xcd_row_slot(bin_size);
     if (slot0 < 0) return;
     const int slot = slot0 < seg1 ? bin_off + slot0 : bin_off2 + (slot0 - seg1);  // position in the row list
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
         if (MODE == 1) bmo = bm_off[rid];
     }
     if (prof && threadIdx.x == 0) {
-        prof[8ull * blockIdx.x + 6] = 1;
+        prof[8ull * blockIdx.x + 5] = wall_clock64();  // 100 MHz: when this group started
         prof[8ull * blockIdx.x + 7] = (unsigned long long)RA;
     }
     const int nz = crpt[rid + 1] - off[0];
@@ -204,8 +203,14 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
         const bool valid = j < alen && (int)threadIdx.x < PARK;
         int c = -2, kb = 0, ke = 0;
         bool tw = false;
+        real av[kBlkRows];
+#pragma unroll
+        for (int r = 0; r < kBlkRows; r++) av[r] = (real)0;
         if (valid) {
             c = __builtin_nontemporal_load(acol + a_beg[0] + j);
+#pragma unroll
+            for (int r = 0; r < kBlkRows; r++)
+                if (r < RA) av[r] = __builtin_nontemporal_load(aval + a_beg[r] + j);
             struct __attribute__((aligned(4))) I2 {
                 int b, e;
             };
@@ -213,13 +218,9 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
             kb = rr.b, ke = rr.e;
             tw = btwin != nullptr && btwin[c] != 0;
         }
-#pragma unroll
-        for (int r = 0; r < kBlkRows; r++)
-            if ((int)threadIdx.x < PARK)
-                s_a[threadIdx.x * kBlkRows + r] = (valid && r < RA) ? __builtin_nontemporal_load(aval + a_beg[r] + j) : (real)0;
-        if (threadIdx.x < 2 * kBlkRows) s_a[PARK * kBlkRows + threadIdx.x] = 0;  // what a run at the very end reads past
         int d, nB, my_run, nruns = 0;
         bool leader;
+        int lead_lane = lane;  // KEYED: the lane whose entry opened my run
         if constexpr (!KEYED) {
             const int cprev = __shfl_up(c, 1);
             // entry j continues the run of entry j - 1 when its row of B is the twin of that one's (same
@@ -239,38 +240,37 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
             nB = end - lane;
             nB = nB > kBlkRun ? kBlkRun : nB;
         } else {
-            // keyed runs: position of the entry among the parked entries with its key, by counting
+            // keyed runs: the entries of this WAVEFRONT whose rows of B share a pattern leader, three at a
+            // time in lane order.  One ballot per distinct key (a third of the entries on a 3-dof mesh)
+            // instead of every entry comparing itself with every parked one; runs never cross a wavefront.
             int key = -3;
             if (valid) {
                 const int l = bkey[c];
                 key = l >= 0 ? l : c;
             }
-            if ((int)threadIdx.x < PARK) s_key[threadIdx.x] = key;
-            __syncthreads();
-            const int nb = alen - a0 < PARK ? alen - a0 : PARK;
-            int before = 0, total = 0, last1 = -1, last2 = -1;
-            if (valid) {
-                for (int i = 0; i < nb; i++) {
-                    const bool eq = s_key[i] == key;
-                    total += eq;
-                    if (eq && i < (int)threadIdx.x) {
-                        before++;
-                        last2 = last1;
-                        last1 = i;
-                    }
-                }
+            unsigned long long mine = 0ull;
+            unsigned long long todo = __ballot(valid);
+            while (todo) {
+                const int src = __ffsll((long long)todo) - 1;
+                const int k = __builtin_amdgcn_readlane(key, src);
+                const unsigned long long m = __ballot(valid && key == k);
+                if (valid && key == k) mine = m;
+                todo &= ~m;
             }
+            const unsigned long long lower = mine & ((1ull << lane) - 1ull);
+            const int before = __popcll(lower);
+            const int last1 = lower ? 63 - __clzll((long long)lower) : 0;
+            const unsigned long long lower2 = lower & ~(1ull << last1);
+            const int last2 = lower2 ? 63 - __clzll((long long)lower2) : 0;
             d = before % kBlkRun;
             leader = valid && d == 0;
-            nB = total - before;
+            nB = __popcll(mine) - before;
             nB = nB > kBlkRun ? kBlkRun : nB;
-            // (kept for the followers below: the entry that leads my run)
-            tw = false;
-            c = d == 1 ? last1 : (d == 2 ? last2 : (int)threadIdx.x);
+            lead_lane = d == 1 ? last1 : (d == 2 ? last2 : lane);
         }
         const unsigned long long lm = __ballot(leader);
         if (lane == 0) s_wcnt[wv] = __popcll(lm);
-        __syncthreads();  // also: bitmap in LDS, accumulators cleared, s_a written
+        __syncthreads();  // also: bitmap in LDS, accumulators cleared; the previous batch's walk is over
         stamp(1);
         if (a0 == 0 && wv == NW - 1) {
             // exclusive prefix of the word popcounts: the last wavefront (it parks the fewest entries)
@@ -289,100 +289,82 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
             nruns += s_wcnt[u];
         }
         my_run = wbase + __popcll(lm & ((2ull << lane) - 1ull)) - 1;  // of the last leader at or below this lane
-        if constexpr (KEYED) {
-            if (leader) s_runof[threadIdx.x] = my_run;  // (every s_key was read before the barrier above)
-            __syncthreads();
-            if (valid && !leader) my_run = s_runof[c];
-        }
-        if (valid) {
-            reinterpret_cast<int *>(&s_rec[my_run])[d] = kb;
-            if constexpr (KEYED) reinterpret_cast<unsigned char *>(&s_ent[my_run])[d] = (unsigned char)threadIdx.x;
-            if (leader) {
-                s_rec[my_run].w = (ke - kb) | (nB << 21) | (KEYED ? 0 : (int)threadIdx.x << 23);
-                if constexpr (KEYED)
-                    for (int q = nB; q < kBlkRun; q++)
-                        reinterpret_cast<unsigned char *>(&s_ent[my_run])[q] = (unsigned char)PARK;
-            }
-        }
-        __syncthreads();
-        stamp(2);
+        if constexpr (KEYED) my_run = __shfl(my_run, lead_lane);       // of the entry that opened my run
 
-        // ---- walk: the (run, chunk) pairs of the batch are one flat task list; group q takes a
-        // contiguous stretch of it, U tasks in flight (their loads issued before the first is added) ----
         const int nch = (maxb + G - 1) >> lg;  // chunks per run, by the longest row of B this C row meets
-        const int ntask = nruns * nch;
-        const int per = (ntask + NG - 1) / NG;
-        const int t0 = gid * per;
-        const int t1 = t0 + per < ntask ? t0 + per : ntask;
-        int u = t0 / nch, ch = t0 - u * nch;
-        for (int tb = t0; tb < t1; tb += U) {
-            int col[U], ru[U], meta[U];
-            real v[kBlkRun][U];
-            bool ok[U];
+        for (int run0 = 0; run0 < nruns; run0 += RUNCAP) {
+            // ---- stage the runs [run0, run0 + RUNCAP) -------------------------------------------------
+            if (run0 > 0) __syncthreads();  // the walk of the previous pass is over
+            const int rel = my_run - run0;
+            if (valid && rel >= 0 && rel < RUNCAP) {
+                reinterpret_cast<int *>(&s_rec[rel])[d] = kb;
 #pragma unroll
-            for (int i = 0; i < U; i++) {
-                const bool live = tb + i < t1;
-                const int4 rec = s_rec[live ? u : 0];
-                const int len = rec.w & 0x1fffff;
-                const int nb = (rec.w >> 21) & 3;
-                const int p = gl + (ch << lg);
-                ok[i] = live && p < len;
-                ru[i] = live ? u : 0;
-                meta[i] = rec.w;
-                const unsigned idx = ok[i] ? (unsigned)p : 0u;  // masked lanes re-read entry 0 of the run
-                const unsigned k0 = len > 0 ? (unsigned)rec.x : 0u;  // an empty row may start at the very end
-                col[i] = bcol[k0 + idx];
-                v[0][i] = bval[k0 + idx];
-                v[1][i] = nb > 1 ? bval[(unsigned)rec.y + idx] : (real)0;
-                v[2][i] = nb > 2 ? bval[(unsigned)rec.z + idx] : (real)0;
-                ch++;
-                if (ch == nch) {
-                    ch = 0;
-                    u++;
+                for (int r = 0; r < kBlkRows; r++) s_a[(rel * kBlkRun + d) * kBlkRows + r] = av[r];
+                if (leader) {
+                    s_rec[rel].w = (ke - kb) | (nB << 21);
+                    for (int q = nB; q < kBlkRun; q++)
+#pragma unroll
+                        for (int r = 0; r < kBlkRows; r++) s_a[(rel * kBlkRun + q) * kBlkRows + r] = (real)0;
                 }
             }
+            __syncthreads();
+            stamp(2);
+
+            // ---- walk: the (run, chunk) pairs of the pass are one flat task list; group q takes a
+            // contiguous stretch of it, U tasks in flight (their loads issued before the first is added) ----
+            const int npass = nruns - run0 < RUNCAP ? nruns - run0 : RUNCAP;
+            const int ntask = npass * nch;
+            const int per = (ntask + NG - 1) / NG;
+            const int t0 = gid * per;
+            const int t1 = t0 + per < ntask ? t0 + per : ntask;
+            int u = t0 / nch, ch = t0 - u * nch;
+            for (int tb = t0; tb < t1; tb += U) {
+                int col[U], ru[U];
+                real v[kBlkRun][U];
+                bool ok[U];
 #pragma unroll
-            for (int i = 0; i < U; i++) {
-                if (ok[i]) {
-                    int e[kBlkRun];  // the parked entries of the run (past its end: zero values of B)
-                    if constexpr (KEYED) {
-                        const unsigned int ent = s_ent[ru[i]];
-#pragma unroll
-                        for (int dd = 0; dd < kBlkRun; dd++) e[dd] = (int)((ent >> (8 * dd)) & 0xffu);
-                    } else {  // neighbours: leader entry, + 1, + 2
-                        const int j0 = (int)((unsigned int)meta[i] >> 23);
-#pragma unroll
-                        for (int dd = 0; dd < kBlkRun; dd++) e[dd] = j0 + dd;
+                for (int i = 0; i < U; i++) {
+                    const bool live = tb + i < t1;
+                    const int4 rec = s_rec[live ? u : 0];
+                    const int len = rec.w & 0x1fffff;
+                    const int nb = (rec.w >> 21) & 3;
+                    const int p = gl + (ch << lg);
+                    ok[i] = live && p < len;
+                    ru[i] = live ? u : 0;
+                    const unsigned idx = ok[i] ? (unsigned)p : 0u;  // masked lanes re-read entry 0 of the run
+                    const unsigned k0 = len > 0 ? (unsigned)rec.x : 0u;  // an empty row may start at the very end
+                    col[i] = bcol[k0 + idx];
+                    v[0][i] = bval[k0 + idx];
+                    v[1][i] = nb > 1 ? bval[(unsigned)rec.y + idx] : (real)0;
+                    v[2][i] = nb > 2 ? bval[(unsigned)rec.z + idx] : (real)0;
+                    ch++;
+                    if (ch == nch) {
+                        ch = 0;
+                        u++;
                     }
-                    const int idx = col[i] - lo;
-                    const int rank = s_pre[idx >> 5] + __popc(s_bits[idx >> 5] & ((1u << (idx & 31)) - 1u));
-                    // a run shorter than kBlkRun must not pick up the values of the NEXT parked entries: with v = 0
-                    // a finite neighbour is harmless, an Inf or NaN neighbour would turn this product into NaN
-                    // (the reference yields NaN / Inf only in the columns the offending entry touches)
-                    const int nb_i = (meta[i] >> 21) & 3;
-                    real a[kBlkRun][kBlkRows];
+                }
 #pragma unroll
-                    for (int dd = 0; dd < kBlkRun; dd++)
+                for (int i = 0; i < U; i++) {
+                    if (ok[i]) {
+                        const int idx = col[i] - lo;
+                        const int rank = s_pre[idx >> 5] + __popc(s_bits[idx >> 5] & ((1u << (idx & 31)) - 1u));
+                        const real *ab = s_a + ru[i] * (kBlkRun * kBlkRows);
 #pragma unroll
                         for (int r = 0; r < kBlkRows; r++) {
-                            const real t = s_a[e[dd] * kBlkRows + r];
-                            a[dd][r] = (dd == 0 || dd < nb_i) ? t : (real)0;
-                        }
-#pragma unroll
-                    for (int r = 0; r < kBlkRows; r++) {
-                        if (r < RA) {
-                            acc_t sum = (acc_t)(a[0][r] * v[0][i]);
-                            sum += (acc_t)(a[1][r] * v[1][i]);  // v is zero for the rows the run lacks
-                            sum += (acc_t)(a[2][r] * v[2][i]);
-                            unsafeAtomicAdd(acc + r * nzs + rank, sum);
+                            if (r < RA) {
+                                acc_t sum = (acc_t)(ab[r] * v[0][i]);
+                                sum += (acc_t)(ab[kBlkRows + r] * v[1][i]);  // both factors are zero for the rows the run lacks
+                                sum += (acc_t)(ab[2 * kBlkRows + r] * v[2][i]);
+                                unsafeAtomicAdd(acc + r * nzs + rank, sum);
+                            }
                         }
                     }
                 }
             }
+            stamp(3);
         }
-        __syncthreads();
-        stamp(3);
     }
+    __syncthreads();
 
     // ---- emission: values are in output order already; columns are read off the bitmap ------------
     for (int r = 0; r < RA; r++)
@@ -396,7 +378,11 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
             }
         }
     }
-    if (prof) { __syncthreads(); stamp(4); }
+    if (prof) {
+        __syncthreads();
+        stamp(4);
+        if (threadIdx.x == 0) prof[8ull * blockIdx.x + 6] = wall_clock64();  // ... and when it was done
+    }
 }
 
 

@@ -686,7 +686,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         hipLaunchKernelGGL((k_num_block<BS, SPAN, MODEX, kBlkU, KEYEDX>), dim3(8 * ceil_div(heads + heads6, 8)), dim3(BS), \
                            lds_blk, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
                            c->d_val, row_perm, row_maxb, row_lo, row_span, fold6_ ? off[6] : off[bin_], \
-                           heads + heads6, b->nnz, bm_off, bm, grp, btwin, blk_prof, members, desc, bkey, \
+                           heads + heads6, b->nnz, bm_off, bm, grp, btwin, blk_prof ? blk_prof + 8ull * off[bin_] : nullptr, members, desc, bkey, \
                            fold6_ ? heads6 : 0x7fffffff, off[bin_]);                           \
     }
 // keyed runs (twin rows of B that are not neighbours): the default 128-thread, full-call form only
@@ -761,7 +761,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
 #define NSP_RANKWIN(MODEX)                                                                      \
     hipLaunchKernelGGL((k_num_block<128, 65536, MODEX, kBlkU>), dim3(8 * ceil_div(heads, 8)), dim3(128), lds_blk, st, \
                        arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_maxb, \
-                       row_lo, row_span, off[bin_], heads, b->nnz, bm_off, bm, grp, btwin, blk_prof, members, desc, (const int *)nullptr)
+                       row_lo, row_span, off[bin_], heads, b->nnz, bm_off, bm, grp, btwin, blk_prof ? blk_prof + 8ull * off[bin_] : nullptr, members, desc, (const int *)nullptr)
         if (write_col & 1) NSP_RANKWIN(1); else NSP_RANKWIN(2);
 #undef NSP_RANKWIN
         NSP_LAUNCH_CHECK();
@@ -850,10 +850,35 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         std::vector<unsigned long long> hb(8 * (size_t)(a->M + 8));
         NSP_CHECK(hipMemcpy(hb.data(), blk_prof, hb.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
         unsigned long long h[8] = {};
-        for (size_t i = 0; i < hb.size(); i++) h[i & 7] += hb[i];
+        // [5], [6]: start / end of every group on the 100 MHz clock -> groups resident over the kernel's life
+        unsigned long long t_lo = ~0ull, t_hi = 0, life = 0;
+        for (size_t i = 0; i < hb.size(); i += 8) {
+            if (hb[i + 6] == 0) continue;
+            for (int q = 0; q < 5; q++) h[q] += hb[i + q];
+            h[6]++;
+            h[7] += hb[i + 7];
+            t_lo = hb[i + 5] < t_lo ? hb[i + 5] : t_lo;
+            t_hi = hb[i + 6] > t_hi ? hb[i + 6] : t_hi;
+            life += hb[i + 6] - hb[i + 5];
+        }
         const double g = h[6] ? (double)h[6] : 1.0;
         fprintf(stderr, "[blk] groups %llu rows %llu | cycles per group: meta %.0f clear+park-loads %.0f runs %.0f walk %.0f emit %.0f\n",
                 h[6], h[7], h[0] / g, h[1] / g, h[2] / g, h[3] / g, h[4] / g);
+        if (h[6] && t_hi > t_lo) {
+            const double span = (double)(t_hi - t_lo);
+            int dec[10] = {};
+            for (size_t i = 0; i < hb.size(); i += 8) {
+                if (hb[i + 6] == 0) continue;
+                for (int q = 0; q < 10; q++) {
+                    const double t = (double)t_lo + span * (q + 0.5) / 10.0;
+                    dec[q] += (double)hb[i + 5] <= t && t < (double)hb[i + 6];
+                }
+            }
+            fprintf(stderr, "[blk] first start to last end %.1f us (all window bins), mean life %.2f us, mean resident %.0f groups = %.2f per CU | resident at 5%%..95%%:",
+                    span * 0.01, life / g * 0.01, life / span, life / span / cx.num_cus);
+            for (int q = 0; q < 10; q++) fprintf(stderr, " %d", dec[q]);
+            fprintf(stderr, "\n");
+        }
         dev_free(blk_prof);
     }
     return L;
