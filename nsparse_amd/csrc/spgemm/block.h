@@ -127,16 +127,22 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
     acc_t *acc = reinterpret_cast<acc_t *>(nsp_dyn_lds);  // RA rows of nzs accumulators
     __shared__ unsigned int s_bits[NWORDS];
     __shared__ int s_pre[NWORDS];
-    // Runs of one pass (at most RUNCAP; a batch whose entries form more runs is walked in two passes).
-    // s_rec: x, y, z = first entry of the (up to 3) rows of B, w = length | rows << 21.
+    // A batch of parked entries is walked in passes of at most RUNCAP runs, a pass in stretches of at most
+    // TCAP tasks (one pass and one stretch on the cant class: 27 runs, 81 tasks).
+    // s_task: one record per (run, chunk of G entries of its rows of B) -- x, y, z = first entry of the
+    // chunk in the (up to 3) rows of B, w = entries in the chunk | rows << 8 | run << 16.  Written ONCE by
+    // the lane that leads the run, so that the lanes of a group do not each decode extents, chunk
+    // counters and bounds again, and a run only has the chunks its own length needs.
     // s_a: the 3 x 3 block of A values of a run, [row of B in the run][row of the group] -- 9 consecutive
     // words written by the entries themselves once they know (run, place in the run), ZERO where the run has
     // fewer rows of B: the walk reads them back to back without conditions, and neither the values of a
     // neighbouring run nor an Inf / NaN of it can leak into this one (the reference yields NaN / Inf only
     // in the columns the offending entry touches).
-    constexpr int RUNCAP = PARK / 2;
-    __shared__ int4 s_rec[RUNCAP];
+    constexpr int RUNCAP = PARK * 5 / 12, TCAP = KEYED ? PARK * 4 / 3 : PARK;
+    constexpr int NPASS = (PARK + RUNCAP - 1) / RUNCAP;
+    __shared__ int4 s_task[TCAP];
     __shared__ real s_a[RUNCAP * kBlkRun * kBlkRows];
+    __shared__ int s_wtask[NW], s_tstart[NPASS + 1];
     __shared__ int s_wcnt[NW];
     const int slot0 = xcd_row_slot(bin_size);
     if (slot0 < 0) return;
@@ -197,7 +203,12 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
     const int NG = BS >> lg;
     if (prof) { __syncthreads(); stamp(0); }
 
-    for (int a0 = 0; a0 < alen; a0 += PARK) {
+    // One iteration = one stretch of one pass of one batch of parked entries.  Batches with several passes or
+    // stretches (more than RUNCAP runs / TCAP tasks among PARK entries: rare) park their entries AGAIN for each
+    // of them, so that nothing but three uniform counters lives across the walk (registers: 6 waves per SIMD).
+    int a0 = 0, pass = 0, base = 0;
+    bool first_iter = true;
+    while (a0 < alen) {
         // ---- park up to PARK entries of A and cut them into runs ---------------------------------
         const int j = a0 + (int)threadIdx.x;
         const bool valid = j < alen && (int)threadIdx.x < PARK;
@@ -220,7 +231,8 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
         }
         int d, nB, my_run, nruns = 0;
         bool leader;
-        int lead_lane = lane;  // KEYED: the lane whose entry opened my run
+        int lead_lane = lane;  // KEYED: the lane whose entry opened my run,
+        int f1 = lane, f2 = lane;  // ... and (for that lane) the lanes of its run mates
         if constexpr (!KEYED) {
             const int cprev = __shfl_up(c, 1);
             // entry j continues the run of entry j - 1 when its row of B is the twin of that one's (same
@@ -267,12 +279,29 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
             nB = __popcll(mine) - before;
             nB = nB > kBlkRun ? kBlkRun : nB;
             lead_lane = d == 1 ? last1 : (d == 2 ? last2 : lane);
+            const unsigned long long upper = lane < 63 ? mine & ~((2ull << lane) - 1ull) : 0ull;
+            const unsigned long long upper2 = upper & (upper - 1ull);
+            f1 = upper ? __ffsll((long long)upper) - 1 : lane;
+            f2 = upper2 ? __ffsll((long long)upper2) - 1 : lane;
         }
         const unsigned long long lm = __ballot(leader);
+        // the leader of a run collects the extents of its run mates and counts the chunks of the run
+        int kb1, kb2;
+        if constexpr (!KEYED) {
+            kb1 = __shfl_down(kb, 1);
+            kb2 = __shfl_down(kb, 2);
+        } else {
+            kb1 = __shfl(kb, f1);
+            kb2 = __shfl(kb, f2);
+        }
+        const int blen = ke - kb;
+        const int nchunk = leader ? (blen + G - 1) >> lg : 0;
+        const int tincl = wave_incl_scan(nchunk);
+        if (lane == 63) s_wtask[wv] = tincl;
         if (lane == 0) s_wcnt[wv] = __popcll(lm);
         __syncthreads();  // also: bitmap in LDS, accumulators cleared; the previous batch's walk is over
         stamp(1);
-        if (a0 == 0 && wv == NW - 1) {
+        if (first_iter && wv == NW - 1) {
             // exclusive prefix of the word popcounts: the last wavefront (it parks the fewest entries)
             int carry = 0;
             for (int b0 = 0; b0 < nw; b0 += 64) {
@@ -282,42 +311,56 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                 carry += __shfl(inc, 63);
             }
         }
-        int wbase = 0;
+        int wbase = 0, tbase = 0, ttotal = 0;
 #pragma unroll
         for (int u = 0; u < NW; u++) {
             wbase += u < wv ? s_wcnt[u] : 0;
             nruns += s_wcnt[u];
+            tbase += u < wv ? s_wtask[u] : 0;
+            ttotal += s_wtask[u];
         }
         my_run = wbase + __popcll(lm & ((2ull << lane) - 1ull)) - 1;  // of the last leader at or below this lane
         if constexpr (KEYED) my_run = __shfl(my_run, lead_lane);       // of the entry that opened my run
+        const int tpre = tbase + tincl - nchunk;  // leaders: the first task of my run among the batch's
+        // where the tasks of every pass start (read after the barrier that follows the first staging)
+        if (leader && my_run % RUNCAP == 0) s_tstart[my_run / RUNCAP] = tpre;
+        if (threadIdx.x == 0) s_tstart[(nruns + RUNCAP - 1) / RUNCAP] = ttotal;
 
-        const int nch = (maxb + G - 1) >> lg;  // chunks per run, by the longest row of B this C row meets
-        for (int run0 = 0; run0 < nruns; run0 += RUNCAP) {
-            // ---- stage the runs [run0, run0 + RUNCAP) -------------------------------------------------
-            if (run0 > 0) __syncthreads();  // the walk of the previous pass is over
-            const int rel = my_run - run0;
+        // ---- stage the A values of the runs [pass RUNCAP, (pass + 1) RUNCAP) and the task records of the
+        // stretch [base, base + TCAP): the tasks of the batch are numbered through -----------------------
+        {
+            const int rel = my_run - pass * RUNCAP;
             if (valid && rel >= 0 && rel < RUNCAP) {
-                reinterpret_cast<int *>(&s_rec[rel])[d] = kb;
 #pragma unroll
                 for (int r = 0; r < kBlkRows; r++) s_a[(rel * kBlkRun + d) * kBlkRows + r] = av[r];
                 if (leader) {
-                    s_rec[rel].w = (ke - kb) | (nB << 21);
                     for (int q = nB; q < kBlkRun; q++)
 #pragma unroll
                         for (int r = 0; r < kBlkRows; r++) s_a[(rel * kBlkRun + q) * kBlkRows + r] = (real)0;
+                    const int meta = (nB << 8) | (rel << 16);
+                    int q = base - tpre > 0 ? base - tpre : 0;
+                    const int q1 = base + TCAP - tpre < nchunk ? base + TCAP - tpre : nchunk;
+                    for (; q < q1; q++) {
+                        const int st = q << lg;
+                        const int cnt = blen - st < G ? blen - st : G;
+                        s_task[tpre + q - base] =
+                            make_int4(kb + st, (nB > 1 ? kb1 : kb) + st, (nB > 2 ? kb2 : kb) + st, cnt | meta);
+                    }
                 }
             }
-            __syncthreads();
-            stamp(2);
-
-            // ---- walk: the (run, chunk) pairs of the pass are one flat task list; group q takes a
-            // contiguous stretch of it, U tasks in flight (their loads issued before the first is added) ----
-            const int npass = nruns - run0 < RUNCAP ? nruns - run0 : RUNCAP;
-            const int ntask = npass * nch;
+        }
+        __syncthreads();
+        stamp(2);
+        const int tA = s_tstart[pass], tB = s_tstart[pass + 1];  // the tasks of this pass
+        {
+            // ---- walk: group q takes a contiguous stretch of the task list, U tasks in flight (their
+            // loads issued before the first is added) ---------------------------------------------
+            const int lo_t = (tA > base ? tA : base) - base;
+            const int hi_t = (tB < base + TCAP ? tB : base + TCAP) - base;
+            const int ntask = hi_t - lo_t;
             const int per = (ntask + NG - 1) / NG;
-            const int t0 = gid * per;
-            const int t1 = t0 + per < ntask ? t0 + per : ntask;
-            int u = t0 / nch, ch = t0 - u * nch;
+            const int t0 = lo_t + gid * per;
+            const int t1 = t0 + per < hi_t ? t0 + per : hi_t;
             for (int tb = t0; tb < t1; tb += U) {
                 int col[U], ru[U];
                 real v[kBlkRun][U];
@@ -325,23 +368,15 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
 #pragma unroll
                 for (int i = 0; i < U; i++) {
                     const bool live = tb + i < t1;
-                    const int4 rec = s_rec[live ? u : 0];
-                    const int len = rec.w & 0x1fffff;
-                    const int nb = (rec.w >> 21) & 3;
-                    const int p = gl + (ch << lg);
-                    ok[i] = live && p < len;
-                    ru[i] = live ? u : 0;
-                    const unsigned idx = ok[i] ? (unsigned)p : 0u;  // masked lanes re-read entry 0 of the run
-                    const unsigned k0 = len > 0 ? (unsigned)rec.x : 0u;  // an empty row may start at the very end
-                    col[i] = bcol[k0 + idx];
-                    v[0][i] = bval[k0 + idx];
-                    v[1][i] = nb > 1 ? bval[(unsigned)rec.y + idx] : (real)0;
-                    v[2][i] = nb > 2 ? bval[(unsigned)rec.z + idx] : (real)0;
-                    ch++;
-                    if (ch == nch) {
-                        ch = 0;
-                        u++;
-                    }
+                    const int4 e = s_task[live ? tb + i : t0];
+                    const int nb = (e.w >> 8) & 3;
+                    ok[i] = live && gl < (e.w & 0xff);
+                    ru[i] = e.w >> 16;
+                    const unsigned idx = ok[i] ? (unsigned)gl : 0u;  // masked lanes re-read the first entry of the chunk
+                    col[i] = bcol[(unsigned)e.x + idx];
+                    v[0][i] = bval[(unsigned)e.x + idx];
+                    v[1][i] = nb > 1 ? bval[(unsigned)e.y + idx] : (real)0;
+                    v[2][i] = nb > 2 ? bval[(unsigned)e.z + idx] : (real)0;
                 }
 #pragma unroll
                 for (int i = 0; i < U; i++) {
@@ -361,8 +396,19 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                     }
                 }
             }
-            stamp(3);
         }
+        stamp(3);
+        if (base + TCAP < tB) {
+            base += TCAP;  // the next stretch of this pass
+        } else if ((pass + 1) * RUNCAP < nruns) {
+            pass++;  // the next pass starts where this one ended
+            base = tB / TCAP * TCAP;
+        } else {
+            a0 += PARK;
+            pass = 0;
+            base = 0;
+        }
+        first_iter = false;
     }
     __syncthreads();
 

@@ -685,9 +685,9 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         const int heads6 = fold6_ ? (grp ? listed[6] : hist[6]) : 0;                            \
         hipLaunchKernelGGL((k_num_block<BS, SPAN, MODEX, kBlkU, KEYEDX>), dim3(8 * ceil_div(heads + heads6, 8)), dim3(BS), \
                            lds_blk, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,  \
-                           c->d_val, row_perm, row_maxb, row_lo, row_span, fold6_ ? off[6] : off[bin_], \
+                           c->d_val, row_perm, row_maxb, row_lo, row_span, (fold6_ && !fold_rev) ? off[6] : off[bin_], \
                            heads + heads6, b->nnz, bm_off, bm, grp, btwin, blk_prof ? blk_prof + 8ull * off[bin_] : nullptr, members, desc, bkey, \
-                           fold6_ ? heads6 : 0x7fffffff, off[bin_]);                           \
+                           fold6_ ? (fold_rev ? heads : heads6) : 0x7fffffff, fold_rev ? off[6] : off[bin_]); \
     }
 // keyed runs (twin rows of B that are not neighbours): the default 128-thread, full-call form only
 #define NSP_NUM_BLOCK_GO(BS, SPAN, MODEX)                                                       \
@@ -741,7 +741,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // ramp-up less.  Measured on the irregular cant-class stand-in (42 K + 20 K rows), same box, three runs each:
     // 0.377-0.384 ms with two launches side by side, 0.393-0.402 folded.  Two kernels that overlap hide each
     // other's tails better than one.
-    static const bool fold_win = getenv("NSPARSE_FOLD_WIN") && atoi(getenv("NSPARSE_FOLD_WIN")) == 1;
+    static const bool fold_win = getenv("NSPARSE_FOLD_WIN") && atoi(getenv("NSPARSE_FOLD_WIN")) >= 1;
+    static const bool fold_rev = getenv("NSPARSE_FOLD_WIN") && atoi(getenv("NSPARSE_FOLD_WIN")) == 2;  // bin 7's rows first
     const bool fold6 = fold_win && blk && tune_nd7 == 128 && tune_nd6 == 128 && hist[6] > 0 && hist[7] > 0;
     // ranked-window rows (numeric bin 9): always the node-block kernel, windows up to 65536 columns
     if (hist[kRankBin] > 0 && now(kRankBin)) {
