@@ -35,6 +35,7 @@ namespace spgemm {
 
 constexpr int kBlkRows = 3;        // twin rows of A per workgroup
 constexpr int kBlkRun = 3;         // twin rows of B per run
+constexpr int kBlkCols = 2;        // columns of a chunk per lane
 constexpr int kBlkAccElems = 4608;  // LDS budget of the accumulator rows of one workgroup (36 KiB)
 
 // grp[r]: bits 0-1 = position of row r inside its group (0: head), bits 2-3 = rows in the group (heads).
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void k_twin_groups(const int *__restrict__ twi
 }
 
 template <int BS, int SPAN_MAX, int MODE, int U, bool KEYED = false>
-__global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, const int *__restrict__ acol,
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6))) void k_num_block(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                   const real *__restrict__ aval,
                                                   const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                   const real *__restrict__ bval,
@@ -197,8 +198,14 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
         }
     }
     for (int i = threadIdx.x; i < RA * nzs; i += BS) acc[i] = 0;
-    const int G = lean_group(maxb, 3);
+    // A lane takes K columns of a chunk (gl, gl + G, ...): one task record and one 3 x 3 block of A values read
+    // from LDS serve K columns -- the LDS unit is the busiest part of a CU under this kernel (counters: 69 %
+    // of the cycles with one column per lane, the block alone 36 of 72 cycles per task and wavefront).
+    constexpr int K = kBlkCols;
+    int G = 4;
+    while (G < 64 / K && G * (3 * K) < maxb) G <<= 1;  // three chunks cover the longest row of B this C row meets
     const int lg = 31 - __clz(G);
+    const int GW = G * K;  // entries per chunk
     const int gid = (int)threadIdx.x >> lg, gl = (int)threadIdx.x & (G - 1);
     const int NG = BS >> lg;
     if (prof) { __syncthreads(); stamp(0); }
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
             kb2 = __shfl(kb, f2);
         }
         const int blen = ke - kb;
-        const int nchunk = leader ? (blen + G - 1) >> lg : 0;
+        const int nchunk = leader ? (blen + GW - 1) / GW : 0;
         const int tincl = wave_incl_scan(nchunk);
         if (lane == 63) s_wtask[wv] = tincl;
         if (lane == 0) s_wcnt[wv] = __popcll(lm);
@@ -341,8 +348,8 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
                     int q = base - tpre > 0 ? base - tpre : 0;
                     const int q1 = base + TCAP - tpre < nchunk ? base + TCAP - tpre : nchunk;
                     for (; q < q1; q++) {
-                        const int st = q << lg;
-                        const int cnt = blen - st < G ? blen - st : G;
+                        const int st = q * GW;
+                        const int cnt = blen - st < GW ? blen - st : GW;
                         s_task[tpre + q - base] =
                             make_int4(kb + st, (nB > 1 ? kb1 : kb) + st, (nB > 2 ? kb2 : kb) + st, cnt | meta);
                     }
@@ -362,35 +369,50 @@ __global__ __launch_bounds__(BS) void k_num_block(const int *__restrict__ arpt, 
             const int t0 = lo_t + gid * per;
             const int t1 = t0 + per < hi_t ? t0 + per : hi_t;
             for (int tb = t0; tb < t1; tb += U) {
-                int col[U], ru[U];
-                real v[kBlkRun][U];
-                bool ok[U];
+                int col[U][K], ru[U];
+                real v[kBlkRun][U][K];
+                bool ok[U][K];
 #pragma unroll
                 for (int i = 0; i < U; i++) {
                     const bool live = tb + i < t1;
                     const int4 e = s_task[live ? tb + i : t0];
                     const int nb = (e.w >> 8) & 3;
-                    ok[i] = live && gl < (e.w & 0xff);
+                    const int cnt = live ? e.w & 0xff : 0;
                     ru[i] = e.w >> 16;
-                    const unsigned idx = ok[i] ? (unsigned)gl : 0u;  // masked lanes re-read the first entry of the chunk
-                    col[i] = bcol[(unsigned)e.x + idx];
-                    v[0][i] = bval[(unsigned)e.x + idx];
-                    v[1][i] = nb > 1 ? bval[(unsigned)e.y + idx] : (real)0;
-                    v[2][i] = nb > 2 ? bval[(unsigned)e.z + idx] : (real)0;
+#pragma unroll
+                    for (int k = 0; k < K; k++) {
+                        const int pk = gl + k * G;
+                        ok[i][k] = pk < cnt;
+                        const unsigned idx = ok[i][k] ? (unsigned)pk : 0u;  // masked lanes re-read the first entry of the chunk
+                        col[i][k] = bcol[(unsigned)e.x + idx];
+                        v[0][i][k] = bval[(unsigned)e.x + idx];
+                        v[1][i][k] = nb > 1 ? bval[(unsigned)e.y + idx] : (real)0;
+                        v[2][i][k] = nb > 2 ? bval[(unsigned)e.z + idx] : (real)0;
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < U; i++) {
-                    if (ok[i]) {
-                        const int idx = col[i] - lo;
-                        const int rank = s_pre[idx >> 5] + __popc(s_bits[idx >> 5] & ((1u << (idx & 31)) - 1u));
+                    if (ok[i][0]) {  // (the columns of a lane are filled in order)
+                        int rank[K];
+#pragma unroll
+                        for (int k = 0; k < K; k++) {
+                            const int idx = ok[i][k] ? col[i][k] - lo : 0;
+                            rank[k] = s_pre[idx >> 5] + __popc(s_bits[idx >> 5] & ((1u << (idx & 31)) - 1u));
+                        }
                         const real *ab = s_a + ru[i] * (kBlkRun * kBlkRows);
 #pragma unroll
                         for (int r = 0; r < kBlkRows; r++) {
                             if (r < RA) {
-                                acc_t sum = (acc_t)(ab[r] * v[0][i]);
-                                sum += (acc_t)(ab[kBlkRows + r] * v[1][i]);  // both factors are zero for the rows the run lacks
-                                sum += (acc_t)(ab[2 * kBlkRows + r] * v[2][i]);
-                                unsafeAtomicAdd(acc + r * nzs + rank, sum);
+                                const real a0 = ab[r], a1 = ab[kBlkRows + r], a2 = ab[2 * kBlkRows + r];
+#pragma unroll
+                                for (int k = 0; k < K; k++) {
+                                    if (ok[i][k]) {
+                                        acc_t sum = (acc_t)(a0 * v[0][i][k]);
+                                        sum += (acc_t)(a1 * v[1][i][k]);  // both factors are zero for the rows the run lacks
+                                        sum += (acc_t)(a2 * v[2][i][k]);
+                                        unsafeAtomicAdd(acc + r * nzs + rank[k], sum);
+                                    }
+                                }
                             }
                         }
                     }

@@ -558,7 +558,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     static const int tb_bucket = getenv("NSPARSE_TB_BUCKET") ? atoi(getenv("NSPARSE_TB_BUCKET")) : 0;
     // workgroups per CU of the persistent form of the big-table hash bins (0: one workgroup per row)
     static const int tb_persist = getenv("NSPARSE_TB_PERSIST") ? atoi(getenv("NSPARSE_TB_PERSIST")) : 0;  // measured: no gain (R-MAT-22 76.1 / 76.5 / 75.3 / 76.4 ms for 0 / 1 / 2 / 4)
-    constexpr int kBlkU = 4;  // tasks in flight per lane in the node-block kernel
+    constexpr int kBlkU = 2;  // tasks in flight per lane in the node-block kernel (of kBlkCols columns each)
     // diagnostics: extra dynamic LDS per workgroup = fewer groups in flight per CU (what bounds the kernel?)
     static const int blk_pad = getenv("NSPARSE_BLK_PAD") ? atoi(getenv("NSPARSE_BLK_PAD")) : 0;
     static const int blk_prof_on = getenv("NSPARSE_BLK_PROF") ? atoi(getenv("NSPARSE_BLK_PROF")) : 0;
