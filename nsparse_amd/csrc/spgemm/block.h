@@ -154,7 +154,6 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6))) void k_
         const int4 d0 = desc[3 * slot], d1 = desc[3 * slot + 1], d2 = desc[3 * slot + 2];
         rid = d0.x, lo = d0.y, span = d0.z, maxb = d0.w;
         bmo = d1.x, a_beg[0] = d1.y, alen = d1.z, RA = d1.w;
-        off[0] = crpt[rid];
         off[1] = RA > 1 ? crpt[d2.x] : 0;
         off[2] = RA > 2 ? crpt[d2.y] : 0;
         a_beg[1] = RA > 1 ? arpt[d2.x] : 0;
@@ -171,7 +170,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6))) void k_
 #pragma unroll
         for (int r = 0; r < kBlkRows; r++) {
             const int rr = (r == 0 || r >= RA) ? rid : members[kGroupMembers * rid + r - 1];
-            off[r] = r < RA ? crpt[rr] : 0;
+            off[r] = (r > 0 && r < RA) ? crpt[rr] : 0;
             a_beg[r] = r < RA ? arpt[rr] : 0;
         }
         alen = arpt[rid + 1] - a_beg[0];
@@ -182,13 +181,54 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6))) void k_
         prof[8ull * blockIdx.x + 5] = wall_clock64();  // 100 MHz: when this group started
         prof[8ull * blockIdx.x + 7] = (unsigned long long)RA;
     }
-    const int nz = crpt[rid + 1] - off[0];
-    const int nzs = ((nz + 7) >> 3) << 3;  // the number k_twin_groups sized the group with
+    struct __attribute__((aligned(4))) I2 {
+        int b, e;
+    };
+    // The first batch of A entries is requested HERE, as soon as the row's place in A is known, and the
+    // extents of their rows of B right behind them: the row words, the bitmap and the accumulators are set up
+    // while those two round trips are under way (they used to start after all of that: three round trips more
+    // on the critical path of a group).
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    struct Parked {
+        int c, kb, ke, kl;
+        unsigned char twb;
+        real av[kBlkRows];
+    };
+    auto park_a = [&](int a0, Parked &pk) {  // the entries themselves
+        pk.c = -2;
+#pragma unroll
+        for (int r = 0; r < kBlkRows; r++) pk.av[r] = (real)0;
+        const int j = a0 + (int)threadIdx.x;
+        if (j < alen && (int)threadIdx.x < PARK) {
+            pk.c = __builtin_nontemporal_load(acol + a_beg[0] + j);
+#pragma unroll
+            for (int r = 0; r < kBlkRows; r++)
+                if (r < RA) pk.av[r] = __builtin_nontemporal_load(aval + a_beg[r] + j);
+        }
+    };
+    auto park_b = [&](Parked &pk) {  // what hangs on their columns (values as loaded: nothing here waits)
+        pk.kb = 0, pk.ke = 0, pk.kl = -1, pk.twb = 0;
+        if (pk.c >= 0) {
+            const I2 rr = *reinterpret_cast<const I2 *>(brpt + pk.c);
+            pk.kb = rr.b, pk.ke = rr.e;
+            if (btwin != nullptr) pk.twb = btwin[pk.c];
+            if constexpr (KEYED) pk.kl = bkey[pk.c];
+        }
+    };
+    Parked pk0;
+    park_a(0, pk0);
     const int nw = (span + 31) >> 5;
+    unsigned int bw0 = 0;  // the first bitmap word of this thread: requested between the two
+    if (MODE == 1 && (int)threadIdx.x < nw) bw0 = bm[bmo + threadIdx.x];
+    park_b(pk0);
+    const I2 cr = *reinterpret_cast<const I2 *>(crpt + rid);
+    off[0] = cr.b;
+    const int nz = cr.e - cr.b;
+    const int nzs = ((nz + 7) >> 3) << 3;  // the number k_twin_groups sized the group with
     if (MODE == 1) {
         const unsigned int *bits = bm + bmo;
-        for (int i = threadIdx.x; i < nw; i += BS) s_bits[i] = bits[i];
+        if ((int)threadIdx.x < nw) s_bits[threadIdx.x] = bw0;
+        for (int i = threadIdx.x + BS; i < nw; i += BS) s_bits[i] = bits[i];
     } else {
         for (int i = threadIdx.x; i < nw; i += BS) s_bits[i] = 0;
         __syncthreads();
@@ -219,23 +259,16 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6))) void k_
         // ---- park up to PARK entries of A and cut them into runs ---------------------------------
         const int j = a0 + (int)threadIdx.x;
         const bool valid = j < alen && (int)threadIdx.x < PARK;
-        int c = -2, kb = 0, ke = 0;
-        bool tw = false;
+        Parked pk = pk0;
+        if (!first_iter) {
+            park_a(a0, pk);
+            park_b(pk);
+        }
+        const int c = pk.c, kb = pk.kb, ke = pk.ke;
+        const bool tw = pk.twb != 0;
         real av[kBlkRows];
 #pragma unroll
-        for (int r = 0; r < kBlkRows; r++) av[r] = (real)0;
-        if (valid) {
-            c = __builtin_nontemporal_load(acol + a_beg[0] + j);
-#pragma unroll
-            for (int r = 0; r < kBlkRows; r++)
-                if (r < RA) av[r] = __builtin_nontemporal_load(aval + a_beg[r] + j);
-            struct __attribute__((aligned(4))) I2 {
-                int b, e;
-            };
-            const I2 rr = *reinterpret_cast<const I2 *>(brpt + c);
-            kb = rr.b, ke = rr.e;
-            tw = btwin != nullptr && btwin[c] != 0;
-        }
+        for (int r = 0; r < kBlkRows; r++) av[r] = pk.av[r];
         int d, nB, my_run, nruns = 0;
         bool leader;
         int lead_lane = lane;  // KEYED: the lane whose entry opened my run,
@@ -262,11 +295,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6))) void k_
             // keyed runs: the entries of this WAVEFRONT whose rows of B share a pattern leader, three at a
             // time in lane order.  One ballot per distinct key (a third of the entries on a 3-dof mesh)
             // instead of every entry comparing itself with every parked one; runs never cross a wavefront.
-            int key = -3;
-            if (valid) {
-                const int l = bkey[c];
-                key = l >= 0 ? l : c;
-            }
+            const int key = valid ? (pk.kl >= 0 ? pk.kl : c) : -3;
             unsigned long long mine = 0ull;
             unsigned long long todo = __ballot(valid);
             while (todo) {
