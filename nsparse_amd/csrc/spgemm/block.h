@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_twin_groups(const int *__restrict__ twi
 }
 
 template <int BS, int SPAN_MAX, int MODE, int U, bool KEYED = false>
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(6))) void k_num_block(const int *__restrict__ arpt, const int *__restrict__ acol,
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(BS <= 256 ? 6 : 2))) void k_num_block(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                   const real *__restrict__ aval,
                                                   const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                   const real *__restrict__ bval,

@@ -179,8 +179,11 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     const int slot = persist ? (j8 < nb8 ? (int)(blockIdx.x & 7) * nb8 + j8 : bin_size) : xcd_row_slot(bin_size);
     if (slot < 0 || slot >= bin_size) return;
     const int rid = row_perm[bin_off + slot];
+    // every row word in ONE round trip (the loads that stood behind the barrier below started a trip later)
     const int off = crpt[rid];
     const int n = crpt[rid + 1] - off;
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int np_row = row_prod[rid], mb_row = row_maxb[rid];
     int T = pow2_ceil(n + (n >> 1));
     if (T < 64) T = 64;
     if (T > TMAX) T = TMAX;
@@ -196,8 +199,7 @@ __global__ __launch_bounds__(BS) void k_num_tb(const int *__restrict__ arpt,
     __syncthreads();
     tick(0);
 
-    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    walk_products_mixed<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, row_prod[rid], row_maxb[rid],
+    walk_products_mixed<BS, true>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, np_row, mb_row,
                                   s_ext, s_av, &s_defer,
                                   [&](const IVec &k, const RVec &v, int n, real sc) {
                                       int h[VW], fresh = 0;

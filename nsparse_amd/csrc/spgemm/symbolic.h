@@ -112,7 +112,10 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
     const int slot = xcd_row_slot(bin_size);
     if (slot < 0) return;
     const int rid = row_perm[bin_off + slot];
+    // every row word in ONE round trip (the loads that stood behind the barrier below started a trip later)
     const int np = row_prod[rid];
+    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+    const int mb_row = row_maxb[rid];
     int T = LARGE ? TMAX : pow2_ceil(np + (np >> 1));  // load factor <= 2/3 where the bin's table allows
     if (T < 64) T = 64;
     if (T > TMAX) T = TMAX;
@@ -128,12 +131,11 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
     }
     __syncthreads();
 
-    const int a_beg = arpt[rid], a_end = arpt[rid + 1];
-    const int g = group_width(np, a_end - a_beg, BS, row_maxb[rid]);
+    const int g = group_width(np, a_end - a_beg, BS, mb_row);
     int cnt = 0;
     if (!LARGE) {
         walk_products_mixed<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz,
-                                       a_beg, a_end, np, row_maxb[rid], s_ext, (real *)nullptr, &s_defer,
+                                       a_beg, a_end, np, mb_row, s_ext, (real *)nullptr, &s_defer,
                                        [&](const IVec &k, const RVecT<1> &, int n, real) {
                                            int h[VW];
                                            if (COOP) ht_insert_vec_coop(tab, mask, k, n, h, cnt, COOP);
