@@ -239,7 +239,8 @@ using RVecS = RVecT<1>;  // symbolic walks carry no values
 __device__ __forceinline__ int group_width(int np, int alen, int BS, int maxb = 0, int vw = VW)
 {
     if (alen <= 0) return 64;
-    const int avg = (np + alen - 1) / alen;
+    // (the average only steers the choice: a float reciprocal instead of an integer division's ~25 scalar steps)
+    const int avg = (int)((float)np * __builtin_amdgcn_rcpf((float)alen) + 0.998f);  // ~ceil; exact multiples stay exact
     int best_g = 64, best_t = 0x7fffffff;
 #pragma unroll
     for (int g = 64; g >= 1; g >>= 1) {
@@ -329,15 +330,21 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
                                               const real *__restrict__ bval, int bnnz, int a_beg,
                                               int a_end, int g, int2 *s_ext, real *s_av, F &&consume,
                                               DeferList<WITH_VAL, DCAP> *dl = nullptr, int defer_len = 0x7fffffff,
-                                              const unsigned char *skip_twin = nullptr)
+                                              const unsigned char *skip_twin = nullptr, const int2 *pre_e = nullptr,
+                                              const real *pre_av = nullptr)
 {
+    // pre_e / pre_av (k_num_wave): the lane's B extent and A value of the FIRST batch, fetched by the caller
+    // while it was busy with the row before this one
     // skip_twin (symbolic walks only): rows of B flagged as twins of the row before them have that row's
     // columns; an A entry that points at such a row right after an entry that points at the row before it
     // adds no column and is not walked (the 3 dof of a mesh node: a third of the products remains).
-    const int ngroups = BS / g;
-    const int gid = threadIdx.x / g, gl = threadIdx.x % g;
+    // g is a power of two (group_width, or 64): shifts, not the four integer divisions the compiler would emit
+    static_assert((BS & (BS - 1)) == 0, "workgroup size is a power of two");
+    const int lg = 31 - __clz(g), lng = (31 - __clz(BS)) - lg;
+    const int ngroups = 1 << lng;
+    const int gid = (int)threadIdx.x >> lg, gl = (int)threadIdx.x & (g - 1);
     const int first = a_beg + gid;
-    const int cnt = first < a_end ? (a_end - first + ngroups - 1) / ngroups : 0;
+    const int cnt = first < a_end ? (a_end - first + ngroups - 1) >> lng : 0;
     int2 *ext = s_ext + gid * g;
     real *avs = s_av + gid * g;
     const int lane_off = gl * V;
@@ -347,6 +354,10 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
         int2 e = make_int2(0, 0);
         real av = 0;
         if (m < cnt) {
+            if (pre_e && b0 == 0) {
+                e = *pre_e;
+                if (WITH_VAL) av = *pre_av;
+            } else {
             const int j = first + m * ngroups;
             const int c = __builtin_nontemporal_load(acol + j);
             if (WITH_VAL) av = __builtin_nontemporal_load(aval + j);
@@ -357,6 +368,7 @@ __device__ __forceinline__ void walk_products(const int *__restrict__ acol, cons
             e.x = r.b;
             e.y = r.e;
             if (!WITH_VAL && skip_twin && j > a_beg && skip_twin[c] && acol[j - 1] == c - 1) e = make_int2(0, 0);
+            }
             if (dl && e.y - e.x > defer_len) {  // far longer than the rows g was chosen for
                 const int i = atomicAdd(&dl->n, 1);
                 if (i < DCAP) {

@@ -144,8 +144,9 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                        flat_on == 2);
     } else {
         // try-in-LDS: plain walk with early exit once the table holds kSymLargeLimit keys
-        const int ngroups = BS / g;
-        const int gid = threadIdx.x / g, gl = threadIdx.x % g;
+        const int lg = 31 - __clz(g);
+        const int ngroups = BS >> lg;
+        const int gid = (int)threadIdx.x >> lg, gl = (int)threadIdx.x & (g - 1);
         bool full = false;
         for (int j = a_beg + gid; j < a_end && !full; j += ngroups) {
             const int c = __builtin_nontemporal_load(acol + j);

@@ -776,6 +776,21 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     NSP_NUM_TB(4, 1024, 8192, 8192)
     NSP_NUM_TB(3, 512, 4096, 4096)
     if (tune_n2 == 128) { NSP_NUM_TB(2, 128, 1024, 1024) } else if (tune_n2 == 512) { NSP_NUM_TB(2, 512, 1024, 1024) } else { NSP_NUM_TB(2, 256, 1024, 1024) }
+    // bin 1, NSPARSE_WAVE1=n: n persistent wavefronts per CU with the next rows' loads in flight (numeric.h: k_num_wave).
+    // Off by default: measured slower (27-point stencil numeric 1.87 -> 2.58 ms): the bin is bound by instruction
+    // issue, not by its chain of round trips, and the pipeline costs registers (5 wavefronts per SIMD instead of 8).
+    static const int wave1 = getenv("NSPARSE_WAVE1") ? atoi(getenv("NSPARSE_WAVE1")) : 0;
+    if (wave1 > 0 && g_coop == 0 && !tb_prof && tune_n1 != 128) {
+        if (hist[1] > 0 && now(1)) {
+            hipStream_t st = L.begin(1);
+            const int full_ = 8 * ceil_div(hist[1], 8), pers_ = 8 * ceil_div(cx.num_cus * wave1, 8);
+            hipLaunchKernelGGL((k_num_wave<256, 256>), dim3(pers_ < full_ ? pers_ : full_), dim3(64), 0, st, arpt, acol, aval,
+                               brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_prod, row_maxb, off[1], hist[1],
+                               b->nnz, write_col);
+            NSP_LAUNCH_CHECK();
+            L.end(1);
+        }
+    } else
     if (tune_n1 == 128) { NSP_NUM_TB(1, 128, 256, 256) } else { NSP_NUM_TB(1, 64, 256, 256) }
     if (hist[0] > 0 && now(0)) {
         hipStream_t st = L.begin(0);
