@@ -106,7 +106,8 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
     // network of the numeric bins, one returning atomic for its place in the slab.
     __shared__ __attribute__((aligned(16))) int tab[TMAX];
     __shared__ int2 s_ext[LARGE ? 1 : BS];
-    __shared__ DeferList<false, (LARGE ? 32 : (TMAX / 32 > 32 ? TMAX / 32 : 32))> s_defer;
+    // (the 1024-slot, one-wavefront instance: 24 parked rows keep a row's LDS below 5120 B = 32 rows per CU)
+    __shared__ DeferList<false, (LARGE ? 32 : (TMAX / 32 > 32 ? TMAX / 32 : (TMAX == 1024 && BS == 64 ? 24 : 32)))> s_defer;
     __shared__ FlatScratch<LARGE ? 64 : BS> s_flat;
     __shared__ int s_nz;
     const int slot = xcd_row_slot(bin_size);

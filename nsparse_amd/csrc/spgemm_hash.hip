@@ -177,7 +177,9 @@ static int launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *binf
                                 int *long_cnt, TwinMap tw, bool reduce, hipStream_t st)
 {
     const int M = a->M;
-    const int w = pick_w_regular(a->nnz, M, a->nnz_max);
+    static const int w_env = getenv("NSPARSE_RP_W") ? atoi(getenv("NSPARSE_RP_W")) : 0;  // lanes per row, forced (experiments)
+    const int w = (w_env == 1 || w_env == 2 || w_env == 4 || w_env == 8 || w_env == 16 || w_env == 32 || w_env == 64)
+                      ? w_env : pick_w_regular(a->nnz, M, a->nnz_max);
     int grid = ceil_div((long long)M * w, 256);
     if (grid > kSetupMaxGrid - 256) grid = kSetupMaxGrid - 256;
     const int *no_todo = nullptr;
@@ -465,6 +467,11 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     static const int tune_s2 = getenv("NSPARSE_SYM2_BS") ? atoi(getenv("NSPARSE_SYM2_BS")) : 128;
     NSP_SYM_TB(4, 1024, 32768)
     if (tune_s3 == 512) { NSP_SYM_TB(3, 512, 8192) } else if (tune_s3 == 1024) { NSP_SYM_TB(3, 1024, 8192) } else { NSP_SYM_TB(3, 256, 8192) }
+    // bin 2 when no row of the matrix has more than 870 products (a stencil: 729 everywhere): half the table, one
+    // wavefront per row -- 5 KB of LDS per row, so the 32 wavefronts of a CU are 32 rows in flight instead of 15
+    // (NSPARSE_SYM2_SMALL=0: off)
+    static const int sym2_small = getenv("NSPARSE_SYM2_SMALL") ? atoi(getenv("NSPARSE_SYM2_SMALL")) : 1;
+    if (sym2_small && g_coop == 0 && max_prod <= 870) { NSP_SYM_TB(2, 64, 1024) } else
     if (tune_s2 == 256) { NSP_SYM_TB(2, 256, 2048) } else if (tune_s2 == 64) { NSP_SYM_TB(2, 64, 2048) } else { NSP_SYM_TB(2, 128, 2048) }
     NSP_SYM_TB(1, 64, 512)
     if (hist[0] > 0 && now(0)) {
