@@ -13,7 +13,8 @@ constexpr int NB = kMaxBins;
 // ---- bin ladders ------------------------------------------------------------------
 // Symbolic, n = intermediate products of the row (upper bound of its nnz):
 //   bin 0  n <= 32      sub-wave rows, 4 lanes per row, 64-key table per row
-//   bin 1  n <= 435     one workgroup per row,   64 threads, table <=   512 keys ( 2 KiB)
+//   bin 1  n <= 870     one workgroup per row,   64 threads, table <=  1024 keys ( 4 KiB; round 3: was 435 / 512 --
+//                       5 KB of LDS per one-wavefront row still means 32 rows per CU, bin 2 holds 15)
 //   bin 2  n <= 1740                            128 threads,        <=  2048      ( 8 KiB)
 //   bin 3  n <= 6963                            256 threads,        <=  8192      (32 KiB)
 //   bin 4  n <= 27852                          1024 threads,        <= 32768      (128 KiB)
@@ -57,7 +58,7 @@ struct Thr {
     // sorting.  0 disables.
     int rank_span, rank_ratio, rank_max_nz;
 };
-constexpr Thr kSymThr = {32,   {435, 1740, 6963, 27852}, {4096, 16384, 65536}, 8, {262144, 1048576}, 64, 2048,
+constexpr Thr kSymThr = {32,   {870, 1740, 6963, 27852}, {4096, 16384, 65536}, 8, {262144, 1048576}, 64, 2048,
                          8192, 16 * 1048576, 0, 0, 0};
 constexpr Thr kNumThr = {16, {170, 682, 2730, 5461}, {1536, 4096, 12288}, 8, {0, 0}, 0, 0, 0, 0, 65536, 64, 4096};
 constexpr int kRankBin = 9;  // numeric ladder only (the symbolic ladder's bins 9 / 10 are the bit windows)

@@ -99,6 +99,19 @@ static const Thr &num_ladder()
     return t;
 }
 
+// Symbolic ladder in force.  Bin 1 takes rows of up to 870 products with a 1024-slot table (round 3): a one-wavefront
+// row of that instance is 5 KB of LDS, so a CU still holds 32 of them, where bin 2 (two wavefronts, 2048 slots) holds
+// 15.  NSPARSE_SYM1_T=512 restores the 512-slot bin (rows of up to 435 products).
+static const Thr &sym_ladder()
+{
+    static Thr t = [] {
+        Thr v = kSymThr;
+        if (getenv("NSPARSE_SYM1_T") && atoi(getenv("NSPARSE_SYM1_T")) == 512) v.hash_t[0] = 435;
+        return v;
+    }();
+    return t;
+}
+
 // NSPARSE_COOP=1 / 2: wave-cooperative probing in the LDS hash bins (common.h: ht_insert_vec_coop), the
 // alternative BASELINE's north_star names; 0 (default): one lane per key.  Measured in DESIGN 4.1.
 static const int g_coop = getenv("NSPARSE_COOP") ? atoi(getenv("NSPARSE_COOP")) : 0;
@@ -467,13 +480,8 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     static const int tune_s2 = getenv("NSPARSE_SYM2_BS") ? atoi(getenv("NSPARSE_SYM2_BS")) : 128;
     NSP_SYM_TB(4, 1024, 32768)
     if (tune_s3 == 512) { NSP_SYM_TB(3, 512, 8192) } else if (tune_s3 == 1024) { NSP_SYM_TB(3, 1024, 8192) } else { NSP_SYM_TB(3, 256, 8192) }
-    // bin 2 when no row of the matrix has more than 870 products (a stencil: 729 everywhere): half the table, one
-    // wavefront per row -- 5 KB of LDS per row, so the 32 wavefronts of a CU are 32 rows in flight instead of 15
-    // (NSPARSE_SYM2_SMALL=0: off)
-    static const int sym2_small = getenv("NSPARSE_SYM2_SMALL") ? atoi(getenv("NSPARSE_SYM2_SMALL")) : 1;
-    if (sym2_small && g_coop == 0 && max_prod <= 870) { NSP_SYM_TB(2, 64, 1024) } else
     if (tune_s2 == 256) { NSP_SYM_TB(2, 256, 2048) } else if (tune_s2 == 64) { NSP_SYM_TB(2, 64, 2048) } else { NSP_SYM_TB(2, 128, 2048) }
-    NSP_SYM_TB(1, 64, 512)
+    if (sym_ladder().hash_t[0] > 435) { NSP_SYM_TB(1, 64, 1024) } else { NSP_SYM_TB(1, 64, 512) }
     if (hist[0] > 0 && now(0)) {
         hipStream_t st = L.begin(0);
         constexpr int BS = 256, LPR = 4;
@@ -1034,7 +1042,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         const char *e = getenv("NSPARSE_DENSE");
         g_dense_enabled = !(e && e[0] == '0');
     }
-    Thr sym_thr = kSymThr, num_thr = num_ladder();
+    Thr sym_thr = sym_ladder(), num_thr = num_ladder();
     if (!g_dense_enabled) sym_thr.dense_ratio = num_thr.dense_ratio = sym_thr.bits_ratio = num_thr.rank_span = 0;
     NSP_CHECK(hipStreamSynchronize(0));  // inputs queued on the null stream by the caller
     // one fill for both counter blocks and the four words at long_cnt (the two list counters and the
@@ -1469,7 +1477,7 @@ void nsparse_get_spgemm_bins(int *sym, int *num)
 {
     // 18 ints each: tiny, hash_t[4], dense_span[3], dense_ratio, bits_span[2], bits_ratio,
     // bits_min, bits_wide_min, bits_wide_span, rank_span, rank_ratio, rank_max_nz (ratios / rank_span are 0 when NSPARSE_DENSE=0)
-    const nsp::spgemm::Thr *t[2] = {&nsp::spgemm::kSymThr, &nsp::spgemm::num_ladder()};
+    const nsp::spgemm::Thr *t[2] = {&nsp::spgemm::sym_ladder(), &nsp::spgemm::num_ladder()};
     int *out[2] = {sym, num};
     if (nsp::spgemm::g_dense_enabled < 0) {
         const char *e = getenv("NSPARSE_DENSE");
