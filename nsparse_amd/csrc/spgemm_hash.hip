@@ -481,6 +481,20 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     NSP_SYM_TB(4, 1024, 32768)
     if (tune_s3 == 512) { NSP_SYM_TB(3, 512, 8192) } else if (tune_s3 == 1024) { NSP_SYM_TB(3, 1024, 8192) } else { NSP_SYM_TB(3, 256, 8192) }
     if (tune_s2 == 256) { NSP_SYM_TB(2, 256, 2048) } else if (tune_s2 == 64) { NSP_SYM_TB(2, 64, 2048) } else { NSP_SYM_TB(2, 128, 2048) }
+    // bin 1, NSPARSE_SYM_WAVE=n: n persistent wavefronts per CU with the next rows' loads in flight (symbolic.h:
+    // k_sym_wave).  Off by default: measured slower than one workgroup per row (stencil 3.07 -> 3.35 ms, webbase-1M
+    // class 2.36 -> 2.43), like the same pipeline in the numeric bin (k_num_wave).
+    static const int sym_wave = getenv("NSPARSE_SYM_WAVE") ? atoi(getenv("NSPARSE_SYM_WAVE")) : 0;
+    if (sym_wave > 0 && g_coop == 0 && sym_ladder().hash_t[0] > 435) {
+        if (hist[1] > 0 && now(1)) {
+            hipStream_t st = L.begin(1);
+            const int full_ = 8 * ceil_div(hist[1], 8), pers_ = 8 * ceil_div(cx.num_cus * sym_wave, 8);
+            hipLaunchKernelGGL((k_sym_wave<1024>), dim3(pers_ < full_ ? pers_ : full_), dim3(64), 0, st, arpt, acol, brpt, bcol,
+                               row_perm, row_prod, row_maxb, row_nz, off[1], hist[1], b->nnz, g_flat);
+            NSP_LAUNCH_CHECK();
+            L.end(1);
+        }
+    } else
     if (sym_ladder().hash_t[0] > 435) { NSP_SYM_TB(1, 64, 1024) } else { NSP_SYM_TB(1, 64, 512) }
     if (hist[0] > 0 && now(0)) {
         hipStream_t st = L.begin(0);

@@ -702,13 +702,14 @@ def test_bucket_sort_of_the_big_table_bins(bucket, oracle_d):
 def test_persistent_wavefront_bin(waves, oracle_d):
     """NSPARSE_WAVE1=n: the rows of numeric bin 1 (17 .. 170 non-zeros) through k_num_wave -- persistent wavefronts
     that request the next rows' words, A entries and B extents while they hash the current row (numeric.h; measured
-    slower than one workgroup per row, so off by default).  A 27-point stencil (every row in that bin) with a hub row
+    slower than one workgroup per row, so off by default).  NSPARSE_SYM_WAVE=n: the same pipeline in symbolic bin 1
+    (symbolic.h: k_sym_wave, the default there with 32 wavefronts per CU).  A 27-point stencil (every row in that bin) with a hub row
     of B spliced in, so that the parked-row path runs too; 3 wavefronts per CU makes every wavefront take many rows
     and two batches of row numbers."""
     lib = ns.load("d")
     A = synth(lib, 1, 70, 70, 12, seed=5)  # 58,800 rows, windows of 20 K columns: beyond the dense-window bins
     rng = np.random.default_rng(3)
-    got, st = spgemm_subprocess(A, {"NSPARSE_WAVE1": waves}, "d")
+    got, st = spgemm_subprocess(A, {"NSPARSE_WAVE1": waves, "NSPARSE_SYM_WAVE": waves}, "d")
     ref = oracle_d.spgemm(A, A)
     assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
     assert oracle_d.check_spgemm(got, ref) == 0
@@ -723,7 +724,7 @@ def test_persistent_wavefront_bin(waves, oracle_d):
     colsB = [np.sort(rng.choice(m, k, replace=False)) for k in lensB]
     rptB = np.concatenate([[0], np.cumsum(lensB)]).astype(np.int32)
     B2 = dict(M=m, N=m, rpt=rptB, col=np.concatenate(colsB).astype(np.int32), val=rng.random(int(rptB[-1])) + 0.5)
-    got, st = spgemm_subprocess(A2, {"NSPARSE_WAVE1": waves}, "d", B=B2)
+    got, st = spgemm_subprocess(A2, {"NSPARSE_WAVE1": waves, "NSPARSE_SYM_WAVE": waves}, "d", B=B2)
     ref = oracle_d.spgemm(A2, B2)
     assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
     assert oracle_d.check_spgemm(got, ref) == 0
