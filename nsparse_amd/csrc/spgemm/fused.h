@@ -1,5 +1,5 @@
 // spgemm/fused.h -- the tails of the set-up and of the symbolic phase as ONE launch each, for matrices of
-// up to 256 K rows.
+// up to 1 M rows (one row per thread up to 256 K rows, four beyond).
 // Part of the spgemm_hash.hip translation unit.
 //
 // Between the big kernels of a call sit chains of 1024-rows-per-workgroup helpers that each run for a
@@ -145,10 +145,10 @@ __device__ __forceinline__ int rank_in_bin(int bin, int *s_cnt)
 // totals) was complete at the barrier, so one wavefront of workgroup 0 publishes at once while the others
 // place their rows: a workgroup's rows follow those of the workgroups before it in every bin (sums of the
 // records written before the barrier -- no atomics, and the lists come out in ascending row order).
-// returns the list position of the thread's row (-1: not listed)
-__device__ __forceinline__ int fused_tail(int i, int M, int excl, int *out_scan, int bin, bool listed, int rank,
-                                           int *s_base, int *s_pref /* kFusedRec */, int *s_h /* NB */, BinState *bs,
-                                           int *perm, const FusedSync &fs, bool set_nnz)
+// Leaves s_pref[0] = scan carry of the workgroups before this one and s_base[q] = where this workgroup's rows of
+// bin q start in the permutation; the caller then places its rows (fused_place).
+__device__ __forceinline__ void fused_tail(int *s_base, int *s_pref /* kFusedRec */, int *s_h /* NB */, BinState *bs,
+                                           const FusedSync &fs, bool set_nnz)
 {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     static_assert(kFusedRec + 2 <= 16, "one wavefront per quantity");
@@ -177,6 +177,12 @@ __device__ __forceinline__ int fused_tail(int i, int M, int excl, int *out_scan,
         s_base[threadIdx.x] = off + s_pref[1 + threadIdx.x];
     }
     __syncthreads();
+}
+
+// row i of this thread: its scan value and its place in the permutation; returns the list position (-1: not listed)
+__device__ __forceinline__ int fused_place(int i, int M, int excl, int *out_scan, int bin, bool listed, int rank,
+                                            const int *s_base, const int *s_pref, int *perm)
+{
     if (out_scan && i <= M) out_scan[i] = s_pref[0] + excl;
     if (!listed) return -1;
     perm[s_base[bin] + rank] = i;
@@ -185,6 +191,9 @@ __device__ __forceinline__ int fused_tail(int i, int M, int excl, int *out_scan,
 
 // ---- set-up tail: fold the per-workgroup partials of k_row_products, offsets of the column bitmaps,
 //      symbolic row permutation, publish ---------------------------------------------------------------
+// R rows per thread: workgroup b owns rows [b * R * 1024, (b + 1) * R * 1024) in R slices of 1024 (R = 1 up to 256 K
+// rows, R = 4 up to 1 M: the grid stays at one workgroup per CU at most; the row records -- desc -- only with R = 1)
+template <int R>
 __global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict__ partial, int nparts,
                                                      BinState *bs, const int *__restrict__ bm_words,
                                                      int *__restrict__ bm_off,
@@ -222,25 +231,32 @@ __global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict
         }
     }
     // (2) bitmap words of this workgroup's rows, scanned; (3) bin and rank of every listed row
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    const int v = (bm_words && i <= M) ? bm_words[i] : 0;
-    int total = 0;
-    const int excl = block_scan_1024(v, s_w, total);
-    const bool listed = i < M && !(skip && skip[i]);
-    int bin = -1;
+    int v[R], excl[R], bin[R], rank[R];
+    bool listed[R];
     int4 d0 = make_int4(0, 0, 0, 0), d1 = d0;
-    if (listed) {
-        const int ni = row_prod[i], sp = row_span[i];
-        bin = bin_of(ni, sp, thr, ni);
-        if (bin >= kDenseBin0) {
-            atomicMax(&s_span[bin], sp);
-            if (desc) {
-                d0 = make_int4(i, row_lo[i], sp, row_maxb[i]);
-                d1 = make_int4(arpt[i], arpt[i + 1], ni, 0);
+    int carry = 0;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int i = ((int)blockIdx.x * R + k) * 1024 + (int)threadIdx.x;
+        v[k] = (bm_words && i <= M) ? bm_words[i] : 0;
+        int total = 0;
+        excl[k] = carry + block_scan_1024(v[k], s_w, total);
+        carry += total;
+        listed[k] = i < M && !(skip && skip[i]);
+        bin[k] = -1;
+        if (listed[k]) {
+            const int ni = row_prod[i], sp = row_span[i];
+            bin[k] = bin_of(ni, sp, thr, ni);
+            if (bin[k] >= kDenseBin0) {
+                atomicMax(&s_span[bin[k]], sp);
+                if (R == 1 && desc) {
+                    d0 = make_int4(i, row_lo[i], sp, row_maxb[i]);
+                    d1 = make_int4(arpt[i], arpt[i + 1], ni, 0);
+                }
             }
         }
+        rank[k] = rank_in_bin(bin[k], s_cnt);  // (slices in order: a later slice ranks behind the earlier ones)
     }
-    const int rank = rank_in_bin(bin, s_cnt);
     __syncthreads();
     if (threadIdx.x < NB) {
         if (s_acc[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], (int)s_acc[threadIdx.x]);
@@ -255,21 +271,26 @@ __global__ __launch_bounds__(1024) void k_setup_tail(const long long *__restrict
         if (s_acc[NB + 2]) atomicAdd((unsigned long long *)&bs->bm_total, s_acc[NB + 2]);
         if (s_acc[NB + 4]) atomicAdd((unsigned long long *)&bs->list_total, s_acc[NB + 4]);
         if (s_alen) atomicMax((unsigned long long *)&bs->max_alen, (unsigned long long)s_alen);
-        __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!grid_barrier(fs, &s_ok)) return;
-    const int pos = fused_tail(i, M, excl, bm_words ? bm_off : nullptr, bin, listed, rank, s_base, s_pref, s_h, bs,
-                               perm, fs, false);
-    if (desc && pos >= 0 && bin >= kDenseBin0) {
-        d1.w = s_pref[0] + excl;  // this row's bitmap offset (what the scan wrote to bm_off[i])
-        desc[3 * pos] = d0;
-        desc[3 * pos + 1] = d1;
-        desc[3 * pos + 2] = make_int4(v, 0, 0, 0);
+    fused_tail(s_base, s_pref, s_h, bs, fs, false);
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int i = ((int)blockIdx.x * R + k) * 1024 + (int)threadIdx.x;
+        const int pos = fused_place(i, M, excl[k], bm_words ? bm_off : nullptr, bin[k], listed[k], rank[k], s_base, s_pref, perm);
+        if (R == 1 && desc && pos >= 0 && bin[k] >= kDenseBin0) {
+            d1.w = s_pref[0] + excl[k];  // this row's bitmap offset (what the scan wrote to bm_off[i])
+            desc[3 * pos] = d0;
+            desc[3 * pos + 1] = d1;
+            desc[3 * pos + 2] = make_int4(v[k], 0, 0, 0);
+        }
     }
 }
 
 // ---- symbolic tail: twins take their leader's result, node-block groups, C.rpt, numeric histogram and
 //      row permutation, publish (k_twin_copy, k_twin_groups, scan, k_hist, k_bin_scatter, k_publish) -----
+template <int R>
 __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ twin_of,
                                                         const int *__restrict__ members, int *row_nz,
                                                         int *row_span_num, int *bm_off,
@@ -281,7 +302,7 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
                                                         const int *__restrict__ row_lo,
                                                         const int *__restrict__ row_maxb)
 {
-    // desc != nullptr: a record per row listed in a window bin, in list order, for the node-block kernel
+    // desc != nullptr (R = 1 only): a record per row listed in a window bin, in list order, for the node-block kernel
     // (block.h): {row, lo, span, longest B row | bitmap offset, first A entry, A entries, rows in the group |
     // member rows}
     __shared__ int s_hist[NB], s_cnt[NB], s_base[NB], s_span[NB], s_w[16], s_pref[kFusedRec], s_h[NB];
@@ -294,10 +315,16 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
         s_sum = 0;
     }
     __syncthreads();
-    const int i = blockIdx.x * 1024 + threadIdx.x;
-    int nz = 0, bin = -1, hbin = -1;
-    bool listed = false;
+    int excl[R], bin[R], rank[R];
+    bool listed[R];
     int4 d0 = make_int4(0, 0, 0, 0), d1 = d0, d2 = d0;
+    int carry = 0;
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+    const int i = ((int)blockIdx.x * R + k) * 1024 + (int)threadIdx.x;
+    int nz = 0, hbin = -1;
+    bin[k] = -1;
+    listed[k] = false;
     if (i < M) {
         const int l = twin_of ? twin_of[i] : -1;
         const int lead = l >= 0 ? l : i;
@@ -330,12 +357,12 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
             }
             grp[i] = (unsigned char)code;
         }
-        listed = (code & 3) == 0;
-        if (listed) {
-            bin = hbin;
-            if (bin >= kDenseBin0) {
-                atomicMax(&s_span[bin], sp);
-                if (desc) {
+        listed[k] = (code & 3) == 0;
+        if (listed[k]) {
+            bin[k] = hbin;
+            if (hbin >= kDenseBin0) {
+                atomicMax(&s_span[hbin], sp);
+                if (R == 1 && desc) {
                     const int ra = code >> 2, ab = arpt[i];
                     d0 = make_int4(i, row_lo[i], sp, row_maxb[i]);
                     d1 = make_int4(bm_off ? bm_off[i] : 0, ab, arpt[i + 1] - ab, ra);
@@ -368,8 +395,10 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
         }
     }
     int total = 0;
-    const int excl = block_scan_1024(nz, s_w, total);
-    const int rank = rank_in_bin(bin, s_cnt);
+    excl[k] = carry + block_scan_1024(nz, s_w, total);
+    carry += total;
+    rank[k] = rank_in_bin(bin[k], s_cnt);
+    }  // slices
     __syncthreads();
     if (threadIdx.x < NB) {
         if (s_hist[threadIdx.x]) atomicAdd(&bs->hist[threadIdx.x], s_hist[threadIdx.x]);
@@ -382,14 +411,19 @@ __global__ __launch_bounds__(1024) void k_numeric_setup(const int *__restrict__ 
         if (s_max) atomicMax(&bs->maxv, s_max);
         if (s_sum) atomicAdd((unsigned long long *)&bs->total, s_sum);
         if (s_far) atomicAdd(&bs->far_twins, s_far);
-        __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fs.blk + blockIdx.x * kFusedRec, carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (!grid_barrier(fs, &s_ok)) return;
-    const int pos = fused_tail(i, M, excl, crpt, bin, listed, rank, s_base, s_pref, s_h, bs, perm, fs, true);
-    if (desc && pos >= 0 && bin >= kDenseBin0) {
-        desc[3 * pos] = d0;
-        desc[3 * pos + 1] = d1;
-        desc[3 * pos + 2] = d2;
+    fused_tail(s_base, s_pref, s_h, bs, fs, true);
+#pragma unroll
+    for (int k = 0; k < R; k++) {
+        const int i = ((int)blockIdx.x * R + k) * 1024 + (int)threadIdx.x;
+        const int pos = fused_place(i, M, excl[k], crpt, bin[k], listed[k], rank[k], s_base, s_pref, perm);
+        if (R == 1 && desc && pos >= 0 && bin[k] >= kDenseBin0) {
+            desc[3 * pos] = d0;
+            desc[3 * pos + 1] = d1;
+            desc[3 * pos + 2] = d2;
+        }
     }
 }
 

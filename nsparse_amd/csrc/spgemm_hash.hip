@@ -42,7 +42,7 @@
 //   spgemm/common.h        bin ladders, BinState, hash probe, product walk, wave helpers
 //   spgemm/setup.h         k_b_info, k_row_products (+ twin_probe), k_reduce_partials, k_hist, k_bin_scatter,
 //                          k_publish, k_ab_compare, k_finish
-//   spgemm/fused.h         k_setup_tail, k_numeric_setup                  (the helper chains as one launch, M < 256 K)
+//   spgemm/fused.h         k_setup_tail, k_numeric_setup                  (the helper chains as one launch, M < 1 M)
 //   spgemm/symbolic.h      k_sym_small, k_sym_tb, k_sym_global            (bins 0-5)
 //   spgemm/numeric.h       k_num_small, k_num_tb, k_num_global            (bins 0-4, fallback)
 //   spgemm/window.h        k_sym_dense, k_sym_bits, k_num_dense           (bins 6-10)
@@ -1127,9 +1127,12 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     int *bm_off = (int *)(c_ptr[o_bmo]);
     int *row_span_num = (int *)(c_ptr[o_spn]);
     const bool use_bm = !numeric_only && num_thr.dense_ratio > 0;
-    // matrices of up to 256 K rows: the helper chains behind the big kernels are one launch each (fused.h)
+    // matrices of up to 1 M rows: the helper chains behind the big kernels are one launch each (fused.h)
     static const bool fused_on = !(getenv("NSPARSE_FUSED") && atoi(getenv("NSPARSE_FUSED")) == 0);
-    const int fgrid = ceil_div(M + 1, 1024);
+    // rows per thread of the fused tails: one up to 256 K rows, four up to 1 M (NSPARSE_FUSED_BIG=0: chains beyond 256 K)
+    static const bool fused_big = !(getenv("NSPARSE_FUSED_BIG") && atoi(getenv("NSPARSE_FUSED_BIG")) == 0);
+    const int frows = (M + 1 <= kFusedMaxBlocks * 1024 || !fused_big) ? 1 : 4;
+    const int fgrid = ceil_div(M + 1, 1024 * frows);
     // (one 1024-thread workgroup per CU at most: the grid barrier needs all of them resident, also on a
     //  partitioned or CU-masked device)
     // NSPARSE_FUSED_FORCE=1 (tests): skip the census, so that a CU-masked device exercises the time-out path
@@ -1147,15 +1150,18 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     const int grid_m = ceil_div(M, 1024);
     // (row records: not with the cache off -- two more megabyte-sized hipMalloc / hipFree pairs cost more
     //  than the round trips they save)
-    if (pooled && fuse && use_bm && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
+    if (pooled && fuse && frows == 1 && use_bm && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
         sym_desc = (int4 *)dev_alloc(sizeof(int4) * 3 * (size_t)M);
     if (fuse) {
         const int seq = ++cx.seq;
         const FusedSync fs = {cx.d_scratch + 244, cx.d_scratch + 512, cx.d_mapped, cx.d_mapped + 120, seq, cx.d_mapped + 123};
-        hipLaunchKernelGGL(k_setup_tail, dim3(fgrid), dim3(1024), 0, s0, (const long long *)partial, nparts, d_sym,
-                           use_bm ? (const int *)bm_words : (const int *)nullptr, bm_off, (const int *)row_prod,
-                           (const int *)row_span, M, sym_thr, row_perm, (const unsigned char *)twin, fs, sym_desc,
-                           (const int *)a->d_rpt, (const int *)row_lo, (const int *)row_maxb);
+#define NSP_SETUP_TAIL(RX)                                                                        \
+        hipLaunchKernelGGL(k_setup_tail<RX>, dim3(fgrid), dim3(1024), 0, s0, (const long long *)partial, nparts, d_sym, \
+                           use_bm ? (const int *)bm_words : (const int *)nullptr, bm_off, (const int *)row_prod,  \
+                           (const int *)row_span, M, sym_thr, row_perm, (const unsigned char *)twin, fs, sym_desc, \
+                           (const int *)a->d_rpt, (const int *)row_lo, (const int *)row_maxb)
+        if (frows == 1) NSP_SETUP_TAIL(1); else NSP_SETUP_TAIL(4);
+#undef NSP_SETUP_TAIL
         NSP_LAUNCH_CHECK();
         tm.mark(1, s0);
         // two copies of one matrix (C = A * A as the reference's sample calls it)?  Compared while the host is
@@ -1301,18 +1307,21 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
     const int *num_span = numeric_only ? row_span : row_span_num;
     if (!numeric_only && bm == nullptr) num_thr.dense_ratio = num_thr.rank_span = 0;
-    if (pooled && fuse && bm && lean_on && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
+    if (pooled && fuse && frows == 1 && bm && lean_on && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
         blk_desc = (int4 *)dev_alloc(sizeof(int4) * 3 * (size_t)M);
     if (fuse) {
         // twins' results, groups, C.rpt, histogram, permutation and the publish in one launch (fused.h)
         const int seq = ++cx.seq;
         const FusedSync fs = {cx.d_scratch + 246, cx.d_scratch + 512 + kFusedMaxBlocks * kFusedRec,
                               reinterpret_cast<int *>(h_num_dev), cx.d_mapped + 121, seq, cx.d_mapped + 123};
-        hipLaunchKernelGGL(k_numeric_setup, dim3(fgrid), dim3(1024), 0, s0,
-                           S.twin_rows > 0 ? (const int *)twin_of : (const int *)nullptr, (const int *)members, row_nz,
-                           row_span_num, bm ? bm_off : (int *)nullptr, (const int *)row_prod, M, num_thr, d_num,
-                           c->d_rpt, row_perm, grp, fs, blk_desc, (const int *)a->d_rpt, (const int *)row_lo,
-                           (const int *)row_maxb);
+#define NSP_NUM_SETUP(RX)                                                                         \
+        hipLaunchKernelGGL(k_numeric_setup<RX>, dim3(fgrid), dim3(1024), 0, s0,                                    \
+                           S.twin_rows > 0 ? (const int *)twin_of : (const int *)nullptr, (const int *)members, row_nz, \
+                           row_span_num, bm ? bm_off : (int *)nullptr, (const int *)row_prod, M, num_thr, d_num,     \
+                           c->d_rpt, row_perm, grp, fs, blk_desc, (const int *)a->d_rpt, (const int *)row_lo,       \
+                           (const int *)row_maxb)
+        if (frows == 1) NSP_NUM_SETUP(1); else NSP_NUM_SETUP(4);
+#undef NSP_NUM_SETUP
         NSP_LAUNCH_CHECK();
         wait_published(121, seq, s0);
         retry = __atomic_load_n(cx.h_mapped + 123, __ATOMIC_ACQUIRE) == seq;
