@@ -100,7 +100,7 @@ struct BinState {
     long long list_total;            // sum of min(products, window) over those rows: capacity of the list slab
     unsigned long long list_cursor;  // bump allocator of the symbolic kernels (one returning atomic per row)
     int queue_head3;                 // row queue of the listed numeric kernel
-    int pad_;
+    int twin_sample;                 // some pattern occurs twice among the sampled rows of A (k_b_info; big matrices only)
 };
 static_assert(sizeof(BinState) <= 64 * sizeof(int), "k_publish and the fused tails copy one word per lane");
 

@@ -97,6 +97,35 @@ __global__ __launch_bounds__(256) void k_col_range_fold(const unsigned int *__re
     }
 }
 
+// contribution of one column id to the order-independent key of a row pattern (splitmix64 finaliser)
+__device__ __forceinline__ unsigned long long col_key(int c)
+{
+    unsigned long long z = (unsigned long long)(unsigned)c + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+
+// Is twin detection worth its price on this matrix?  On a matrix without twin rows (a scalar stencil) the pattern map
+// costs k_row_products one returning 64-bit atomic per row and more than doubles its time (27-point stencil, 10^6 rows:
+// 121 -> 263 us), for nothing.  So for matrices of kTwinSampleMin rows and more k_b_info -- which runs first anyway --
+// looks at a SAMPLE of the rows of A: the first 64 rows of every 1024 (consecutive rows, so that neighbouring twins
+// are seen; a sixteenth of the matrix, so that scattered ones are seen by chance), rows of 1 .. 4096 entries, one
+// wavefront per row.  Their pattern keys go into a table (48 bits of the key + a 16-bit tag of this call, so the table
+// needs no clearing: words with another tag are free); the first key that is already there raises bs->twin_sample,
+// and k_row_products probes only if it is raised.  Exact on the sample (tests/gpu_util.py: twin_rows mirrors the
+// rule); a miss only costs the optimisation, never the result.
+constexpr int kTwinSampleMin = 131072;
+struct TwinSample {
+    const int *arpt;
+    const int *acol;
+    int M;
+    unsigned long long *tab;  // nullptr: no sampling (small matrices: always probe)
+    unsigned int mask;
+    unsigned int tag;         // 1 .. 65535
+};
+
 template <int W>
 __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                 int K, BInfo *__restrict__ info, BinState *bs,
@@ -104,8 +133,43 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
                                                 const int *__restrict__ todo,
                                                 const unsigned int *__restrict__ range,
                                                 unsigned char *__restrict__ btwin,
-                                                unsigned long long *__restrict__ fill, long long fill_words)
+                                                unsigned long long *__restrict__ fill, long long fill_words,
+                                                TwinSample ts = TwinSample{nullptr, nullptr, 0, nullptr, 0u, 0u})
 {
+    if (ts.tab) {  // (first: the workgroups that find no rows of B below must not leave before it)
+        const long long ns = (long long)((ts.M + 1023) >> 10) * 64;
+        const int wl = threadIdx.x & 63;
+        for (long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); q < ns; q += (long long)gridDim.x * 4) {
+            const long long r64 = ((q >> 6) << 10) + (q & 63);
+            if (r64 >= ts.M) continue;
+            const int r = (int)r64;
+            const int b = ts.arpt[r], len = ts.arpt[r + 1] - b;
+            if (len < 1 || len > 4096) continue;
+            unsigned long long key = 0;
+            for (int k = wl; k < len; k += 64) key += col_key(ts.acol[b + k]);
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) key += __shfl_xor(key, o);
+            if (wl == 0) {
+                key += 0x9E3779B97F4A7C15ull * (unsigned long long)len;
+                const unsigned long long mine = (key & ~0xFFFFull) | ts.tag;
+                unsigned int sl = (unsigned int)(key >> 20) & ts.mask;
+                for (unsigned int tries = 0; tries <= ts.mask; tries++) {
+                    unsigned long long cur = __hip_atomic_load(ts.tab + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned int)(cur & 0xFFFFull) != ts.tag) {  // free: a word of another call (or none)
+                        const unsigned long long old = atomicCAS(ts.tab + sl, cur, mine);
+                        if (old == cur) break;
+                        cur = old;
+                        if ((unsigned int)(cur & 0xFFFFull) != ts.tag) continue;  // (cannot happen: only this call writes)
+                    }
+                    if (cur == mine) {
+                        bs->twin_sample = 1;  // plain store: everybody who finds a repeat writes the same word
+                        break;
+                    }
+                    sl = (sl + 1) & ts.mask;
+                }
+            }
+        }
+    }
     // fill: fill_words 64-bit words set to all ones on the way (the twin map of k_row_products, which runs
     // next: a fill launch less).
     for (long long w = (long long)blockIdx.x * 256 + threadIdx.x; w < fill_words; w += (long long)gridDim.x * 256)
@@ -176,15 +240,6 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
     }
 }
 
-// contribution of one column id to the order-independent key of a row pattern (splitmix64 finaliser)
-__device__ __forceinline__ unsigned long long col_key(int c)
-{
-    unsigned long long z = (unsigned long long)(unsigned)c + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-
 // Rows of A with EQUAL column patterns ("twin rows": the degrees of freedom of one mesh node), wherever
 // they are: a hash map from pattern to the first row that claimed it, probed by the W lanes that have
 // just walked the row in k_row_products.  An empty slot is claimed with one CAS (the row becomes the
@@ -200,6 +255,7 @@ struct TwinMap {
     unsigned char *twin;
     int *fcnt;     // leader -> followers that signed up - 1 (only a brake, see below)
     int *members;  // leader -> the lowest and the highest of the followers that signed up (-1: none)
+    const int *sample_flag;  // nullptr: always probe; else probe only if *sample_flag != 0 (TwinSample, k_b_info)
 };
 
 template <int W>
@@ -328,6 +384,10 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
     // way and twin_probe groups the rows with EQUAL patterns (the degrees of freedom of one node of a
     // finite-element mesh, wherever the numbering put them).
     const int nrows = todo ? (*long_cnt < kLongCap ? *long_cnt : kLongCap) : M;
+    // big matrices: the pattern map is used only when the sample of k_b_info saw a pattern twice (TwinSample)
+    const bool probe = tw.table != nullptr &&
+                       (tw.sample_flag == nullptr ||
+                        __hip_atomic_load(tw.sample_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
     if (!todo && blockIdx.x == 0 && threadIdx.x == 0) {  // scan tails (instead of two memset launches)
         bm_words[M] = 0;
         row_nz[M] = 0;
@@ -371,7 +431,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
                 BInfo bi[4];
 #pragma unroll
                 for (int u = 0; u < 4; u++) c[u] = __builtin_nontemporal_load(acol + j + u * W);
-                if (tw.table) {
+                if (probe) {
 #pragma unroll
                     for (int u = 0; u < 4; u++) key += col_key(c[u]);
                 }
@@ -387,7 +447,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
             }
             for (; j < e; j += W) {
                 const int c = __builtin_nontemporal_load(acol + j);
-                if (tw.table) key += col_key(c);
+                if (probe) key += col_key(c);
                 const BInfo bi = binfo[c];
                 n += bi.len;
                 mb = bi.len > mb ? bi.len : mb;
@@ -408,7 +468,7 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
         // (rows of the tiny symbolic bin are not worth a probe: nothing to skip there, and they are no
         //  candidates for the node-block groups -- on a web graph that is most of a million rows)
         if (tw.table && row < M) {
-            if (n > thr.tiny) {
+            if (probe && n > thr.tiny) {
                 leader = twin_probe<W>(arpt, acol, row, key, tw, lane);
             } else if (lane == 0) {
                 tw.twin_of[row] = -1;
@@ -554,8 +614,11 @@ __global__ __launch_bounds__(64) void k_publish(const BinState *__restrict__ src
 // (a look first: when B is another matrix every workgroup finds one).
 __global__ __launch_bounds__(256) void k_ab_compare(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                     const int *__restrict__ brpt, const int *__restrict__ bcol,
-                                                    int M, int nnz, BinState *bs)
+                                                    int M, int nnz, BinState *bs, const int *__restrict__ need = nullptr)
 {
+    // need (big matrices, TwinSample): the answer only matters when there are twin rows; no repeat in the sample = no
+    // probing = no twins, and 26 M entries of the stencil need not be compared (39 us behind the set-up tail)
+    if (need && __hip_atomic_load(need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
     bool diff = false;
     const int stride = gridDim.x * 256;
     for (int i = blockIdx.x * 256 + threadIdx.x; i <= M; i += stride) diff |= arpt[i] != brpt[i];

@@ -1016,11 +1016,19 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     unsigned int tsize = 1024;
     while (find_twins && tsize < 2u * (unsigned int)M) tsize <<= 1;
     const long long twin_fill_words = find_twins ? (long long)tsize + ((long long)M * (1 + kGroupMembers) + 1) / 2 : 0;
+    // matrices of kTwinSampleMin rows and more: k_b_info samples the rows of A, k_row_products probes the pattern map
+    // only if the sample holds a pattern twice (setup.h: TwinSample; NSPARSE_TWIN_SAMPLE=0: always probe)
+    static const bool sample_on = !(getenv("NSPARSE_TWIN_SAMPLE") && atoi(getenv("NSPARSE_TWIN_SAMPLE")) == 0);
+    unsigned int sample_slots = 0;
+    if (find_twins && sample_on && M >= kTwinSampleMin) {
+        sample_slots = 1024;
+        while (sample_slots < 2u * 64u * (unsigned int)((M + 1023) >> 10)) sample_slots <<= 1;  // load <= 1/2
+    }
     // (with the cache switched off -- "reference-compatible" timing -- every array is its own hipMalloc as
     //  before: the runtime serves small blocks from pools, one block of megabytes is mapped for real and
     //  made that timing 1.17 -> 1.62 ms)
     const bool pooled = dev_cache_enabled();
-    constexpr int kCarveMax = 16;
+    constexpr int kCarveMax = 20;
     size_t carve = 0, c_off[kCarveMax], c_sz[kCarveMax];
     int ncarve = 0;
     auto reserve = [&](size_t bytes) {
@@ -1038,7 +1046,8 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
               o_bmw = reserve(sizeof(int) * (M1 + 1)), o_bmo = reserve(sizeof(int) * (M1 + 1)),
               o_spn = reserve(sizeof(int) * M1), o_btwin = reserve(want_btwin ? (size_t)K : 0),
               o_table = reserve(sizeof(unsigned long long) * (size_t)twin_fill_words),
-              o_twof = reserve(find_twins ? sizeof(int) * M1 : 0), o_twin = reserve(find_twins ? M1 : 0);
+              o_twof = reserve(find_twins ? sizeof(int) * M1 : 0), o_twin = reserve(find_twins ? M1 : 0),
+              o_stab = reserve(sizeof(unsigned long long) * (size_t)sample_slots);
     char *block_base = pooled ? (char *)dev_alloc(carve) : nullptr;
     char *c_ptr[kCarveMax];
     for (int q = 0; q < ncarve; q++)
@@ -1074,7 +1083,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     unsigned char *twin = nullptr;
     int *twin_of = nullptr, *fcnt = nullptr, *members = nullptr;
     unsigned long long *ttable = nullptr;
-    TwinMap tw = {nullptr, 0u, 0, nullptr, nullptr, nullptr, nullptr};
+    TwinMap tw = {nullptr, 0u, 0, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (find_twins) {
         // table, sign-up counters and members side by side, one fill (all ones = free / -1 / none;
         // k_b_info fills them on its way, in 64-bit words)
@@ -1083,8 +1092,13 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         members = fcnt + M;
         twin_of = (int *)(c_ptr[o_twof]);
         twin = (unsigned char *)(c_ptr[o_twin]);
-        tw = TwinMap{ttable, tsize - 1, a->nnz, twin_of, twin, fcnt, members};
+        tw = TwinMap{ttable, tsize - 1, a->nnz, twin_of, twin, fcnt, members,
+                     sample_slots ? (const int *)&d_sym->twin_sample : (const int *)nullptr};
     }
+    TwinSample tsamp = {nullptr, nullptr, 0, nullptr, 0u, 0u};
+    if (sample_slots)
+        tsamp = TwinSample{a->d_rpt, a->d_col, M, (unsigned long long *)(c_ptr[o_stab]), sample_slots - 1,
+                           1u + (unsigned int)(cx.seq % 65535)};
     // ---- setup: column window of every B row, products + window per C row, symbolic bins ----
     const bool same_shape = find_twins && lean_on && M == K && a->N == b->N && a->nnz == b->nnz;
     {
@@ -1109,7 +1123,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 #define NSP_BI(W)                                                                              \
     case W:                                                                                    \
         hipLaunchKernelGGL(k_b_info<W>, dim3(gb), dim3(256), 0, s0, b->d_rpt, b->d_col, K, binfo, d_sym, \
-                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range, btwin, ttable, twin_fill_words); \
+                           blist, long_cnt, kLongFactor * W, (const int *)nullptr, range, btwin, ttable, twin_fill_words, tsamp); \
         break;
         switch (wb) {
             NSP_BI(1) NSP_BI(2) NSP_BI(4) NSP_BI(8) NSP_BI(16) NSP_BI(32) NSP_BI(64)
@@ -1170,7 +1184,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
             int gc = ceil_div(a->nnz, 4 * 256);
             gc = gc < 1 ? 1 : (gc > 2048 ? 2048 : gc);
             hipLaunchKernelGGL(k_ab_compare, dim3(gc), dim3(256), 0, s0, (const int *)a->d_rpt, (const int *)a->d_col,
-                               (const int *)b->d_rpt, (const int *)b->d_col, M, a->nnz, d_num);
+                               (const int *)b->d_rpt, (const int *)b->d_col, M, a->nnz, d_num, tw.sample_flag);
             NSP_LAUNCH_CHECK();
         }
         wait_published(120, seq, s0);
@@ -1226,7 +1240,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                 unsigned long long *tb = (unsigned long long *)btw_block;
                 int *fc = (int *)(tb + tsb);
                 b_twin_of = (int *)(btw_block + sizeof(unsigned long long) * words64);
-                const TwinMap tmb = {tb, tsb - 1, b->nnz, b_twin_of, (unsigned char *)(b_twin_of + K), fc, fc + K};
+                const TwinMap tmb = {tb, tsb - 1, b->nnz, b_twin_of, (unsigned char *)(b_twin_of + K), fc, fc + K, nullptr};
                 hipStream_t sb = cx.stream[kMaxBins - 1];  // (no bin of either ladder runs there)
                 NSP_CHECK(hipEventRecord(cx.ev_fork, s0));
                 NSP_CHECK(hipStreamWaitEvent(sb, cx.ev_fork, 0));

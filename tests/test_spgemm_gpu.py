@@ -731,6 +731,27 @@ def test_persistent_wavefront_bin(waves, oracle_d):
     assert st["num"][1] > 0, st["num"][:8]
 
 
+@pytest.mark.parametrize("kind,dims,twins", [(1, (52, 52, 52), False), (0, (12, 12, 310), True), (5, (12, 12, 310), True)])
+def test_twin_sample_of_big_matrices(kind, dims, twins, lib_d, oracle_d):
+    """Matrices of 131,072 rows and more: k_b_info looks at a sample of the rows of A (the first 64 of every 1024) and
+    k_row_products uses the pattern map only if the sample holds a pattern twice (setup.h: TwinSample) -- a scalar
+    stencil skips the map (one returning atomic per row for nothing), finite-element matrices keep it whether their
+    twin rows are neighbours (kind 0) or scattered (kind 5: seen by chance, a sixteenth of the rows is sampled).  The
+    count is exact on the sample: gpu_util.twin_rows mirrors the rule."""
+    A = synth(lib_d, kind, *dims, seed=11)
+    assert A["M"] >= 131072
+    ref = oracle_d.spgemm(A, A)
+    got, st = spgemm(lib_d, A)
+    assert_parity(oracle_d, got, ref)
+    rp, _, _ = oracle_d.nprod(A["rpt"], A["col"], A["rpt"])
+    tw = twin_rows(A, rp)
+    assert st.twin_rows == int(tw.sum())
+    assert (st.twin_rows > A["M"] // 2) if twins else st.twin_rows == 0
+    # the switch: always probe
+    got0, st0 = spgemm_subprocess(A, {"NSPARSE_TWIN_SAMPLE": "0"}, "d")
+    assert np.array_equal(got0["rpt"], ref["rpt"]) and np.array_equal(got0["col"], ref["col"])
+
+
 def test_keyed_runs_for_a_general_b(oracle_d):
     """A * B with B != A, both finite-element matrices whose twin rows are scattered (kind 5, different
     renumberings): the node-block kernel gets the pattern leaders of B's rows from k_b_twins (setup.h) instead of
