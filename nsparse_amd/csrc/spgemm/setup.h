@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
                         if ((unsigned int)(cur & 0xFFFFull) != ts.tag) continue;  // (cannot happen: only this call writes)
                     }
                     if (cur == mine) {
-                        bs->twin_sample = 1;  // plain store: everybody who finds a repeat writes the same word
+                        __hip_atomic_store(&bs->twin_sample, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all write 1)
                         break;
                     }
                     sl = (sl + 1) & ts.mask;
