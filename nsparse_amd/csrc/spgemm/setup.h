@@ -138,20 +138,25 @@ __global__ __launch_bounds__(256) void k_b_info(const int *__restrict__ brpt, co
 {
     if (ts.tab) {  // (first: the workgroups that find no rows of B below must not leave before it)
         const long long ns = (long long)((ts.M + 1023) >> 10) * 64;
-        const int wl = threadIdx.x & 63;
-        for (long long q = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); q < ns; q += (long long)gridDim.x * 4) {
+        constexpr int SL = 16;  // lanes per sampled row (a wavefront per row was 29 us of the stencil's k_b_info, this is 8)
+        const int wl = threadIdx.x & (SL - 1);
+        for (long long q = (long long)blockIdx.x * (256 / SL) + (threadIdx.x / SL); q < ns;
+             q += (long long)gridDim.x * (256 / SL)) {
             // (the answer is in: a web graph or a finite-element matrix raises the flag within the first rows, and the
             //  rest of the sample -- 25 us of a 0.65 ms call on the 1 M-row web graph -- is skipped)
             if (__hip_atomic_load(&bs->twin_sample, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
             const long long r64 = ((q >> 6) << 10) + (q & 63);
-            if (r64 >= ts.M) continue;
-            const int r = (int)r64;
-            const int b = ts.arpt[r], len = ts.arpt[r + 1] - b;
-            if (len < 1 || len > 4096) continue;
+            int b = 0, len = 0;
+            if (r64 < ts.M) {
+                b = ts.arpt[r64];
+                len = ts.arpt[r64 + 1] - b;
+            }
+            if (len > 4096) len = 0;  // (not sampled)
             unsigned long long key = 0;
-            for (int k = wl; k < len; k += 64) key += col_key(ts.acol[b + k]);
+            for (int k = wl; k < len; k += SL) key += col_key(ts.acol[b + k]);
 #pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) key += __shfl_xor(key, o);
+            for (int o = SL / 2; o >= 1; o >>= 1) key += __shfl_xor(key, o);
+            if (len < 1) continue;
             if (wl == 0) {
                 key += 0x9E3779B97F4A7C15ull * (unsigned long long)len;
                 const unsigned long long mine = (key & ~0xFFFFull) | ts.tag;
