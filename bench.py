@@ -240,6 +240,11 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(relaunch_under_torchrun(args))
+    # stdout carries ONE line, the JSON record: whatever libraries print there on the way (RCCL's version banner at
+    # communicator creation, the loader's "Read mtx file" lines) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -780,7 +785,8 @@ def main():
             "spmv_hbm": spmv_hbm,
         }
         C.CDLL(None).fflush(None)  # the library's own stdio lines ("Read mtx file: ...") go out first
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
