@@ -396,9 +396,9 @@ __global__ __launch_bounds__(256) void k_row_products(const int *__restrict__ ar
     // finite-element mesh, wherever the numbering put them).
     const int nrows = todo ? (*long_cnt < kLongCap ? *long_cnt : kLongCap) : M;
     // big matrices: the pattern map is used only when the sample of k_b_info saw a pattern twice (TwinSample)
-    const bool probe = tw.table != nullptr &&
-                       (tw.sample_flag == nullptr ||
-                        __hip_atomic_load(tw.sample_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+    // (written by the kernel before this one: a plain, scalar load -- it travels with the kernel arguments instead of
+    //  being one more vector round trip in front of every workgroup's two batches of rows)
+    const bool probe = tw.table != nullptr && (tw.sample_flag == nullptr || *tw.sample_flag != 0);
     if (!todo && blockIdx.x == 0 && threadIdx.x == 0) {  // scan tails (instead of two memset launches)
         bm_words[M] = 0;
         row_nz[M] = 0;
