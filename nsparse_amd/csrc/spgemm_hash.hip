@@ -73,6 +73,7 @@
 #include "spgemm/heavy_tiled.h"
 #include "spgemm/heavy_ranked.h"
 #include "spgemm/listed.h"
+#include "spgemm/lean.h"
 
 namespace nsp {
 namespace spgemm {
@@ -121,6 +122,9 @@ static const int g_coop = getenv("NSPARSE_COOP") ? atoi(getenv("NSPARSE_COOP")) 
 // 86.5 / 86.3 / 72.8 ms for 0 / 1 / 2 -- its rows are all hubs, so their AVERAGE B row is long as well --
 // webbase-1M class 2.71 / 2.46 / 2.42.
 static const int g_flat = getenv("NSPARSE_FLAT") ? atoi(getenv("NSPARSE_FLAT")) : 2;
+// round 4: the hash bins 1..4 of both phases run the lean kernels (lean.h); NSPARSE_TB_LEAN=0: round 3's k_sym_tb / k_num_tb,
+// bit 0: symbolic, bit 1: numeric
+static const int g_tb_lean = getenv("NSPARSE_TB_LEAN") ? atoi(getenv("NSPARSE_TB_LEAN")) : 0;  // (off until the fixed 24-bit hash has been measured)
 
 // Column lists (common.h: list_wanted): a heavy row goes to the listed kernel while slices x products stays within
 // this (NSPARSE_LIST_WORK); beyond it the cursor kernels, which see every product once, are cheaper.
@@ -407,7 +411,11 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        if (g_coop == 1) NSP_SYM_TB_GO(BS, TMAX, 1);                                           \
+        if ((g_tb_lean & 1) && g_coop == 0)                                                    \
+            hipLaunchKernelGGL((k_sym_lean<BS, TMAX, (BS >= 256 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
+                               arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], hist[bin_], b->nnz, d_bs, \
+                               TMAX >= 8192 ? tcol : (int *)nullptr, list_off, row_span, 12, 12288);  \
+        else if (g_coop == 1) NSP_SYM_TB_GO(BS, TMAX, 1);                                      \
         else if (g_coop == 2) NSP_SYM_TB_GO(BS, TMAX, 2);                                      \
         else NSP_SYM_TB_GO(BS, TMAX, 0);                                                       \
         NSP_LAUNCH_CHECK();                                                                    \
@@ -687,7 +695,11 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        if (g_coop == 1) NSP_NUM_TB_GO(BS, TMAX, PMAX, 1);                                     \
+        if ((g_tb_lean & 2) && g_coop == 0 && !tb_prof)                                        \
+            hipLaunchKernelGGL((k_num_lean<BS, TMAX, (BS >= 256 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
+                               arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_prod, row_maxb, \
+                               off[bin_], hist[bin_], b->nnz, write_col);                      \
+        else if (g_coop == 1) NSP_NUM_TB_GO(BS, TMAX, PMAX, 1);                                \
         else if (g_coop == 2) NSP_NUM_TB_GO(BS, TMAX, PMAX, 2);                                \
         else NSP_NUM_TB_GO(BS, TMAX, PMAX, 0);                                                 \
         NSP_LAUNCH_CHECK();                                                                    \
