@@ -43,8 +43,26 @@ the bin's own stream):
                     the 34.5 TB/s aggregate L2 ceiling: what the cache hierarchy serves
   lds_atomic        products / (measured ds_add_f64 rate): tools/lds_atomic/, profiles/r02_lds_atomic.json
 
-Launch: python bench.py [--gpus N --steps K --warmup W]; N > 1 without WORLD_SIZE in the
-environment re-launches itself through python -m torch.distributed.run (one rank per GPU).
+configs  (N = 1) BASELINE configs 3 and 5 and the 27-point stencil through the same protocol, each in its own
+         torch-free process (tools/bench_config.py): webbase-1M class in fp32 (libnsparse_s.so), R-MAT scale 22 with
+         7,340,032 edges, stencil 100^3 -- ms, GFLOPS, nnz(C) and C.rpt checked against rocSPARSE, whole-call
+         compulsory HBM fraction, dominant kernel, PMC traffic of the call.
+
+No torch anywhere in the measuring processes (round 4): the library binds to the system ROCm runtime
+(/opt/rocm/lib/libamdhip64.so.7, librccl.so.1) -- with torch imported first it bound to torch's bundled HIP 7.0 /
+RCCL 2.26, which is not the runtime the GPU tests validate and doubled the allocate-inside-the-call timing.
+Ranks: one process per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_PORT from the environment (the driver's
+`python -m torch.distributed.run ... bench.py` sets them; only ITS agent process imports torch).  The ncclUniqueId
+travels through nsparse_amd/rendezvous.py (a directory + a localhost socket), the barriers and max / sum
+reductions around the timed loops are nsparse_dist_barrier / nsparse_dist_allreduce_f64 of the native library
+(RCCL on the rank's stream).  Every wait has a deadline: more ranks than GPUs, or a rank that never starts, is an
+error message and a non-zero exit code, not a hang.
+
+Launch: python bench.py [--gpus N --steps K --warmup W]; N > 1 without WORLD_SIZE in the environment spawns its N
+ranks itself as plain subprocesses.  NSPARSE_BENCH_EMULATE=1 (tests, never a measurement): the ranks share the
+GPUs that exist, no communicator; barriers / reductions through the rendezvous socket, the all-gather replaced by
+the library's own staging + gap-closing copy (nsparse_dist_close_gaps) -- the whole multi-rank control flow on a
+one-GPU box.
 """
 import argparse
 import ctypes as C
@@ -215,14 +233,126 @@ def find_kernel(traffic, patterns):
     return None, None
 
 
-def relaunch_under_torchrun(args):
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    log(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks: {' '.join(cmd[1:9])} ...")
-    return subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1"))
+def runtime_report():
+    """Which HIP / RCCL / rocSPARSE shared objects this process has mapped (from /proc/self/maps): the evidence that
+    the library ran on the system ROCm runtime and not on a copy some Python package brought along."""
+    libs = {}
+    try:
+        for ln in open("/proc/self/maps"):
+            path = ln.split()[-1] if "/" in ln else ""
+            base = os.path.basename(path)
+            for key in ("libamdhip64", "librccl", "librocsparse", "libnsparse_", "libtorch", "libc10"):
+                if base.startswith(key):
+                    libs[base] = path
+    except OSError:
+        pass
+    return {"mapped": libs, "torch_imported": "torch" in sys.modules,
+            "system_rocm_runtime": all(v.startswith("/opt/rocm") for k, v in libs.items()
+                                       if k.startswith(("libamdhip64", "librccl", "librocsparse")))}
+
+
+def run_config(case, pmc, deadline):
+    """One BASELINE config in its own process (tools/bench_config.py); with `pmc`, two more runs of it under
+    rocprofv3 (FETCH_SIZE, WRITE_SIZE: separate passes) for the HBM traffic of one whole call."""
+    script = os.path.join(ROOT, "tools", "bench_config.py")
+    left = deadline - time.time()
+    if left < 20:
+        return {"case": case, "skipped": "configs time budget spent"}
+    try:
+        r = subprocess.run([sys.executable, script, case], capture_output=True, text=True, cwd=ROOT,
+                           timeout=min(left, 100.0))
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if not lines:
+            return {"case": case, "error": f"rc {r.returncode}: {r.stderr[-300:]}"}
+        rec = json.loads(lines[-1])
+    except subprocess.TimeoutExpired as e:
+        lines = [ln for ln in (e.stdout or b"").decode(errors="replace").splitlines() if ln.startswith("{")]
+        if not lines:
+            return {"case": case, "error": "timed out before the first record"}
+        rec = json.loads(lines[-1])
+        rec["structure_check"] = {"against": "rocSPARSE csrgemm", "error": "timed out"}
+    if not pmc:
+        return rec
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    tot = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        left = deadline - time.time()
+        if left < 25 or not os.path.exists(exe):
+            rec["traffic"] = None
+            rec["traffic_note"] = "PMC pass skipped: " + ("time budget" if left < 25 else "no rocprofv3")
+            return rec
+        td = tempfile.mkdtemp(prefix="nsp_pmc_", dir="/tmp")
+        try:
+            rr = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "p", "--",
+                                 sys.executable, script, case, "--pmc-child"], cwd="/tmp",
+                                env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=min(left, 90.0))
+            if rr.returncode != 0:
+                raise RuntimeError(f"rc {rr.returncode}: {rr.stderr[-200:]}")
+            import csv
+            per = {}
+            for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row.get("Counter_Name") == counter:
+                        per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            # two calls were made; the second half of every kernel's launches belongs to the second (warm) call
+            tot[counter] = {k: float(np.sum(v[len(v) // 2:])) for k, v in per.items()}
+        except Exception as e:
+            rec["traffic"] = None
+            rec["traffic_note"] = f"{counter} pass: {e!r}"[:200]
+            return rec
+        finally:
+            shutil.rmtree(td, ignore_errors=True)
+    kern = {k: tot["FETCH_SIZE"].get(k, 0.0) * FETCH_UNIT + tot["WRITE_SIZE"].get(k, 0.0) * WRITE_UNIT
+            for k in set(tot["FETCH_SIZE"]) | set(tot["WRITE_SIZE"])}
+    call = float(sum(kern.values()))
+    top = sorted(kern.items(), key=lambda kv: -kv[1])[:3]
+
+    def short(k):
+        return k.split("(")[0].replace("void ", "").replace("nsp::spgemm::", "")[:80]
+    rec["traffic"] = int(call)
+    rec["traffic_how"] = ("HBM bytes of ONE whole call: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), summed over "
+                          "the kernels of the second of two calls, x 2048 / x 1024 B per unit (profiles/r01_pmc_calibration.txt)")
+    rec["traffic_over_compulsory"] = round(call / max(rec["roofline"]["compulsory_bytes"], 1), 2)
+    rec["traffic_top_kernels"] = [{"kernel": short(k), "hbm_bytes": int(v)} for k, v in top]
+    rec["roofline"]["measured_achieved"] = round(call / (rec["ms"] * 1e-3) / 1e9, 1)
+    rec["roofline"]["measured_frac"] = round(call / (rec["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+    return rec
+
+
+def spawn_ranks(args):
+    """--gpus N without WORLD_SIZE: N plain subprocesses of this script, one per GPU (no torch, no torchrun).  The
+    first rank that fails takes the others down; the whole run has a deadline."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    rdv = tempfile.mkdtemp(prefix="nsparse_rdv_", dir="/tmp")
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), NSPARSE_RDV=rdv)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    log(f"[bench] --gpus {args.gpus} without WORLD_SIZE: spawned {args.gpus} rank processes (rendezvous {rdv})")
+    deadline = time.time() + float(os.environ.get("NSPARSE_BENCH_DEADLINE_S", "1500"))
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p for p in procs if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            rc = bad[0].returncode if bad else 124
+            log(f"[bench] {'a rank exited with ' + str(rc) if bad else 'deadline passed'}: stopping the other ranks")
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    shutil.rmtree(rdv, ignore_errors=True)
+    return rc
 
 
 def main():
@@ -236,10 +366,12 @@ def main():
     ap.add_argument("--no-vendor", action="store_true", help="skip the rocSPARSE baseline")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-irregular", action="store_true", help="skip the regular brick and the structure sweep")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 3 / 5 and the stencil (the `configs` block)")
+    ap.add_argument("--configs-budget", type=float, default=130.0, help="seconds the `configs` block may take")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(relaunch_under_torchrun(args))
+        sys.exit(spawn_ranks(args))
     # stdout carries ONE line, the JSON record: whatever libraries print there on the way (RCCL's version banner at
     # communicator creation, the loader's "Read mtx file" lines) is sent to stderr
     sys.stdout.flush()
@@ -251,46 +383,73 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
-    import torch
-    import torch.distributed as dist
-    # NSPARSE_BENCH_BACKEND=gloo: smoke-test the multi-rank path on a box with fewer GPUs than
-    # ranks (ranks share devices; RCCL refuses that).  Never used for reported numbers.
-    backend = os.environ.get("NSPARSE_BENCH_BACKEND", "nccl")
-    ndev = torch.cuda.device_count()
-    dev_index = local_rank if backend == "nccl" else local_rank % max(ndev, 1)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    import nsparse_amd as ns
+    from nsparse_amd.dist import csr_row_block, row_partition, row_partition_nnz
+    from nsparse_amd.rendezvous import Rendezvous
+    assert "torch" not in sys.modules, "the measuring process must not import torch (it brings its own HIP / RCCL)"
+    lib = ns.load("d")
+    dl = ns.load_dist("d")
+    w = 8
+    # NSPARSE_BENCH_EMULATE=1: the multi-rank control flow on fewer GPUs than ranks (tests; never a measurement)
+    emulate = os.environ.get("NSPARSE_BENCH_EMULATE") == "1"
+    ndev = int(dl.nsparse_dist_device_count())
+    if ndev < 1:
+        log(f"[rank {rank}] no GPU visible to this process")
+        sys.exit(3)
+    if world > ndev and not emulate:
+        log(f"[rank {rank}] --gpus {world} but this box has {ndev} GPU(s): one rank per GPU is the only measured "
+            "configuration (RCCL refuses two ranks on one device).  NSPARSE_BENCH_EMULATE=1 runs the control flow "
+            "of the multi-rank path on the GPUs that exist, as a test, without a communicator.")
+        sys.exit(3)
+    lib.hip.hipSetDevice.argtypes = [C.c_int]
+    assert lib.hip.hipSetDevice(local_rank % ndev) == 0
+    lib.nsparse_set_bin_timing(0)
+    dl.nsparse_dist_set_timeout(float(os.environ.get("NSPARSE_DIST_TIMEOUT_S", "90")))
 
-    red_dev = dev if backend == "nccl" else torch.device("cpu")
+    # ---- ranks: rendezvous (host), then ONE communicator for the whole run -------------------------------------
+    rdv = Rendezvous(rank, world, timeout=float(os.environ.get("NSPARSE_RDV_TIMEOUT_S", "120")))
+    h = C.c_void_p()
+    if world > 1 and not emulate:
+        idb = C.create_string_buffer(ns.DIST_ID_BYTES)
+        if rank == 0:
+            assert dl.nsparse_dist_unique_id(idb) == 0, "ncclGetUniqueId failed"
+        idb = C.create_string_buffer(rdv.bcast(idb.raw if rank == 0 else None, "ncclUniqueId"), ns.DIST_ID_BYTES)
+        rc = dl.nsparse_dist_init(C.byref(h), idb, rank, world)
+        if not rdv.all_ok(rc == 0, "communicator"):
+            log(f"[rank {rank}] RCCL communicator not created on every rank (this rank: {rc}); no measurement")
+            sys.exit(4)
+    else:
+        rc = dl.nsparse_dist_init(C.byref(h), None, rank, world)
+        assert rc == 0, f"nsparse_dist_init -> {rc}"
+    native_coll = world > 1 and not emulate
+
+    def check(rc, what):
+        if rc != 0:
+            log(f"[rank {rank}] {what} -> {rc} (nsparse_dist_last_error {dl.nsparse_dist_last_error()})")
+            sys.exit(5)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        if native_coll:
+            check(dl.nsparse_dist_barrier(h), "nsparse_dist_barrier")
+        elif world > 1:
+            lib.hip.hipDeviceSynchronize()
+            rdv.barrier()
+        lib.hip.hipDeviceSynchronize()
+
+    def reduce_ranks(x, op):
+        if world == 1:
+            return float(x)
+        if not native_coll:
+            return rdv.allreduce([x], "sum" if op == 0 else "max")[0]
+        v = (C.c_double * 1)(float(x))
+        check(dl.nsparse_dist_allreduce_f64(h, v, 1, op), "nsparse_dist_allreduce_f64")
+        return float(v[0])
 
     def max_over_ranks(x):
-        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+        return reduce_ranks(x, 1)
 
     def sum_over_ranks(x):
-        t = torch.tensor([float(x)], dtype=torch.float64, device=red_dev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        return float(t.item())
-
-    import nsparse_amd as ns
-    from nsparse_amd.dist import csr_row_block, make_gpu_sharded_spmv, row_partition, row_partition_nnz
-    lib = ns.load("d")
-    lib.nsparse_set_bin_timing(0)
-    w = 8
+        return reduce_ranks(x, 0)
 
     # ------------------------------------------------------------------ workload ----
     nz = 257 * world
@@ -481,114 +640,90 @@ def main():
     # ------------------------------------------------------------------- SpMV ----
     # Row-sharded AMB SpMV through the NATIVE library (include/nsparse_dist.h, libnsparse_dist_d.so): partition,
     # conversion, the per-iteration sequence [memset] -> kernel -> ncclAllGather -> [gap closing] and the timed loop
-    # itself are C; torch.distributed only carries the RCCL id to the ranks and provides the barriers around the
-    # loop.  (NSPARSE_BENCH_BACKEND=gloo -- ranks sharing a GPU, which RCCL refuses -- keeps round 2's Python
-    # driver, nsparse_amd/dist.py, as the smoke-test path.)
-    dl = ns.load_dist("d") if backend == "nccl" else None
-
-    def native_handle():
-        idb = C.create_string_buffer(ns.DIST_ID_BYTES)
-        if rank == 0:
-            assert dl.nsparse_dist_unique_id(idb) == 0, "ncclGetUniqueId failed"
-        if world > 1:
-            t = torch.tensor(list(idb.raw), dtype=torch.uint8, device=red_dev)
-            dist.broadcast(t, 0)
-            idb = C.create_string_buffer(bytes(t.cpu().tolist()), ns.DIST_ID_BYTES)
-        h = C.c_void_p()
-        rc = dl.nsparse_dist_init(C.byref(h), idb, rank, world)
-        assert rc == 0, f"nsparse_dist_init -> {rc}"
-        return h
-
-    def native_loop(h, d_y, d_x, gather, steps):
-        assert dl.nsparse_dist_spmv_loop(h, d_y, d_x, gather, 2, None, None, None) == 0  # warm-up
+    # itself are C; so are the barriers and reductions around the loop (nsparse_dist_barrier / _allreduce_f64).  One
+    # communicator for the whole run: the handle drops its matrix between the two workloads.
+    def native_loop(d_y, d_x, gather, steps):
+        check(dl.nsparse_dist_spmv_loop(h, d_y, d_x, gather, 2, None, None, None), "warm-up SpMV loop")
         mw, me, us = C.c_double(), C.c_double(), C.c_double()
         barrier()
         t = time.perf_counter()
         rc = dl.nsparse_dist_spmv_loop(h, d_y, d_x, gather, steps, C.byref(mw), C.byref(me), C.byref(us))
         barrier()
-        assert rc == 0, f"nsparse_dist_spmv_loop -> {rc}"
+        check(rc, "nsparse_dist_spmv_loop")
         return max_over_ranks(time.perf_counter() - t) * 1e3 / steps, max_over_ranks(me.value), max_over_ranks(us.value)
 
-    def time_spmv(op, x, steps, gather):
-        for _ in range(2):
-            op(x, gather=gather)
-        barrier()
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        t = time.perf_counter()
-        e0.record()
-        for _ in range(steps):
-            op(x, gather=gather)
-        e1.record()
-        barrier()
-        return max_over_ranks(time.perf_counter() - t) * 1e3 / steps, e0.elapsed_time(e1) / steps
+    def emulated_gather(d_y, cuts, m_loc):
+        """NSPARSE_BENCH_EMULATE: what the all-gather + gap closing do to THIS rank's rows, with the library's own copy
+        kernel: the local rows go to this rank's share of a staging buffer (equal shares of the longest block) and
+        nsparse_dist_close_gaps puts them where they belong in a second y.  Returns the rows it landed."""
+        M = int(cuts[-1])
+        rpr = max(1, int(np.max(np.diff(cuts))))
+        staged = lib.dmalloc(world * rpr * w)
+        lib.hip.hipMemset(staged, 0, world * rpr * w)
+        d_y2 = lib.dmalloc((M + 64) * w)
+        lib.hip.hipMemset(d_y2, 0, (M + 64) * w)
+        d_cuts = lib.dmalloc(4 * (world + 1))
+        lib.h2d(d_cuts, np.ascontiguousarray(cuts, dtype=np.int32))
+        if m_loc > 0:
+            assert lib.hip.hipMemcpy(C.c_void_p(staged.value + rank * rpr * w), C.c_void_p(d_y.value + int(cuts[rank]) * w),
+                                     m_loc * w, 3) == 0  # device to device
+        check(dl.nsparse_dist_close_gaps(d_y2, staged, d_cuts, world, rpr, M, dl.nsparse_dist_stream(h)), "nsparse_dist_close_gaps")
+        check(dl.nsparse_dist_sync(h), "nsparse_dist_sync")
+        out = lib.d2h(C.c_void_p(d_y2.value + int(cuts[rank]) * w), (m_loc,), np.float64)
+        for p_ in (staged, d_y2, d_cuts):
+            lib.dfree(p_)
+        return out
 
     def spmv_report(A_rows, M_global, nnz_global, label, N_cols, blocks, traffic=None):
         xh = np.random.default_rng(1).random(N_cols + 20)
         cuts = np.array([blocks[0][0]] + [e for _, e in blocks], dtype=np.int32)
-        extra = {}
-        native = dl is not None
-        if native:
-            # communicator, conversion and one gathered SpMV; the ranks then AGREE that all of them got that far
-            # (at N > 1 this is the first time the RCCL path runs on real links): if any rank failed, every rank
-            # takes the Python driver for this leg and the line says so -- a launch-mode fallback, never a CPU one
-            err = ""
-            try:
-                h = native_handle()
-                csr = lib.csr_from_numpy(A_rows["rpt"], A_rows["col"], A_rows["val"], N_cols)
-                lib.csr_memcpy(C.byref(csr))
-                d_x = lib.dmalloc(xh.nbytes)
-                lib.h2d(d_x, xh)
-                plan = ns.sfPlan()
-                lib.init_plan(C.byref(plan))
-                rc = dl.nsparse_dist_spmv_setup(h, C.byref(csr), cuts.ctypes.data_as(ns.capi.c_int_p), d_x, C.byref(plan))
-                assert rc == 0, f"nsparse_dist_spmv_setup -> {rc}"
-                ny = int(dl.nsparse_dist_y_elems(h))
-                d_y = lib.dmalloc((ny + 64) * w)
-                lib.hip.hipMemset(d_y, 0, (ny + 64) * w)
-                assert dl.nsparse_dist_spmv(h, d_y, d_x, 1) == 0 and dl.nsparse_dist_sync(h) == 0, \
-                    f"first gathered SpMV -> {dl.nsparse_dist_last_error()}"
-            except Exception as e:
-                if world == 1:
-                    raise
-                err = repr(e)[:200]
-            if world > 1 and max_over_ranks(1.0 if err else 0.0) > 0:
-                log(f"[rank {rank}] native multi-GPU SpMV unavailable ({err or 'another rank failed'}): Python driver for this leg")
-                native = False
-                extra_note = {"native_driver_error": err or "another rank failed"}
-        if native:
-            amb = dl.nsparse_dist_amb(h).contents
-            fp = int(lib.nsparse_amb_footprint_bytes(C.byref(amb))) if A_rows["M"] > 0 else 0
-            ms_c, ms_c_ev, us_c = native_loop(h, d_y, d_x, 0, args.spmv_steps)
-            ms_g, ms_g_ev, us_g = native_loop(h, d_y, d_x, 1, args.spmv_steps) if world > 1 else (ms_c, ms_c_ev, us_c)
-            extra = {"driver": "native: libnsparse_dist_d.so (C loop, RCCL all-gather, no Python per iteration)",
-                     "host_us_per_spmv": round(us_g, 2), "ms_events_with_gather": round(ms_g_ev, 5)}
-            # the same sequence replayed from a hipGraph (one hipGraphLaunch per SpMV)
-            if world == 1 or os.environ.get("NSPARSE_DIST_GRAPH") == "1":
-                if dl.nsparse_dist_capture(h, d_y, d_x, 1 if world > 1 else 0) == 0:
-                    ms_gr, ms_gr_ev, us_gr = native_loop(h, d_y, d_x, 1 if world > 1 else 0, args.spmv_steps)
-                    extra["hipgraph"] = {"ms_per_spmv": round(ms_gr, 5), "ms_events": round(ms_gr_ev, 5),
-                                         "host_us_per_spmv": round(us_gr, 2)}
-                else:
-                    extra["hipgraph"] = {"error": int(dl.nsparse_dist_last_error())}
+        # communicator-wide agreement after the set-up and ONE gathered SpMV: at N > 1 this is the first time the
+        # RCCL path runs on real links -- a rank that failed must not leave the others in the collective
+        err = ""
+        csr = lib.csr_from_numpy(A_rows["rpt"], A_rows["col"], A_rows["val"], N_cols)
+        lib.csr_memcpy(C.byref(csr))
+        d_x = lib.dmalloc(xh.nbytes)
+        lib.h2d(d_x, xh)
+        plan = ns.sfPlan()
+        lib.init_plan(C.byref(plan))
+        rc = dl.nsparse_dist_spmv_setup(h, C.byref(csr), cuts.ctypes.data_as(ns.capi.c_int_p), d_x, C.byref(plan))
+        if rc != 0:
+            err = f"nsparse_dist_spmv_setup -> {rc}"
+        ny = int(dl.nsparse_dist_y_elems(h)) if not err else 1
+        d_y = lib.dmalloc((ny + 64) * w)
+        lib.hip.hipMemset(d_y, 0, (ny + 64) * w)
+        if world > 1 and not rdv.all_ok(not err, "SpMV set-up"):
+            log(f"[rank {rank}] SpMV set-up failed on some rank ({err or 'another rank'}); no measurement")
+            sys.exit(6)
+        assert not err, err
+        gather_flag = 1 if native_coll else 0
+        check(dl.nsparse_dist_spmv(h, d_y, d_x, gather_flag), "first SpMV")
+        check(dl.nsparse_dist_sync(h), "first SpMV (sync)")
+        amb = dl.nsparse_dist_amb(h).contents
+        fp = int(lib.nsparse_amb_footprint_bytes(C.byref(amb))) if A_rows["M"] > 0 else 0
+        ms_c, ms_c_ev, us_c = native_loop(d_y, d_x, 0, args.spmv_steps)
+        ms_g, ms_g_ev, us_g = native_loop(d_y, d_x, 1, args.spmv_steps) if native_coll else (ms_c, ms_c_ev, us_c)
+        extra = {"driver": "native: libnsparse_dist_d.so (C loop, RCCL all-gather, no Python per iteration)",
+                 "host_us_per_spmv": round(us_g, 2), "ms_events_with_gather": round(ms_g_ev, 5)}
+        # the same sequence replayed from a hipGraph (one hipGraphLaunch per SpMV)
+        if world == 1 or os.environ.get("NSPARSE_DIST_GRAPH") == "1":
+            if dl.nsparse_dist_capture(h, d_y, d_x, gather_flag) == 0:
+                ms_gr, ms_gr_ev, us_gr = native_loop(d_y, d_x, gather_flag, args.spmv_steps)
+                extra["hipgraph"] = {"ms_per_spmv": round(ms_gr, 5), "ms_events": round(ms_gr_ev, 5),
+                                     "host_us_per_spmv": round(us_gr, 2)}
+            else:
+                extra["hipgraph"] = {"error": int(dl.nsparse_dist_last_error())}
 
-            def local_rows():
-                assert dl.nsparse_dist_spmv(h, d_y, d_x, 0) == 0 and dl.nsparse_dist_sync(h) == 0
-                return lib.d2h(C.c_void_p(d_y.value + int(cuts[rank]) * w), (A_rows["M"],), np.float64)
-            plan_o, amb_o = plan, amb
-        else:
-            op = make_gpu_sharded_spmv(lib, A_rows, M_global, rank, world, dev, blocks=blocks)
-            x = torch.from_numpy(xh).to(dev)
-            fp = int(lib.nsparse_amb_footprint_bytes(C.byref(op.amb)))
-            ms_c, ms_c_ev = time_spmv(op, x, args.spmv_steps, gather=False)
-            ms_g = time_spmv(op, x, args.spmv_steps, gather=True)[0] if world > 1 else ms_c
-            extra = {"driver": "python (nsparse_amd/dist.py)" + ("" if dl is not None else ": smoke-test backend only"),
-                     **(extra_note if dl is not None else {})}
-            csr, d_x = op.csr, C.c_void_p(x.data_ptr())
-
-            def local_rows():
-                return op(x, gather=False)[:A_rows["M"]].cpu().numpy()
-            plan_o, amb_o = op.plan, op.amb
+        def local_rows():
+            check(dl.nsparse_dist_spmv(h, d_y, d_x, 0), "SpMV (check)")
+            check(dl.nsparse_dist_sync(h), "SpMV (check, sync)")
+            return lib.d2h(C.c_void_p(d_y.value + int(cuts[rank]) * w), (A_rows["M"],), np.float64)
+        plan_o, amb_o = plan, amb
+        if emulate and world > 1:
+            y_loc = local_rows()
+            landed = emulated_gather(d_y, cuts, A_rows["M"])
+            extra["emulated_gather"] = {"rows": int(A_rows["M"]), "landed_equal": bool(np.array_equal(landed, y_loc))}
+            assert extra["emulated_gather"]["landed_equal"], "staging + gap closing moved a row to the wrong place"
         # x is counted once over N instead of the reference's second M*w term
         b_amb = fp - A_rows["M"] * w + N_cols * w
         fp_all = sum_over_ranks(b_amb)
@@ -635,14 +770,10 @@ def main():
                                        "err": int(vl.nsparse_vendor_last_error())}
             except Exception as e:
                 rep["vendor_csrmv"] = {"error": repr(e)[:160]}
-        if native:
-            dl.nsparse_dist_destroy(h)  # releases the AMB arrays and the communicator
-            lib.release_csr(csr)
-            lib.dfree(d_x)
-            lib.dfree(d_y)
-        else:
-            lib.release_amb(op.amb)
-            lib.release_csr(op.csr)
+        check(dl.nsparse_dist_release_matrix(h), "nsparse_dist_release_matrix")  # the communicator stays
+        lib.release_csr(csr)
+        lib.dfree(d_x)
+        lib.dfree(d_y)
         return rep
 
     nnz_glob = int(A_full["rpt"][-1])
@@ -683,7 +814,7 @@ def main():
             assert np.array_equal(v_rpt, crpt), "rocSPARSE C.rpt differs from the library's"
             vl.nsparse_vendor_release_csr(cv)
             reps_v, dev_ms = 5, 0.0
-            torch.cuda.synchronize()
+            lib.hip.hipDeviceSynchronize()
             t = time.perf_counter()
             for _ in range(reps_v):
                 vl.nsparse_vendor_spgemm(C.byref(a), C.byref(b), C.byref(cv), C.byref(msd))
@@ -700,6 +831,18 @@ def main():
             raise
         except Exception as e:
             vendor = {"error": repr(e)[:200]}
+
+    # ------------------------------------------ BASELINE configs 3 and 5 + the stencil ----
+    configs = None
+    if rank == 0 and world == 1 and not args.no_configs:
+        t0 = time.time()
+        lib.nsparse_trim_workspace()  # the children want the memory this process has cached
+        deadline = t0 + args.configs_budget
+        configs = {"protocol": "spgemm_hash.cu:35-54: one warm-up call, then the mean of the timed whole calls; every "
+                               "config in its own torch-free process (tools/bench_config.py)",
+                   "cases": [run_config(cs, not args.no_pmc, deadline) for cs in ("webbase1m", "stencil", "rmat22")]}
+        configs["seconds"] = round(time.time() - t0, 1)
+        log(f"[configs] {configs['seconds']} s")
 
     # ----------------------------------------------------------- CPU baseline ----
     cpu = None
@@ -753,7 +896,9 @@ def main():
             "value": round(gflops, 2), "unit": "GFLOPS", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if "synthetic" in src else "file",
-            **({"backend_override": backend} if backend != "nccl" else {}),
+            **({"emulated_ranks": "NSPARSE_BENCH_EMULATE=1: ranks share the GPUs that exist, no communicator -- a "
+                                  "control-flow test, NOT a measurement"} if emulate and world > 1 else {}),
+            "runtime": runtime_report(),
             "config": {"workload": f"{src}: 3-dof 27-pt FEM brick 9x9x{nz}, {M_glob} rows, C=A^2 by 1-D row blocks of 62451 rows"
                                    if "synthetic" in src else src,
                        "rows_per_gpu": int(a.M), "nnz_A_per_gpu": nnz_a, "n_prod_per_gpu": n_prod,
@@ -777,6 +922,7 @@ def main():
                          "sym_bin_rows": list(st.sym_bin_size)[:11], "num_bin_rows": list(st.num_bin_size)[:11],
                          "note": "separate pass with per-bin events on"},
             "roofline": roofline,
+            "configs": configs,
             "regular_brick": regular,
             "structure_sweep": sweep,
             "cpu_baseline": cpu,
@@ -787,9 +933,9 @@ def main():
         C.CDLL(None).fflush(None)  # the library's own stdio lines ("Read mtx file: ...") go out first
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    barrier()
+    dl.nsparse_dist_destroy(h)
+    rdv.close()
 
 
 if __name__ == "__main__":

@@ -57,6 +57,20 @@ int nsparse_dist_init(nsparse_dist_t *h, const char id[NSPARSE_DIST_ID_BYTES], i
  * caller then drives handle r from its own thread with device r current.                       */
 int nsparse_dist_init_all(nsparse_dist_t *handles, int world);
 void nsparse_dist_destroy(nsparse_dist_t h);
+/* GPUs this process sees (hipGetDeviceCount; 0 on error): a launcher compares it with its rank count
+ * BEFORE any collective, so that "more ranks than GPUs" is a message and not a hang.              */
+int nsparse_dist_device_count(void);
+/* Watchdog (round 4).  No call of this library waits for a peer for ever: nsparse_dist_init gives
+ * ncclCommInitRank, and nsparse_dist_sync / _barrier / _allreduce_f64 / _spmv_loop give the handle's
+ * stream, this many seconds (default 60, NSPARSE_DIST_TIMEOUT_S); then the communicator is aborted
+ * and the call returns -7 (stream) or -8 (communicator creation).  Returns the previous value.   */
+double nsparse_dist_set_timeout(double seconds);
+/* All ranks: returns when every rank has reached the call and the handle's stream is idle (a
+ * one-int ncclAllReduce; world 1 or a handle without communicator: the stream only).             */
+int nsparse_dist_barrier(nsparse_dist_t h);
+/* vals[0, n) <- sum (op 0) or max (op 1) over the ranks; host memory in and out, n <= 64.  With
+ * _barrier this is all a launcher needs around a timed loop: no second communication library.    */
+int nsparse_dist_allreduce_f64(nsparse_dist_t h, double *vals, int n, int op);
 
 /* ---- SpMV ----------------------------------------------------------------------------------
  * a_local: this rank's row block, device arrays valid (csr_memcpy), M = cuts[rank+1] - cuts[rank]
@@ -64,6 +78,9 @@ void nsparse_dist_destroy(nsparse_dist_t h);
  * FALSE lets the library choose and writes the choice back).  cuts: the world+1 row cuts, equal
  * on every rank.  d_x_any: device vector of N + MAX_BLOCK_SIZE elements for the plan search.     */
 int nsparse_dist_spmv_setup(nsparse_dist_t h, sfCSR *a_local, const int *cuts, real *d_x_any, sfPlan *plan);
+/* Drop the handle's matrix (AMB arrays, staging, recorded graph); the communicator stays and the
+ * handle takes the next nsparse_dist_spmv_setup.                                                 */
+int nsparse_dist_release_matrix(nsparse_dist_t h);
 /* Elements the caller must allocate for the gathered y: world * (rows of the longest block),
  * at least M.  (The all-gather is in place with equal shares.)                                  */
 long long nsparse_dist_y_elems(nsparse_dist_t h);

@@ -130,6 +130,11 @@ DIST_SIGNATURES = {
     "nsparse_dist_plan": (_P(sfPlan), [C.c_void_p]),
     "nsparse_dist_stream": (C.c_void_p, [C.c_void_p]),
     "nsparse_dist_last_error": (C.c_int, []),
+    "nsparse_dist_device_count": (C.c_int, []),
+    "nsparse_dist_set_timeout": (C.c_double, [C.c_double]),
+    "nsparse_dist_barrier": (C.c_int, [C.c_void_p]),
+    "nsparse_dist_allreduce_f64": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.c_int]),
+    "nsparse_dist_release_matrix": (C.c_int, [C.c_void_p]),
 }
 DIST_ID_BYTES = 128
 

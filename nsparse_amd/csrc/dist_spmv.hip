@@ -13,11 +13,16 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "nsparse_dist.h"
@@ -50,6 +55,16 @@ inline int fail_nccl(ncclResult_t r, const char *what, int line)
     } while (0)
 
 constexpr ncclDataType_t kNcclReal = sizeof(real) == 8 ? ncclDouble : ncclFloat;
+
+// Watchdog (round 4): nothing that waits on a peer waits for ever.  A collective whose peer never arrives leaves a
+// kernel spinning on the stream; every wait below polls the stream and gives up after this many seconds
+// (NSPARSE_DIST_TIMEOUT_S, nsparse_dist_set_timeout), aborts the communicator and returns -7.
+double g_timeout_s = [] {
+    const char *e = getenv("NSPARSE_DIST_TIMEOUT_S");
+    const double v = e ? atof(e) : 0.0;
+    return v > 0.0 ? v : 60.0;
+}();
+constexpr int kReduceMax = 64;  // doubles per nsparse_dist_allreduce_f64 call
 
 // Unequal blocks are gathered with equal shares of `rpr` elements (share r holds rows of block r at its
 // start); this closes the gaps: y[cuts[r] + i] = staged[r * rpr + i].  One launch, 16 B per row moved.
@@ -86,6 +101,9 @@ struct nsparse_dist {
     real *g_y = nullptr;
     const real *g_x = nullptr;
     int g_gather = -1;
+    // barrier / small reductions among the ranks (device scratch: kReduceMax doubles + one int)
+    double *d_red = nullptr;
+    int *d_tick = nullptr;
 };
 
 namespace {
@@ -129,6 +147,54 @@ int partition(const T *prefix, int M, int world, int align, int *cuts)
     return 0;
 }
 
+// Wait for everything queued on the handle's stream, but not for ever: a poll of the stream (a few microseconds per
+// query, so the timed loops lose nothing against hipStreamSynchronize) that also looks at the communicator's
+// asynchronous error state.  On a time-out the communicator is aborted -- which ends the collective kernel that is
+// waiting for its peer -- and the handle keeps working for local rows only.
+int sync_watch(nsparse_dist *h)
+{
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    long polls = 0;
+    bool slow = false;  // past 5 ms: one poll per 100 us instead of spinning
+    for (;;) {
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q == hipSuccess) return 0;
+        if (q != hipErrorNotReady) return fail_hip(q, "hipStreamQuery", __LINE__);
+        if (slow) std::this_thread::sleep_for(std::chrono::microseconds(100));
+        if (!slow && (++polls & 63) != 0) continue;
+        const double el = std::chrono::duration<double>(clk::now() - t0).count();
+        slow = el > 0.005;
+        if (h->comm && slow) {
+            ncclResult_t ar = ncclSuccess;
+            if (ncclCommGetAsyncError(h->comm, &ar) == ncclSuccess && ar != ncclSuccess && ar != ncclInProgress) {
+                (void)ncclCommAbort(h->comm);
+                h->comm = nullptr;
+                return fail_nccl(ar, "asynchronous communicator error", __LINE__);
+            }
+        }
+        if (el > g_timeout_s) {
+            fprintf(stderr, "nsparse_dist: rank %d of %d waited %.0f s for its stream (a peer that never joined the "
+                            "collective?): aborting the communicator\n", h->rank, h->world, el);
+            if (h->comm) {
+                (void)ncclCommAbort(h->comm);
+                h->comm = nullptr;
+            }
+            return g_err = -7;
+        }
+    }
+}
+
+void free_handle(nsparse_dist *h)
+{
+    if (h->ev[0]) (void)hipEventDestroy(h->ev[0]);
+    if (h->ev[1]) (void)hipEventDestroy(h->ev[1]);
+    if (h->d_red) (void)hipFree(h->d_red);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+// (takes the communicator over: on a failure it is destroyed with the half-built handle)
 int new_handle(nsparse_dist **out, ncclComm_t comm, int rank, int world, int device)
 {
     nsparse_dist *h = new nsparse_dist();
@@ -138,9 +204,17 @@ int new_handle(nsparse_dist **out, ncclComm_t comm, int rank, int world, int dev
     h->comm = comm;
     memset(&h->amb, 0, sizeof(h->amb));
     memset(&h->plan, 0, sizeof(h->plan));
-    D_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    D_HIP(hipEventCreate(&h->ev[0]));
-    D_HIP(hipEventCreate(&h->ev[1]));
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev[0]);
+    if (e == hipSuccess) e = hipEventCreate(&h->ev[1]);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_red, sizeof(double) * kReduceMax + sizeof(int) * 2);
+    if (e == hipSuccess) e = hipMemset(h->d_red, 0, sizeof(double) * kReduceMax + sizeof(int) * 2);
+    if (e != hipSuccess) {
+        if (comm) (void)ncclCommDestroy(comm);
+        free_handle(h);
+        return fail_hip(e, "new_handle", __LINE__);
+    }
+    h->d_tick = reinterpret_cast<int *>(h->d_red + kReduceMax);
     *out = h;
     return 0;
 }
@@ -207,9 +281,36 @@ int nsparse_dist_init(nsparse_dist_t *h, const char id[NSPARSE_DIST_ID_BYTES], i
     D_HIP(hipGetDevice(&device));
     ncclComm_t comm = nullptr;
     if (id) {
+        // ncclCommInitRank returns when ALL ranks have called it: a rank that never starts (fewer GPUs than ranks,
+        // a crashed peer) would hold the others for ever, so the call runs on a helper thread and is given
+        // g_timeout_s; a thread that does not come back is left behind (the process is about to report an error)
+        struct Job {
+            std::mutex m;
+            std::condition_variable cv;
+            bool done = false;
+            ncclResult_t res = ncclSuccess;
+            ncclComm_t comm = nullptr;
+        };
+        auto job = std::make_shared<Job>();
         ncclUniqueId u;
         memcpy(&u, id, sizeof(u));
-        D_NCCL(ncclCommInitRank(&comm, world, u, rank));
+        std::thread([job, u, rank, world, device]() {
+            ncclComm_t c = nullptr;
+            ncclResult_t r = hipSetDevice(device) == hipSuccess ? ncclCommInitRank(&c, world, u, rank) : ncclUnhandledCudaError;
+            std::lock_guard<std::mutex> lk(job->m);
+            job->res = r;
+            job->comm = c;
+            job->done = true;
+            job->cv.notify_all();
+        }).detach();
+        std::unique_lock<std::mutex> lk(job->m);
+        if (!job->cv.wait_for(lk, std::chrono::duration<double>(g_timeout_s), [&] { return job->done; })) {
+            fprintf(stderr, "nsparse_dist: rank %d of %d: ncclCommInitRank did not return within %.0f s (a rank that never "
+                            "started?)\n", rank, world, g_timeout_s);
+            return g_err = -8;
+        }
+        if (job->res != ncclSuccess) return fail_nccl(job->res, "ncclCommInitRank", __LINE__);
+        comm = job->comm;
     }
     return new_handle(h, comm, rank, world, device);
 }
@@ -222,66 +323,112 @@ int nsparse_dist_init_all(nsparse_dist_t *handles, int world)
     if (world > 1) D_NCCL(ncclCommInitAll(comms.data(), world, nullptr));  // devices 0 .. world-1
     int before = 0;
     D_HIP(hipGetDevice(&before));
-    for (int r = 0; r < world; r++) {
-        D_HIP(hipSetDevice(r));
-        const int rc = new_handle(&handles[r], comms[r], r, world, r);
-        if (rc) return rc;
+    int rc = 0;
+    for (int r = 0; r < world; r++) handles[r] = nullptr;
+    for (int r = 0; r < world && rc == 0; r++) {
+        const hipError_t e = hipSetDevice(r);
+        rc = e != hipSuccess ? fail_hip(e, "hipSetDevice", __LINE__) : new_handle(&handles[r], comms[r], r, world, r);
+        if (rc == 0) comms[r] = nullptr;  // owned by the handle now (new_handle destroys it when it fails)
+        else if (e != hipSuccess && comms[r]) (void)ncclCommDestroy(comms[r]), comms[r] = nullptr;
     }
-    D_HIP(hipSetDevice(before));
-    return 0;
+    if (rc) {  // nothing half-built survives: handles made so far, communicators not yet handed over
+        for (int r = 0; r < world; r++) {
+            if (handles[r]) nsparse_dist_destroy(handles[r]), handles[r] = nullptr;
+            else if (comms[r]) (void)ncclCommDestroy(comms[r]);
+        }
+    }
+    (void)hipSetDevice(before);
+    return rc;
 }
 
 void nsparse_dist_destroy(nsparse_dist_t h)
 {
     if (!h) return;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream) (void)sync_watch(h);
+    (void)nsparse_dist_release_matrix(h);
+    if (h->comm) (void)ncclCommDestroy(h->comm);
+    free_handle(h);
+}
+
+int nsparse_dist_release_matrix(nsparse_dist_t h)
+{
+    if (!h) return -1;
+    if (h->stream) (void)sync_watch(h);
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->graph) (void)hipGraphDestroy(h->graph);
+    h->gexec = nullptr;
+    h->graph = nullptr;
+    h->g_y = nullptr;
+    h->g_x = nullptr;
+    h->g_gather = -1;
     if (h->have_amb) release_amb(h->amb);
+    h->have_amb = false;
+    memset(&h->amb, 0, sizeof(h->amb));
     if (h->staged) (void)hipFree(h->staged);
     if (h->d_cuts) (void)hipFree(h->d_cuts);
-    if (h->comm) (void)ncclCommDestroy(h->comm);
-    if (h->ev[0]) (void)hipEventDestroy(h->ev[0]);
-    if (h->ev[1]) (void)hipEventDestroy(h->ev[1]);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
-    delete h;
+    h->staged = nullptr;
+    h->d_cuts = nullptr;
+    h->cuts.clear();
+    h->M = h->rpr = h->m_local = 0;
+    return 0;
 }
 
 int nsparse_dist_spmv_setup(nsparse_dist_t h, sfCSR *a_local, const int *cuts, real *d_x_any, sfPlan *plan)
 {
     g_err = 0;
     if (!h || !a_local || !cuts || !plan) return g_err = -1;
-    if (h->have_amb) return g_err = -3;  // one matrix per handle
-    h->cuts.assign(cuts, cuts + h->world + 1);
-    h->M = h->cuts[h->world];
-    if (h->cuts[0] != 0) return g_err = -1;
+    if (h->have_amb || !h->cuts.empty()) return g_err = -3;  // one matrix at a time (nsparse_dist_release_matrix)
+    // every argument is checked before the handle changes: a refused call leaves it as it was
+    if (cuts[0] != 0) return g_err = -1;
     int rpr = 1;
     for (int r = 0; r < h->world; r++) {
-        const int len = h->cuts[r + 1] - h->cuts[r];
+        const int len = cuts[r + 1] - cuts[r];
         if (len < 0) return g_err = -1;
         rpr = len > rpr ? len : rpr;
     }
-    h->rpr = rpr;
-    h->m_local = h->cuts[h->rank + 1] - h->cuts[h->rank];
-    if (a_local->M != h->m_local) return g_err = -2;
-    h->equal_blocks = true;
+    const int m_local = cuts[h->rank + 1] - cuts[h->rank];
+    if (a_local->M != m_local) return g_err = -2;
+    bool equal_blocks = true;
     for (int r = 0; r < h->world; r++)
-        if (h->cuts[r + 1] > h->cuts[r] && (long long)h->cuts[r] != (long long)r * rpr) h->equal_blocks = false;
-    if (h->m_local > 0) {
-        sf_csr2amb(&h->amb, a_local, d_x_any, plan);  // synchronous; takes the product library's API lock
-        if (nsparse_last_error() != 0) return g_err = nsparse_last_error();
+        if (cuts[r + 1] > cuts[r] && (long long)cuts[r] != (long long)r * rpr) equal_blocks = false;
+    real *staged = nullptr;
+    int *d_cuts = nullptr;
+    if (h->world > 1 && !equal_blocks) {
+        hipError_t e = hipMalloc((void **)&staged, sizeof(real) * (size_t)h->world * (size_t)rpr);
+        if (e == hipSuccess) e = hipMemset(staged, 0, sizeof(real) * (size_t)h->world * (size_t)rpr);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_cuts, sizeof(int) * ((size_t)h->world + 1));
+        if (e == hipSuccess) e = hipMemcpy(d_cuts, cuts, sizeof(int) * ((size_t)h->world + 1), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            if (staged) (void)hipFree(staged);
+            if (d_cuts) (void)hipFree(d_cuts);
+            return fail_hip(e, "gather staging", __LINE__);
+        }
+    }
+    if (m_local > 0) {
+        // synchronous; takes the product library's API lock.  Its error word is per THREAD-OF-CALL state of that
+        // library: compare before / after instead of reading a value another rank's thread may have left there
+        const int before = nsparse_last_error();
+        sf_csr2amb(&h->amb, a_local, d_x_any, plan);
+        const int after = nsparse_last_error();
+        if (after != 0 && after != before) {
+            if (staged) (void)hipFree(staged);
+            if (d_cuts) (void)hipFree(d_cuts);
+            memset(&h->amb, 0, sizeof(h->amb));
+            return g_err = after;
+        }
         h->have_amb = true;
     } else if (plan->isPlan == FALSE) {
         init_plan(plan);
     }
+    h->cuts.assign(cuts, cuts + h->world + 1);
+    h->M = cuts[h->world];
+    h->rpr = rpr;
+    h->m_local = m_local;
+    h->equal_blocks = equal_blocks;
+    h->staged = staged;
+    h->d_cuts = d_cuts;
     h->plan = *plan;
-    if (h->world > 1 && !h->equal_blocks) {
-        D_HIP(hipMalloc((void **)&h->staged, sizeof(real) * (size_t)h->world * (size_t)rpr));
-        D_HIP(hipMemset(h->staged, 0, sizeof(real) * (size_t)h->world * (size_t)rpr));
-        D_HIP(hipMalloc((void **)&h->d_cuts, sizeof(int) * ((size_t)h->world + 1)));
-        D_HIP(hipMemcpy(h->d_cuts, h->cuts.data(), sizeof(int) * ((size_t)h->world + 1), hipMemcpyHostToDevice));
-    }
     return 0;
 }
 
@@ -321,7 +468,8 @@ int nsparse_dist_capture(nsparse_dist_t h, real *d_y, const real *d_x, int gathe
     // warm: first-use allocations of RCCL (channels, proxies) must not fall inside the capture
     int rc = enqueue(h, d_y, d_x, gather);
     if (rc) return rc;
-    D_HIP(hipStreamSynchronize(h->stream));
+    rc = sync_watch(h);
+    if (rc) return rc;
     D_HIP(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
     rc = enqueue(h, d_y, d_x, gather);
     hipGraph_t g = nullptr;
@@ -345,10 +493,40 @@ int nsparse_dist_capture(nsparse_dist_t h, real *d_y, const real *d_x, int gathe
     return 0;
 }
 
-int nsparse_dist_sync(nsparse_dist_t h)
+int nsparse_dist_sync(nsparse_dist_t h) { return sync_watch(h); }
+
+double nsparse_dist_set_timeout(double seconds)
 {
-    D_HIP(hipStreamSynchronize(h->stream));
-    return 0;
+    const double old = g_timeout_s;
+    if (seconds > 0.0) g_timeout_s = seconds;
+    return old;
+}
+
+int nsparse_dist_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+// All ranks: returns when every rank has reached the call and the handle's stream is idle.  A one-int ncclAllReduce on
+// the handle's stream (world 1, or a handle without a communicator: the stream only).  -7 after the time-out.
+int nsparse_dist_barrier(nsparse_dist_t h)
+{
+    if (!h) return g_err = -1;
+    if (h->comm && h->world > 1) D_NCCL(ncclAllReduce(h->d_tick, h->d_tick + 1, 1, ncclInt, ncclSum, h->comm, h->stream));
+    return sync_watch(h);
+}
+
+// vals[0 .. n) <- sum (op 0) or max (op 1) over the ranks, host memory in and out, n <= 64.  What a launcher needs
+// around a timed loop (the slowest rank's time, the total work) without a second communication library.
+int nsparse_dist_allreduce_f64(nsparse_dist_t h, double *vals, int n, int op)
+{
+    if (!h || !vals || n < 0 || n > kReduceMax || (op != 0 && op != 1)) return g_err = -1;
+    if (!h->comm || h->world == 1 || n == 0) return h->world == 1 || n == 0 ? 0 : (g_err = -4);
+    D_HIP(hipMemcpyAsync(h->d_red, vals, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    D_NCCL(ncclAllReduce(h->d_red, h->d_red, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, h->comm, h->stream));
+    D_HIP(hipMemcpyAsync(vals, h->d_red, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    return sync_watch(h);
 }
 
 int nsparse_dist_spmv_loop(nsparse_dist_t h, real *d_y, const real *d_x, int gather, int iters,
@@ -356,7 +534,10 @@ int nsparse_dist_spmv_loop(nsparse_dist_t h, real *d_y, const real *d_x, int gat
 {
     using clk = std::chrono::steady_clock;
     if (iters < 1) return g_err = -1;
-    D_HIP(hipStreamSynchronize(h->stream));
+    {
+        const int rc = sync_watch(h);
+        if (rc) return rc;
+    }
     const auto t0 = clk::now();
     D_HIP(hipEventRecord(h->ev[0], h->stream));
     for (int i = 0; i < iters; i++) {
@@ -365,7 +546,10 @@ int nsparse_dist_spmv_loop(nsparse_dist_t h, real *d_y, const real *d_x, int gat
     }
     D_HIP(hipEventRecord(h->ev[1], h->stream));
     const auto t1 = clk::now();
-    D_HIP(hipStreamSynchronize(h->stream));
+    {
+        const int rc = sync_watch(h);
+        if (rc) return rc;
+    }
     const auto t2 = clk::now();
     float ms = 0;
     D_HIP(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));

@@ -6,8 +6,11 @@
 // per SpMV.  Every rank ends up with the whole y; rank 0's copy is checked.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -19,22 +22,54 @@ struct RankOut {
     int rc = 0;
 };
 
+// The rank threads agree on success BEFORE the first collective: a rank that failed its set-up must not leave the
+// others waiting for it in ncclAllGather (they would sit there until the library's watchdog gives up).
+struct Agree {
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0, world = 0;
+    bool failed = false;
+    // every rank calls this once with its own verdict; returns true when ALL ranks are fine
+    bool all_ok(bool mine_ok)
+    {
+        std::unique_lock<std::mutex> lk(m);
+        failed |= !mine_ok;
+        if (++arrived == world) cv.notify_all();
+        else cv.wait(lk, [&] { return arrived == world; });
+        return !failed;
+    }
+};
+
 static void rank_main(int r, int world, nsparse_dist_t h, const sfCSR *full, const int *cuts, const real *x,
-                      const sfPlan *plan_in, real *y_out, RankOut *out)
+                      const sfPlan *plan_in, real *y_out, RankOut *out, Agree *agree)
 {
-    hipSetDevice(r);
-    sfCSR blk;
-    out->rc = nsparse_dist_csr_row_block(full, cuts[r], cuts[r + 1], &blk);
-    if (out->rc) return;
-    csr_memcpy(&blk);
+    sfCSR blk = {};
     real *d_x = nullptr, *d_y = nullptr;
-    hipMalloc((void **)&d_x, sizeof(real) * (full->N + MAX_BLOCK_SIZE));
-    hipMemset(d_x, 0, sizeof(real) * (full->N + MAX_BLOCK_SIZE));
-    hipMemcpy(d_x, x, sizeof(real) * full->N, hipMemcpyHostToDevice);
-    sfPlan plan = *plan_in;
-    out->rc = nsparse_dist_spmv_setup(h, &blk, cuts, d_x, &plan);
-    if (out->rc) return;
-    hipMalloc((void **)&d_y, sizeof(real) * (size_t)(nsparse_dist_y_elems(h) + WARP));
+    bool have_blk = false;
+    out->rc = hipSetDevice(r) == hipSuccess ? 0 : -1;
+    if (!out->rc) out->rc = nsparse_dist_csr_row_block(full, cuts[r], cuts[r + 1], &blk);
+    if (!out->rc) {
+        have_blk = true;
+        csr_memcpy(&blk);
+        if (hipMalloc((void **)&d_x, sizeof(real) * (full->N + MAX_BLOCK_SIZE)) != hipSuccess) out->rc = -2;
+    }
+    if (!out->rc) {
+        hipMemset(d_x, 0, sizeof(real) * (full->N + MAX_BLOCK_SIZE));
+        hipMemcpy(d_x, x, sizeof(real) * full->N, hipMemcpyHostToDevice);
+        sfPlan plan = *plan_in;
+        out->rc = nsparse_dist_spmv_setup(h, &blk, cuts, d_x, &plan);
+    }
+    if (!out->rc && hipMalloc((void **)&d_y, sizeof(real) * (size_t)(nsparse_dist_y_elems(h) + WARP)) != hipSuccess) out->rc = -2;
+    if (!agree->all_ok(out->rc == 0)) {  // some rank failed: nobody enters a collective
+        if (!out->rc) out->rc = -100;    // (this rank was fine)
+        if (d_x) hipFree(d_x);
+        if (d_y) hipFree(d_y);
+        if (have_blk) {
+            release_csr(blk);
+            release_cpu_csr(blk);
+        }
+        return;
+    }
     hipMemset(d_y, 0, sizeof(real) * (size_t)(nsparse_dist_y_elems(h) + WARP));
     // compute only, then compute + all-gather: TRI_NUM runs each, the first discarded (spmv_amb.cu:46-58)
     out->rc = nsparse_dist_spmv_loop(h, d_y, d_x, 0, 1, nullptr, nullptr, nullptr);
@@ -77,14 +112,18 @@ int main(int argc, char **argv)
     if (nsparse_dist_init_all(h.data(), world)) return 2;
     std::vector<RankOut> out((size_t)world);
     std::vector<std::thread> th;
+    Agree agree;
+    agree.world = world;
     for (int r = 0; r < world; r++)
-        th.emplace_back(rank_main, r, world, h[r], &mat, cuts.data(), x.data(), &plan, y.data(), &out[r]);
+        th.emplace_back(rank_main, r, world, h[r], &mat, cuts.data(), x.data(), &plan, y.data(), &out[r], &agree);
     for (auto &t : th) t.join();
     double ms_g = 0, ms_c = 0, us = 0;
     long long fp = 0;
     for (int r = 0; r < world; r++) {
         if (out[r].rc) {
-            fprintf(stderr, "rank %d failed: %d\n", r, out[r].rc);
+            for (int q = 0; q < world; q++)
+                if (out[q].rc && out[q].rc != -100) fprintf(stderr, "rank %d failed: %d\n", q, out[q].rc);
+            for (int q = 0; q < world; q++) nsparse_dist_destroy(h[q]);
             return 3;
         }
         ms_g = out[r].ms_gather > ms_g ? out[r].ms_gather : ms_g;
