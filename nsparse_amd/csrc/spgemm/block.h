@@ -75,7 +75,9 @@ __global__ __launch_bounds__(256) void k_twin_groups(const int *__restrict__ twi
 }
 
 template <int BS, int SPAN_MAX, int MODE, int U, bool KEYED = false>
-__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(BS <= 256 ? 6 : 2))) void k_num_block(const int *__restrict__ arpt, const int *__restrict__ acol,
+// (six wavefronts per SIMD for the window bins; the ranked-window instance -- SPAN_MAX 65536, two bitmap words more per
+// lane in registers -- reaches four, which is what is asked of it)
+__global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(BS <= 256 ? (SPAN_MAX > 12288 ? 4 : 6) : 2))) void k_num_block(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                   const real *__restrict__ aval,
                                                   const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                   const real *__restrict__ bval,
@@ -108,9 +110,9 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(BS <= 256 ? 
     // prof != nullptr (NSPARSE_BLK_PROF=1): thread 0 of every group head adds the shader-clock cycles of
     // its phases to its slots prof[8 * block + 0..4] (meta, park loads, run building, walk, emission;
     // [5], [6] = start and end of the group on the 100 MHz clock, [7] = rows)
-    unsigned long long t_prev = prof ? __builtin_readcyclecounter() : 0;
+    unsigned long long t_prev = (kExperiments && prof) ? __builtin_readcyclecounter() : 0;
     auto stamp = [&](int phase) {
-        if (prof && threadIdx.x == 0) {
+        if (kExperiments && prof && threadIdx.x == 0) {
             const unsigned long long t = __builtin_readcyclecounter();
             prof[8ull * blockIdx.x + phase] += t - t_prev;
             t_prev = t;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(BS <= 256 ? 
         maxb = row_maxb[rid];
         if (MODE == 1) bmo = bm_off[rid];
     }
-    if (prof && threadIdx.x == 0) {
+    if (kExperiments && prof && threadIdx.x == 0) {
         prof[8ull * blockIdx.x + 5] = wall_clock64();  // 100 MHz: when this group started
         prof[8ull * blockIdx.x + 7] = (unsigned long long)RA;
     }
@@ -248,7 +250,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(BS <= 256 ? 
     const int GW = G * K;  // entries per chunk
     const int gid = (int)threadIdx.x >> lg, gl = (int)threadIdx.x & (G - 1);
     const int NG = BS >> lg;
-    if (prof) { __syncthreads(); stamp(0); }
+    if (kExperiments && prof) { __syncthreads(); stamp(0); }
 
     // One iteration = one stretch of one pass of one batch of parked entries.  Batches with several passes or
     // stretches (more than RUNCAP runs / TCAP tasks among PARK entries: rare) park their entries AGAIN for each
@@ -475,7 +477,7 @@ __global__ __launch_bounds__(BS) __attribute__((amdgpu_waves_per_eu(BS <= 256 ? 
             }
         }
     }
-    if (prof) {
+    if (kExperiments && prof) {
         __syncthreads();
         stamp(4);
         if (threadIdx.x == 0) prof[8ull * blockIdx.x + 6] = wall_clock64();  // ... and when it was done

@@ -10,6 +10,15 @@ namespace spgemm {
 
 constexpr int NB = kMaxBins;
 
+// -DNSPARSE_EXPERIMENTS (make EXTRA=-DNSPARSE_EXPERIMENTS): the in-kernel phase timers, the LDS padding knobs and the
+// workgroup-size / ladder overrides of the measurements in DESIGN.md 4.1.  The product build has none of them: the
+// timers cost registers in the latency-bound row kernels, every override is a kernel instantiation nobody runs.
+#ifdef NSPARSE_EXPERIMENTS
+constexpr bool kExperiments = true;
+#else
+constexpr bool kExperiments = false;
+#endif
+
 // ---- bin ladders ------------------------------------------------------------------
 // Symbolic, n = intermediate products of the row (upper bound of its nnz):
 //   bin 0  n <= 32      sub-wave rows, 4 lanes per row, 64-key table per row
@@ -572,88 +581,6 @@ __device__ __forceinline__ void ht_insert_vec(int *tab, int mask, const IVecT<V>
 }
 
 
-// ---- wave-cooperative probing (BASELINE north_star: "wavefront-wide linear probing using ds_bpermute /
-// ballot") ---------------------------------------------------------------------------------------
-// One key at a time, all the lanes that are active inspect consecutive slots of its probe sequence:
-// lane with rank q among the active lanes reads slot h + q; a ballot finds the key or the first empty slot
-// in probe order, the lane that saw the empty slot claims it with one CAS.  NSPARSE_COOP=1: every lane
-// first tries its own keys with one CAS each (as ht_insert_vec) and only the keys that collided are
-// resolved cooperatively, one after the other; NSPARSE_COOP=2: every key is inserted cooperatively.
-// Kept as a measured alternative: with tables at load factor <= 2/3 a probe sequence is two
-// slots long on average, and the cooperative form spends a whole wavefront instruction stream per key.
-__device__ __forceinline__ int ht_coop_one(int *tab, int mask, int key, int h0, int *fresh)
-{
-    const unsigned long long active = __ballot(1);
-    const int nact = __popcll(active);
-    const int lane = (int)(threadIdx.x & 63);
-    const int q = __popcll(active & ((1ull << lane) - 1ull));
-    int base = h0;
-    while (true) {
-        const int s = (base + q) & mask;
-        const int v = lds_load(tab + s);
-        const unsigned long long hit = __ballot(v == key);
-        if (hit) {
-            *fresh = 0;
-            return __builtin_amdgcn_readlane(s, __ffsll((long long)hit) - 1);
-        }
-        const unsigned long long emp = __ballot(v == -1);
-        if (emp) {
-            const int w = __ffsll((long long)emp) - 1;  // active lanes are ranked in lane order: first in probe order
-            int old = -2;
-            if (lane == w) old = atomicCAS(tab + s, -1, key);
-            old = __builtin_amdgcn_readlane(old, w);
-            if (old == -1 || old == key) {
-                *fresh = old == -1;
-                return __builtin_amdgcn_readlane(s, w);
-            }
-            continue;  // another wavefront took that slot meanwhile: look at the same window again
-        }
-        base += nact;
-    }
-}
-
-template <int V>
-__device__ __forceinline__ void ht_insert_vec_coop(int *tab, int mask, const IVecT<V> &k, int n, int (&h)[V],
-                                                   int &fresh, int mode)
-{
-    const int lane = (int)(threadIdx.x & 63);
-    bool pend[V];
-#pragma unroll
-    for (int i = 0; i < V; i++) {
-        h[i] = hash_slot(k.v[i], mask);
-        pend[i] = i < n;
-        if (mode == 1 && i < n) {
-            const int old = atomicCAS(tab + h[i], -1, k.v[i]);
-            fresh += old == -1;
-            pend[i] = old != -1 && old != k.v[i];
-            h[i] = (h[i] + 1) & mask;  // where the cooperative search of a collided key starts
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < V; i++) {
-        unsigned long long m = __ballot(pend[i]);
-        while (m) {
-            const int L = __ffsll((long long)m) - 1;
-            const int key = __builtin_amdgcn_readlane(k.v[i], L);
-            const int hs = __builtin_amdgcn_readlane(h[i], L);
-            int f;
-            const int slot = ht_coop_one(tab, mask, key, hs, &f);
-            if (lane == L) {
-                h[i] = slot;
-                fresh += f;
-            }
-            m &= m - 1;
-        }
-    }
-    if (mode == 1) {
-        // lanes whose first CAS decided keep h at the slot they used
-#pragma unroll
-        for (int i = 0; i < V; i++)
-            if (i < n && !pend[i]) h[i] = (h[i] - 1) & mask;
-    }
-}
-
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. it
 // waits for the acknowledgement of every global store issued before it; the tiled kernel
 // emits a tile with global stores nobody in the workgroup reads back, so waiting for them
@@ -913,134 +840,6 @@ __device__ __forceinline__ void bitonic_sort_lds(int *s, int P)
         }
         __syncthreads();
     }
-}
-
-// The occupied slots of a hash table (empty = -1, T slots, at most SPT * BS) straight into `srt`, SORTED ascending:
-// one pass partitions the keys into NBK buckets of 2^shift consecutive column ids (count, scan, scatter with LDS
-// atomics -- the slots stay in registers in between), then every bucket is sorted by ONE wavefront in registers:
-// up to 64 keys by counting (readlane), up to 128 / 512 by the register stages of the bitonic network.  Replaces
-// ballot compaction + a full bitonic sort (2 + 19 us of the 39 us of a row of the 8192-slot numeric bin on
-// R-MAT-22, where the sort had become the largest phase once the walk was flat): a bucket holds n / NBK keys on
-// average, and even the power-law skew of R-MAT columns (each id bit is 0 with probability 0.76: the all-zero
-// bucket holds 8.5 % of a row) stays below 512.  Returns false when some bucket does not (srt then holds the keys
-// unsorted: the caller pads and runs the full network).  s_bk: 2 * NBK + 8 ints.  Workgroup barriers inside.
-template <int BS, int NBK, int SPT>
-__device__ __noinline__ bool table_to_sorted(const int *tab, int T, int *srt, int *s_bk)
-{
-    constexpr int PER = NBK / 64;
-    static_assert(NBK % 64 == 0, "one wavefront scans the buckets");
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int *cursor = s_bk, *bstart = s_bk + NBK, *mm = s_bk + 2 * NBK + 1;
-    int kk[SPT], mn = 0x7fffffff, mx = -0x7fffffff - 1;
-#pragma unroll
-    for (int j = 0; j < SPT; j++) {
-        const int i = (int)threadIdx.x + j * BS;
-        kk[j] = i < T ? tab[i] : -1;
-        if (kk[j] != -1) {
-            mn = kk[j] < mn ? kk[j] : mn;
-            mx = kk[j] > mx ? kk[j] : mx;
-        }
-    }
-    for (int i = threadIdx.x; i < NBK; i += BS) cursor[i] = 0;
-    if (threadIdx.x == 0) {
-        mm[0] = 0x7fffffff;
-        mm[1] = -0x7fffffff - 1;
-        mm[2] = 0;
-        mm[3] = 0;  // next bucket to sort
-    }
-    __syncthreads();
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        const int a = __shfl_xor(mn, o), b = __shfl_xor(mx, o);
-        mn = a < mn ? a : mn;
-        mx = b > mx ? b : mx;
-    }
-    if (lane == 0 && mn <= mx) {
-        atomicMin(&mm[0], mn);
-        atomicMax(&mm[1], mx);
-    }
-    __syncthreads();
-    const int lo = mm[0];
-    const unsigned int range = (unsigned int)(mm[1] - lo);
-    int shift = 0;
-    while ((range >> shift) >= (unsigned int)NBK) shift++;
-#pragma unroll
-    for (int j = 0; j < SPT; j++)
-        if (kk[j] != -1) atomicAdd(&cursor[(unsigned int)(kk[j] - lo) >> shift], 1);
-    __syncthreads();
-    if (wv == 0) {
-        int c[PER], sum = 0;
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            c[q] = cursor[lane * PER + q];
-            sum += c[q];
-        }
-        const int incl = wave_incl_scan(sum);
-        int base = incl - sum;
-#pragma unroll
-        for (int q = 0; q < PER; q++) {
-            bstart[lane * PER + q] = base;
-            cursor[lane * PER + q] = base;
-            base += c[q];
-        }
-        if (lane == 63) bstart[NBK] = incl;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < SPT; j++)
-        if (kk[j] != -1) srt[atomicAdd(&cursor[(unsigned int)(kk[j] - lo) >> shift], 1)] = kk[j];
-    __syncthreads();
-    constexpr int INF = 0x7fffffff;
-    // the wavefronts PULL buckets (8 at a time) instead of striding over them: on power-law inputs the big buckets are
-    // those whose index is a power of two -- every one of them a multiple of the wavefront count
-    while (true) {
-        int b8 = 0;
-        if (lane == 0) b8 = atomicAdd(&mm[3], 8);
-        b8 = __builtin_amdgcn_readfirstlane(b8);
-        if (b8 >= NBK) break;
-      for (int b = b8; b < b8 + 8; b++) {
-        const int base = bstart[b], sz = bstart[b + 1] - base;
-        if (sz <= 1) continue;
-        if (sz <= 64) {  // rank by counting: the keys are distinct
-            const int k = lane < sz ? srt[base + lane] : INF;
-            int rank = 0;
-            for (int j = 0; j < sz; j++) rank += __builtin_amdgcn_readlane(k, j) < k ? 1 : 0;
-            if (lane < sz) srt[base + rank] = k;
-        } else if (sz <= 128) {
-            int r0 = lane < sz ? srt[base + lane] : INF, r1 = lane + 64 < sz ? srt[base + lane + 64] : INF;
-            bitonic_stages_reg<1>(r0, r1, lane, 2, lane);
-            bitonic_stages_reg<2>(r0, r1, lane, 4, lane);
-            bitonic_stages_reg<4>(r0, r1, lane, 8, lane);
-            bitonic_stages_reg<8>(r0, r1, lane, 16, lane);
-            bitonic_stages_reg<16>(r0, r1, lane, 32, lane);
-            bitonic_stages_reg<32>(r0, r1, lane, 64, lane);
-            bitonic_stages_reg<64>(r0, r1, lane, 128, lane);
-            if (lane < sz) srt[base + lane] = r0;
-            if (lane + 64 < sz) srt[base + lane + 64] = r1;
-        } else if (sz <= 512) {
-            const int eb = lane * 8;
-            int r[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) r[i] = eb + i < sz ? srt[base + eb + i] : INF;
-            bitonic_stages_reg8<1>(r, eb, 2, lane);
-            bitonic_stages_reg8<2>(r, eb, 4, lane);
-            bitonic_stages_reg8<4>(r, eb, 8, lane);
-            bitonic_stages_reg8<8>(r, eb, 16, lane);
-            bitonic_stages_reg8<16>(r, eb, 32, lane);
-            bitonic_stages_reg8<32>(r, eb, 64, lane);
-            bitonic_stages_reg8<64>(r, eb, 128, lane);
-            bitonic_stages_reg8<128>(r, eb, 256, lane);
-            bitonic_stages_reg8<256>(r, eb, 512, lane);
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (eb + i < sz) srt[base + eb + i] = r[i];
-        } else if (lane == 0) {
-            mm[2] = 1;  // too skewed for this scheme: the caller sorts the whole row
-        }
-      }
-    }
-    __syncthreads();
-    return mm[2] == 0;
 }
 
 // Rows with more than 5461 non-zeros do not fit an LDS hash table, and on power-law inputs

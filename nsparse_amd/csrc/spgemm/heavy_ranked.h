@@ -51,10 +51,10 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
     // belong to k_num_listed.
     // prof (NSPARSE_TILED_PROF=1), 100 MHz ticks of thread 0: 0 set-up, 1 pass 1, 2 scan, 3 pass 2,
     // 4 emission; 5 tiles, 6 rows
-    unsigned long long tk = prof ? wall_clock64() : 0;
+    unsigned long long tk = (kExperiments && prof) ? wall_clock64() : 0;
     unsigned long long t_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto tick = [&](int phase) {
-        if (prof) {
+        if (kExperiments && prof) {
             const unsigned long long now = wall_clock64();
             t_acc[phase] += now - tk;
             tk = now;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
         int t_lo = lo;
         int sym_cnt = 0;
         tick(0);
-        if (prof) {
+        if (kExperiments && prof) {
             t_acc[6]++;
             t_acc[10] += nlong;
             t_acc[11] += alen;
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             }  // pass 1 + scan (rows without a list)
             const int t_hi = rlist ? t_hi_l : s_cut, ntile = rlist ? ntile_l : s_ntile;
             tick(2);
-            if (prof && t_hi != t_max) t_acc[9]++;
+            if (kExperiments && prof && t_hi != t_max) t_acc[9]++;
             walk(std::true_type{}, t_hi);
             lds_barrier();
             tick(t_lo == lo ? 8 : 3);
@@ -477,11 +477,11 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             t_lo = (rlist != nullptr && pos - pos0 < row_nnz) ? rlist[pos - pos0] : t_hi;
             lds_barrier();
             tick(4);
-            if (prof) t_acc[5]++;
+            if (kExperiments && prof) t_acc[5]++;
         }
         if (SYM && threadIdx.x == 0) row_nz_out[rid] = sym_cnt;  // nnz of the row = bits seen over all tiles (uniform)
     }
-    if (prof && threadIdx.x == 0)
+    if (kExperiments && prof && threadIdx.x == 0)
         for (int i = 0; i < 13; i++) atomicAdd(prof + 16 + i, t_acc[i]);
 }
 

@@ -27,10 +27,10 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
     // prof (NSPARSE_TILED_PROF=1): thread 0 adds 100 MHz ticks per phase -- 0 cursor set-up,
     // 2 register-fed accumulation, 3 overflow paths, 4 emission, 5 tiles, 6 rows
     // (kept in registers, one atomic per counter when the workgroup retires)
-    unsigned long long tk = prof ? wall_clock64() : 0;
+    unsigned long long tk = (kExperiments && prof) ? wall_clock64() : 0;
     unsigned long long t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto tick = [&](int phase) {
-        if (prof) {
+        if (kExperiments && prof) {
             const unsigned long long now = wall_clock64();
             t_acc[phase] += now - tk;
             tk = now;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
             }
         }
         tick(0);
-        if (prof) t_acc[6]++;
+        if (kExperiments && prof) t_acc[6]++;
         int pos = crpt[rid];
         for (int t0 = 0; t0 < span; t0 += W) {
             const int tw = span - t0 < W ? span - t0 : W;  // columns in this tile
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
             for (int s = 0; s < KS; s++) fresh[s] = true;
             do {
                 more = false;
-                if (prof) t_acc[10]++;
+                if (kExperiments && prof) t_acc[10]++;
 #pragma unroll
                 for (int s = 0; s < KS; s++) {
                     if (!fresh[s]) continue;  // wave-uniform
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                     }
                 }
             } while (__any(more));
-            if (prof) {
+            if (kExperiments && prof) {
                 __syncthreads();
                 tick(2);
             }
@@ -359,10 +359,10 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
             tick(9);
             lds_barrier();
             tick(4);
-            if (prof) t_acc[5]++;
+            if (kExperiments && prof) t_acc[5]++;
         }
     }
-    if (prof && threadIdx.x == 0)
+    if (kExperiments && prof && threadIdx.x == 0)
         for (int i = 0; i < 12; i++) atomicAdd(prof + i, t_acc[i]);
 }
 

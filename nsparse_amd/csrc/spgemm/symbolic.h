@@ -87,7 +87,7 @@ __global__ __launch_bounds__(BS) void k_sym_small(const int *__restrict__ arpt,
 #ifndef NSP_FLAT_SYM_MIN_T
 #define NSP_FLAT_SYM_MIN_T 512
 #endif
-template <int BS, int TMAX, bool LARGE, int COOP = 0>
+template <int BS, int TMAX, bool LARGE>
 __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                                const int *__restrict__ acol,
                                                const int *__restrict__ brpt,
@@ -139,8 +139,7 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
                                        a_beg, a_end, np, mb_row, s_ext, (real *)nullptr, &s_defer,
                                        [&](const IVec &k, const RVecT<1> &, int n, real) {
                                            int h[VW];
-                                           if (COOP) ht_insert_vec_coop(tab, mask, k, n, h, cnt, COOP);
-                                           else ht_insert_vec(tab, mask, k, n, h, cnt);
+                                           ht_insert_vec(tab, mask, k, n, h, cnt);
                                        }, (TMAX >= NSP_FLAT_SYM_MIN_T && flat_on) ? reinterpret_cast<FlatScratch<BS> *>(&s_flat) : (FlatScratch<BS> *)nullptr,
                                        flat_on == 2);
     } else {
@@ -211,134 +210,6 @@ __global__ __launch_bounds__(BS) void k_sym_tb(const int *__restrict__ arpt,
             int *dst = tcol + s_off;
             for (int i = threadIdx.x; i < nz; i += BS) dst[i] = tab[i];
         }
-    }
-}
-
-// One-wavefront symbolic bin with PERSISTENT wavefronts and the next rows' dependent loads in flight behind the
-// current row (round 3).  k_sym_tb<64, ...> is five dependent round trips per row (row number -> row words ->
-// A entries -> B extents -> B entries) around a few hundred instructions of hashing, with 32 rows in flight per CU
-// (one per wavefront: counters say 60-70 % of the wave cycles wait on memory).  Here a wavefront strides over the
-// rows of its XCD's eighth of the bin with a three-stage pipeline in registers: row i + 2's four row words (ONE
-// vector load, lanes 0..3 one word each: a scalar load would be waited for at the first LDS fence), row i + 1's A
-// entry of the first batch and then its B extent, row i walked from registers.  Rows with one B row far longer than
-// the others ("mixed") take the flat walk as in k_sym_tb; their first batch is not prefetched.
-// MEASURED SLOWER than k_sym_tb<64, 1024> (stencil symbolic 0.75 -> 1.05 ms; so was the same pipeline in the numeric
-// bin, numeric.h: k_num_wave): what helped these bins was more rows in flight per CU, not a shorter chain per
-// wavefront.  Opt-in (NSPARSE_SYM_WAVE=n), parity test test_persistent_wavefront_bin.
-template <int TMAX>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8))) void k_sym_wave(const int *__restrict__ arpt, const int *__restrict__ acol,
-                                                 const int *__restrict__ brpt, const int *__restrict__ bcol,
-                                                 const int *__restrict__ row_perm, const int *__restrict__ row_prod,
-                                                 const int *__restrict__ row_maxb, int *__restrict__ row_nz, int bin_off,
-                                                 int bin_size, int bnnz, int flat_on)
-{
-    constexpr int BS = 64;
-    __shared__ __attribute__((aligned(16))) int tab[TMAX];
-    __shared__ int2 s_ext[BS];
-    __shared__ DeferList<false, (TMAX == 1024 ? 24 : 32)> s_defer;
-    __shared__ FlatScratch<BS> s_flat;
-    const int lane = threadIdx.x;
-    const int nb8 = (bin_size + 7) >> 3;
-    const int xcd = (int)(blockIdx.x & 7), stride = (int)(gridDim.x >> 3), j0 = (int)(blockIdx.x >> 3);
-    auto rid_batch = [&](int i0) {  // lane l: the (i0 + l)-th row of this wavefront, -1 beyond the eighth / the bin
-        const unsigned j = (unsigned)j0 + (unsigned)(i0 + lane) * (unsigned)stride;
-        const unsigned slot = (unsigned)xcd * (unsigned)nb8 + j;
-        return (j < (unsigned)nb8 && slot < (unsigned)bin_size) ? row_perm[(unsigned)bin_off + slot] : -1;
-    };
-    // lanes 0..3 fetch row_prod[rid], arpt[rid], arpt[rid + 1], row_maxb[rid]
-    const int *lane_base = row_prod;
-    lane_base = lane == 1 ? arpt : lane_base;
-    lane_base = lane == 2 ? arpt + 1 : lane_base;
-    lane_base = lane == 3 ? row_maxb : lane_base;
-    auto row_words = [&](int rid) { return (rid >= 0 && lane < 4) ? lane_base[rid] : 0; };
-    // lane groups of the walk for the row whose words are w; bit 8: mixed (walk_products_mixed's rule)
-    auto width_of = [&](int w) {
-        const int np = __builtin_amdgcn_readlane(w, 0);
-        const int alen = __builtin_amdgcn_readlane(w, 2) - __builtin_amdgcn_readlane(w, 1);
-        const int mb = __builtin_amdgcn_readlane(w, 3);
-        const bool mixed = alen > 1 && (long long)mb * alen > 8LL * np;
-        return group_width(np, alen, BS, mb) | (mixed ? 256 : 0);
-    };
-    // the lane's A entry of the first batch of walk_products (b0 = 0: m = gl), -1: none (or a mixed row)
-    auto first_entry = [&](int rid, int w, int gm) {
-        const int g = gm & 255;
-        const int a_beg = __builtin_amdgcn_readlane(w, 1), a_end = __builtin_amdgcn_readlane(w, 2);
-        const int lg = 31 - __clz(g), lng = 6 - lg, ng = 1 << lng, gid = lane >> lg, gl = lane & (g - 1);
-        const int first = a_beg + gid;
-        const int cnt = first < a_end ? (a_end - first + ng - 1) >> lng : 0;
-        return (rid >= 0 && !(gm & 256) && gl < cnt) ? first + gl * ng : -1;
-    };
-    struct __attribute__((aligned(4))) I2 {
-        int b, e;
-    };
-    int rids = rid_batch(0);
-    if (__builtin_amdgcn_readlane(rids, 0) < 0) return;
-    int rid_cur = __builtin_amdgcn_readlane(rids, 0);
-    int w_cur = row_words(rid_cur);
-    int gm_cur = width_of(w_cur);
-    int2 pre_e = make_int2(0, 0);
-    {
-        const int j = first_entry(rid_cur, w_cur, gm_cur);
-        if (j >= 0) {
-            const int c = __builtin_nontemporal_load(acol + j);
-            const I2 r = *reinterpret_cast<const I2 *>(brpt + c);
-            pre_e = make_int2(r.b, r.e);
-        }
-    }
-    int rid_nxt = __builtin_amdgcn_readlane(rids, 1);
-    int w_nxt = row_words(rid_nxt);
-    for (int i = 0;; i++) {
-        // ---- requests for the rows behind this one ----------------------------------------------
-        if (((i + 2) & 63) == 0) rids = rid_batch(i + 2);  // (one trip per 64 rows)
-        const int rid2 = rid_nxt >= 0 ? __builtin_amdgcn_readlane(rids, (i + 2) & 63) : -1;
-        const int w2 = row_words(rid2);
-        const int gm_nxt = width_of(w_nxt);
-        const int jn = first_entry(rid_nxt, w_nxt, gm_nxt);
-        int cn = 0;
-        if (jn >= 0) cn = __builtin_nontemporal_load(acol + jn);
-        // ---- this row -------------------------------------------------------------------------------
-        const int np = __builtin_amdgcn_readlane(w_cur, 0);
-        const int a_beg = __builtin_amdgcn_readlane(w_cur, 1), a_end = __builtin_amdgcn_readlane(w_cur, 2);
-        int T = pow2_ceil(np + (np >> 1));
-        T = T < 64 ? 64 : (T > TMAX ? TMAX : T);
-        const int mask = T - 1;
-        {
-            int4 *t4 = reinterpret_cast<int4 *>(tab);
-            const int4 m1 = make_int4(-1, -1, -1, -1);
-            for (int q = lane; q < T / 4; q += BS) t4[q] = m1;
-        }
-        if (lane == 0) s_defer.n = 0;
-        wave_lds_sync();
-        int cnt = 0;
-        auto consume = [&](const IVec &k, const RVecT<1> &, int n, real) {
-            int h[VW];
-            ht_insert_vec(tab, mask, k, n, h, cnt);
-        };
-        if (gm_cur & 256) {
-            walk_products_mixed<BS, false>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg, a_end,
-                                           np, __builtin_amdgcn_readlane(w_cur, 3), s_ext, (real *)nullptr, &s_defer, consume,
-                                           flat_on ? &s_flat : (FlatScratch<BS> *)nullptr, flat_on == 2);
-        } else {
-            walk_products<BS, false, VW, decltype(consume) &, (TMAX == 1024 ? 24 : 32)>(
-                acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg, a_end, gm_cur & 255, s_ext,
-                (real *)nullptr, consume, (DeferList<false, (TMAX == 1024 ? 24 : 32)> *)nullptr, 0x7fffffff, nullptr, &pre_e,
-                (const real *)nullptr);
-        }
-        // ---- next row: B extent of the lane's entry (its column has had the whole walk to arrive) ----
-        pre_e = make_int2(0, 0);
-        if (jn >= 0) {
-            const I2 r = *reinterpret_cast<const I2 *>(brpt + cn);
-            pre_e = make_int2(r.b, r.e);
-        }
-        cnt = wave_sum(cnt);
-        if (lane == 0) row_nz[rid_cur] = cnt;
-        if (rid_nxt < 0) return;
-        wave_lds_sync();  // the next row clears the table this one has just filled
-        rid_cur = rid_nxt;
-        w_cur = w_nxt;
-        gm_cur = gm_nxt;
-        w_nxt = w2;
-        rid_nxt = rid2;
     }
 }
 

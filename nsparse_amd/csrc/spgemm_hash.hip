@@ -49,7 +49,7 @@
 //   spgemm/block.h         k_num_block, k_twin_groups                     (numeric bins 6-9: node blocks)
 //   spgemm/heavy_tiled.h   k_num_tiled                                    (bin 5, dense tiles)
 //   spgemm/heavy_ranked.h  k_num_ranked                                   (bin 5, thin rows)
-//   spgemm/listed.h        k_num_listed                                   (bin 5, rows with a column list from the symbolic phase)
+//   spgemm/lean.h          k_sym_lean, k_num_lean                         (hash bins 1-4 on an instruction diet, round 4)
 //
 // Results: C.rpt / C.col are bit-identical to the reference by construction (distinct
 // columns per row, ascending); C.val differs only by floating-point summation order
@@ -72,7 +72,6 @@
 #include "spgemm/fused.h"
 #include "spgemm/heavy_tiled.h"
 #include "spgemm/heavy_ranked.h"
-#include "spgemm/listed.h"
 #include "spgemm/lean.h"
 
 namespace nsp {
@@ -82,6 +81,19 @@ namespace spgemm {
 //  host orchestration
 // ===================================================================================
 
+// Switches of the measurements in DESIGN.md 4.1: read from the environment only in a -DNSPARSE_EXPERIMENTS build,
+// constants in the product.
+static inline int exp_env(const char *name, int dflt)
+{
+#ifdef NSPARSE_EXPERIMENTS
+    const char *e = getenv(name);
+    return e ? atoi(e) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 // Numeric ladder in force.  NSPARSE_NUM_HEAVY_MIN=<n> (experiments): rows with more than n non-zeros go
 // to the heavy bin (cursor kernels, no sort) instead of the LDS hash bins above that size.
 static const Thr &num_ladder()
@@ -89,12 +101,10 @@ static const Thr &num_ladder()
     static Thr t = [] {
         Thr v = kNumThr;
         if (getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0) v.rank_span = 0;  // needs the block kernel
-        const char *e = getenv("NSPARSE_NUM_HEAVY_MIN");
-        if (e && atoi(e) > 0) {
-            const int n = atoi(e);
+        const int n = exp_env("NSPARSE_NUM_HEAVY_MIN", 0);
+        if (n > 0)
             for (int q = 0; q < 4; q++)
                 if (v.hash_t[q] > n) v.hash_t[q] = n;
-        }
         return v;
     }();
     return t;
@@ -107,15 +117,15 @@ static const Thr &sym_ladder()
 {
     static Thr t = [] {
         Thr v = kSymThr;
-        if (getenv("NSPARSE_SYM1_T") && atoi(getenv("NSPARSE_SYM1_T")) == 512) v.hash_t[0] = 435;
+        if (exp_env("NSPARSE_SYM1_T", 1024) == 512) v.hash_t[0] = 435;
         return v;
     }();
     return t;
 }
 
-// NSPARSE_COOP=1 / 2: wave-cooperative probing in the LDS hash bins (common.h: ht_insert_vec_coop), the
-// alternative BASELINE's north_star names; 0 (default): one lane per key.  Measured in DESIGN 4.1.
-static const int g_coop = getenv("NSPARSE_COOP") ? atoi(getenv("NSPARSE_COOP")) : 0;
+// (wave-cooperative probing -- every active lane inspects a slot of ONE key's probe sequence, ballot, one CAS -- is
+//  the alternative BASELINE's north_star names.  Built in round 2 and measured 1.2-15x slower than one lane per key at
+//  load factor <= 2/3, profiles/r02_coop_probe.jsonl; removed in round 4.)
 // The flat product walk (common.h: walk_products_flat) in the big-table hash bins (numeric 3 / 4, symbolic 3 / 4).
 // 2 (default): every row of those bins; 1: only rows whose longest B row is more than 8x their average (the
 // round-2 criterion for parking long rows); 0: the round-2 walk (group walk + parked long rows).  R-MAT-22
@@ -128,19 +138,14 @@ static const int g_tb_lean = getenv("NSPARSE_TB_LEAN") ? atoi(getenv("NSPARSE_TB
 
 // Column lists (common.h: list_wanted): a heavy row goes to the listed kernel while slices x products stays within
 // this (NSPARSE_LIST_WORK); beyond it the cursor kernels, which see every product once, are cheaper.
-static long long list_work()
-{
-    static const long long w = getenv("NSPARSE_LIST_WORK") ? atoll(getenv("NSPARSE_LIST_WORK")) : 150000LL;
-    return w;
-}
-// NSPARSE_LIST: 0 no column lists; 1 (default) lists from the symbolic CURSOR kernel only -- matrices wider than
+// NSPARSE_LIST: 0 no column lists; 1 (default) lists from the symbolic CURSOR kernel -- matrices wider than
 // 2^20 columns, where the ranked numeric tiles are bound by the width of their bitmap -- for the list-driven tiles
 // of the ranked kernel (heavy_ranked.h): R-MAT-22 numeric heavy bin 41 -> 30 ms for 5-7 ms more in the symbolic
-// kernel; 2: lists from the one-piece bit-window kernel as well (R-MAT-18: a wash) and the listed kernel
-// (listed.h) for the rows list_wanted picks
+// kernel.  (Round 3 also had lists from the one-piece bit-window kernel and a flat "listed" numeric kernel for the
+// rows with one: R-MAT-18 a wash, R-MAT-22 no gain; removed in round 4, measurements in DESIGN 4.1.)
 static int list_mode()
 {
-    static const int m = getenv("NSPARSE_LIST") ? atoi(getenv("NSPARSE_LIST")) : 1;
+    static const int m = getenv("NSPARSE_LIST") ? (atoi(getenv("NSPARSE_LIST")) != 0) : 1;
     return m;
 }
 
@@ -194,7 +199,7 @@ static int launch_row_products(const sfCSR *a, const sfCSR *b, const BInfo *binf
                                 int *long_cnt, TwinMap tw, bool reduce, hipStream_t st)
 {
     const int M = a->M;
-    static const int w_env = getenv("NSPARSE_RP_W") ? atoi(getenv("NSPARSE_RP_W")) : 0;  // lanes per row, forced (experiments)
+    static const int w_env = exp_env("NSPARSE_RP_W", 0);  // lanes per row, forced
     const int w = (w_env == 1 || w_env == 2 || w_env == 4 || w_env == 8 || w_env == 16 || w_env == 32 || w_env == 64)
                       ? w_env : pick_w_regular(a->nnz, M, a->nnz_max);
     int grid = ceil_div((long long)M * w, 256);
@@ -271,7 +276,7 @@ struct BinLauncher {
     BinLauncher(Context &c, int phase, const int *hist = nullptr, int big_a = -1, int big_b = -1)
         : cx(&c), ev(c.ev_bin + phase * 2 * NB), serial(c.profiling), timed(c.profiling || c.bin_timing), main_bin(-1)
     {
-        static const bool big_main = !(getenv("NSPARSE_BIG_MAIN") && atoi(getenv("NSPARSE_BIG_MAIN")) == 0);
+        static const bool big_main = exp_env("NSPARSE_BIG_MAIN", 1) != 0;
         if (hist) {
             int best = 0;
             for (int b = 0; b < NB; b++)
@@ -295,7 +300,7 @@ struct BinLauncher {
     // further.  So the queueing stays.
     hipStream_t stream_of(int b) const
     {
-        static const bool swap0 = getenv("NSPARSE_BIN0_SWAP") && atoi(getenv("NSPARSE_BIN0_SWAP")) == 1;
+        static const bool swap0 = exp_env("NSPARSE_BIN0_SWAP", 0) == 1;
         if (serial || b == main_bin) return cx->stream[0];
         if (b == 0 && main_bin > 0 && swap0) return cx->stream[main_bin];
         return cx->stream[b];
@@ -370,7 +375,7 @@ static int global_slab_groups(long long slice_elems, size_t bytes_per_elem, int 
 // the receiving launch simply starts earlier.  NSPARSE_FOLD=0 switches it off.
 static void fold_small_hash_bins(const int *hist_in, int *hist, int *off)
 {
-    static const int fold_max = getenv("NSPARSE_FOLD") ? atoi(getenv("NSPARSE_FOLD")) : 128;
+    static const int fold_max = exp_env("NSPARSE_FOLD", 128);
     off[0] = 0;
     for (int q = 0; q < NB; q++) {
         hist[q] = hist_in[q];
@@ -402,8 +407,8 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     *fail_rows = 0;
     int *fail_list = nullptr;
     L.fork();
-#define NSP_SYM_TB_GO(BS, TMAX, COOPX)                                                          \
-    hipLaunchKernelGGL((k_sym_tb<BS, TMAX, false, COOPX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, \
+#define NSP_SYM_TB_GO(BS, TMAX)                                                                 \
+    hipLaunchKernelGGL((k_sym_tb<BS, TMAX, false>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, \
                        st, arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], \
                        hist[bin_], b->nnz, d_bs, (int *)nullptr, g_flat, TMAX >= 8192 ? tcol : (int *)nullptr, list_off,   \
                        row_span, 12, 12288)
@@ -411,13 +416,11 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        if ((g_tb_lean & 1) && g_coop == 0)                                                    \
+        if (g_tb_lean & 1)                                                                     \
             hipLaunchKernelGGL((k_sym_lean<BS, TMAX, (BS >= 256 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
                                arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], hist[bin_], b->nnz, d_bs, \
                                TMAX >= 8192 ? tcol : (int *)nullptr, list_off, row_span, 12, 12288);  \
-        else if (g_coop == 1) NSP_SYM_TB_GO(BS, TMAX, 1);                                      \
-        else if (g_coop == 2) NSP_SYM_TB_GO(BS, TMAX, 2);                                      \
-        else NSP_SYM_TB_GO(BS, TMAX, 0);                                                       \
+        else NSP_SYM_TB_GO(BS, TMAX);                                                          \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -439,7 +442,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         hipStream_t st = L.begin(BIN);                                                         \
         hipLaunchKernelGGL((k_sym_bits<BS, WORDS>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), 0, st, \
                            arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_lo, row_span, row_nz, \
-                           off[BIN], hist[BIN], b->nnz, d_bs, list_mode() == 2 ? tcol : (int *)nullptr, list_off, -1LL, 12, 12288); \
+                           off[BIN], hist[BIN], b->nnz, d_bs, (int *)nullptr, list_off, -1LL, 12, 12288); \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -458,7 +461,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     // bin 10 with windows wider than the 2^20-bit window and sorted rows of B: cursor kernel, every
     // product seen once (k_sym_bits would walk all products once per 2^20-column piece)
     static const int sym_cursor_on = !(getenv("NSPARSE_SYM_CURSOR") && getenv("NSPARSE_SYM_CURSOR")[0] == '0');
-    static const int sym_long_len = getenv("NSPARSE_SYM_LONG") ? atoi(getenv("NSPARSE_SYM_LONG")) : 32;
+    static const int sym_long_len = exp_env("NSPARSE_SYM_LONG", 32);
     if (hist[10] > 0 && now(10) && sym_cursor_on && b_sorted && max_span[10] > 32768 * 32 && max_alen > 0) {
         hipStream_t st = L.begin(10);
         const int rows = hist[10];
@@ -470,7 +473,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
                            (const real *)nullptr, brpt, bcol, (const real *)nullptr, (const int *)nullptr,
                            (int *)nullptr, (real *)nullptr, row_perm, off[10], rows, d_bs, row_lo, row_span, slab,
                            stride_ints, amax, 0, sym_long_len, -1, 0, (unsigned long long *)nullptr, row_nz, tcol, list_off,
-                           getenv("NSPARSE_LIST_DRY") ? -2LL : -1LL, (const int *)row_prod);
+                           exp_env("NSPARSE_LIST_DRY", 0) ? -2LL : -1LL, (const int *)row_prod);
         NSP_LAUNCH_CHECK();
         L.end(10);
         L.free_later(slab);
@@ -478,32 +481,33 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         NSP_SYM_BITS(10, 1024, 32768)
     }
     NSP_SYM_BITS(9, 512, 8192)
-    static const int tune_d6 = getenv("NSPARSE_SYMD6_BS") ? atoi(getenv("NSPARSE_SYMD6_BS")) : 128;
-    static const int tune_d8 = getenv("NSPARSE_SYMD8_BS") ? atoi(getenv("NSPARSE_SYMD8_BS")) : 512;
+    // workgroup sizes: the winners of the round-1 / round-2 sweeps; a -DNSPARSE_EXPERIMENTS build keeps
+    // the alternatives behind NSPARSE_SYMD{6,7,8}_BS / NSPARSE_SYM{2,3}_BS
+#ifdef NSPARSE_EXPERIMENTS
+    static const int tune_d6 = exp_env("NSPARSE_SYMD6_BS", 128), tune_d8 = exp_env("NSPARSE_SYMD8_BS", 512);
+    static const int tune_d7 = exp_env("NSPARSE_SYMD7_BS", 256);
     if (tune_d8 == 256) { NSP_SYM_DENSE(8, 256, 65536) } else if (tune_d8 == 512) { NSP_SYM_DENSE(8, 512, 65536) } else { NSP_SYM_DENSE(8, 1024, 65536) }
-    static const int tune_d7 = getenv("NSPARSE_SYMD7_BS") ? atoi(getenv("NSPARSE_SYMD7_BS")) : 256;
     if (tune_d7 == 128) { NSP_SYM_DENSE(7, 128, 16384) } else if (tune_d7 == 256) { NSP_SYM_DENSE(7, 256, 16384) } else { NSP_SYM_DENSE(7, 512, 16384) }
     if (tune_d6 == 128) { NSP_SYM_DENSE(6, 128, 4096) } else if (tune_d6 == 64) { NSP_SYM_DENSE(6, 64, 4096) } else if (tune_d6 == 512) { NSP_SYM_DENSE(6, 512, 4096) } else { NSP_SYM_DENSE(6, 256, 4096) }
-    static const int tune_s3 = getenv("NSPARSE_SYM3_BS") ? atoi(getenv("NSPARSE_SYM3_BS")) : 512;
-    static const int tune_s2 = getenv("NSPARSE_SYM2_BS") ? atoi(getenv("NSPARSE_SYM2_BS")) : 128;
+    static const int tune_s3 = exp_env("NSPARSE_SYM3_BS", 512), tune_s2 = exp_env("NSPARSE_SYM2_BS", 128);
     NSP_SYM_TB(4, 1024, 32768)
     if (tune_s3 == 512) { NSP_SYM_TB(3, 512, 8192) } else if (tune_s3 == 1024) { NSP_SYM_TB(3, 1024, 8192) } else { NSP_SYM_TB(3, 256, 8192) }
     if (tune_s2 == 256) { NSP_SYM_TB(2, 256, 2048) } else if (tune_s2 == 64) { NSP_SYM_TB(2, 64, 2048) } else { NSP_SYM_TB(2, 128, 2048) }
-    // bin 1, NSPARSE_SYM_WAVE=n: n persistent wavefronts per CU with the next rows' loads in flight (symbolic.h:
-    // k_sym_wave).  Off by default: measured slower than one workgroup per row (stencil 3.07 -> 3.35 ms, webbase-1M
-    // class 2.36 -> 2.43), like the same pipeline in the numeric bin (k_num_wave).
-    static const int sym_wave = getenv("NSPARSE_SYM_WAVE") ? atoi(getenv("NSPARSE_SYM_WAVE")) : 0;
-    if (sym_wave > 0 && g_coop == 0 && sym_ladder().hash_t[0] > 435) {
-        if (hist[1] > 0 && now(1)) {
-            hipStream_t st = L.begin(1);
-            const int full_ = 8 * ceil_div(hist[1], 8), pers_ = 8 * ceil_div(cx.num_cus * sym_wave, 8);
-            hipLaunchKernelGGL((k_sym_wave<1024>), dim3(pers_ < full_ ? pers_ : full_), dim3(64), 0, st, arpt, acol, brpt, bcol,
-                               row_perm, row_prod, row_maxb, row_nz, off[1], hist[1], b->nnz, g_flat);
-            NSP_LAUNCH_CHECK();
-            L.end(1);
-        }
-    } else
+#else
+    NSP_SYM_DENSE(8, 512, 65536)
+    NSP_SYM_DENSE(7, 256, 16384)
+    NSP_SYM_DENSE(6, 128, 4096)
+    NSP_SYM_TB(4, 1024, 32768)
+    NSP_SYM_TB(3, 512, 8192)
+    NSP_SYM_TB(2, 128, 2048)
+#endif
+    // (bin 1 with persistent wavefronts and the next rows' loads in flight -- k_sym_wave, round 3 -- was measured
+    //  slower than one workgroup per row: stencil 3.07 -> 3.35 ms, webbase-1M class 2.36 -> 2.43; removed in round 4)
+#ifdef NSPARSE_EXPERIMENTS
     if (sym_ladder().hash_t[0] > 435) { NSP_SYM_TB(1, 64, 1024) } else { NSP_SYM_TB(1, 64, 512) }
+#else
+    NSP_SYM_TB(1, 64, 1024)
+#endif
     if (hist[0] > 0 && now(0)) {
         hipStream_t st = L.begin(0);
         constexpr int BS = 256, LPR = 4;
@@ -570,8 +574,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     constexpr int kTileW = 12288;  // LDS accumulators are double in both builds
     static const int tiled_on = !(getenv("NSPARSE_TILED") && getenv("NSPARSE_TILED")[0] == '0');
     // B rows longer than this are swept by whole wavefronts (R-MAT-16 / 18 / 22: 128 -> 32 saves 9 / 8 / 4 %)
-    static const int long_len = getenv("NSPARSE_TILED_LONG") ? atoi(getenv("NSPARSE_TILED_LONG")) : 32;
-    static const int tile_sel = getenv("NSPARSE_TILED_W") ? atoi(getenv("NSPARSE_TILED_W")) : 0;
+    static const int long_len = exp_env("NSPARSE_TILED_LONG", 32);
+    static const int tile_sel = exp_env("NSPARSE_TILED_W", 0);
     // rows with fewer than one non-zero per ranked_dens columns of their window take the ranked
     // kernel (0: none, < 0: all)
     static const int ranked_dens = getenv("NSPARSE_RANKED_DENS") ? atoi(getenv("NSPARSE_RANKED_DENS")) : 12;
@@ -579,32 +583,23 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // taking the wide rows there is no limit
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
                            (ranked_dens != 0 || (long long)b->N <= (long long)kTileW * 1024);
-    static const int tb_pad = getenv("NSPARSE_TB_PAD") ? atoi(getenv("NSPARSE_TB_PAD")) : 0;  // diagnostics: LDS padding of the numeric hash kernels
-    // NSPARSE_TB_PROF=1: in-kernel phase timers of the hash bins (thread 0 of every workgroup)
-    static const int tb_prof_on = getenv("NSPARSE_TB_PROF") ? atoi(getenv("NSPARSE_TB_PROF")) : 0;
-    unsigned long long *tb_prof = nullptr;
-    if (tb_prof_on) {
+    // -DNSPARSE_EXPERIMENTS: NSPARSE_TB_PAD / NSPARSE_BLK_PAD = extra dynamic LDS per workgroup (fewer groups in flight per
+    // CU: what bounds the kernel?), NSPARSE_TB_PROF / NSPARSE_BLK_PROF / NSPARSE_TILED_PROF = in-kernel phase timers
+    static const int tb_pad = exp_env("NSPARSE_TB_PAD", 0), blk_pad = exp_env("NSPARSE_BLK_PAD", 0);
+    unsigned long long *tb_prof = nullptr, *blk_prof = nullptr;
+#ifdef NSPARSE_EXPERIMENTS
+    if (exp_env("NSPARSE_TB_PROF", 0)) {
         tb_prof = (unsigned long long *)dev_alloc(8 * NB * sizeof(unsigned long long));
         NSP_CHECK(hipMemsetAsync(tb_prof, 0, 8 * NB * sizeof(unsigned long long), cx.stream[0]));
         NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
     }
-    // NSPARSE_TB_BUCKET=1: the big-table hash bins sort bucket by bucket (common.h: table_to_sorted) instead of
-    // compacting and running the full bitonic network.  Measured slower on power-law rows -- R-MAT-22 bins 3 / 4:
-    // 12.7 / 11.5 ms against 8.2 / 10.8 (the buckets whose index is a power of two hold hundreds of keys each and
-    // take a wavefront 5 us apiece) -- so off by default.
-    static const int tb_bucket = getenv("NSPARSE_TB_BUCKET") ? atoi(getenv("NSPARSE_TB_BUCKET")) : 0;
-    // workgroups per CU of the persistent form of the big-table hash bins (0: one workgroup per row)
-    static const int tb_persist = getenv("NSPARSE_TB_PERSIST") ? atoi(getenv("NSPARSE_TB_PERSIST")) : 0;  // measured: no gain (R-MAT-22 76.1 / 76.5 / 75.3 / 76.4 ms for 0 / 1 / 2 / 4)
-    constexpr int kBlkU = 2;  // tasks in flight per lane in the node-block kernel (of kBlkCols columns each)
-    // diagnostics: extra dynamic LDS per workgroup = fewer groups in flight per CU (what bounds the kernel?)
-    static const int blk_pad = getenv("NSPARSE_BLK_PAD") ? atoi(getenv("NSPARSE_BLK_PAD")) : 0;
-    static const int blk_prof_on = getenv("NSPARSE_BLK_PROF") ? atoi(getenv("NSPARSE_BLK_PROF")) : 0;
-    unsigned long long *blk_prof = nullptr;
-    if (blk_prof_on) {
+    if (exp_env("NSPARSE_BLK_PROF", 0)) {
         blk_prof = (unsigned long long *)dev_alloc(8 * sizeof(unsigned long long) * (size_t)(a->M + 8));
         NSP_CHECK(hipMemsetAsync(blk_prof, 0, 8 * sizeof(unsigned long long) * (size_t)(a->M + 8), cx.stream[0]));
         NSP_CHECK(hipStreamSynchronize(cx.stream[0]));
     }
+#endif
+    constexpr int kBlkU = 2;  // tasks in flight per lane in the node-block kernel (of kBlkCols columns each)
     // launch order: the heavy bin, then the bin with the most rows (main stream), then the rest
     // biggest rows first (see symbolic_phase)
     for (int pass = 0; pass < 3; pass++) {
@@ -619,19 +614,11 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         const long long stride_ints = 3LL * amax + (long long)amax * (sizeof(real) / sizeof(int));
         const int groups = rows < 1024 ? rows : 1024;
         int *slab = (int *)dev_alloc(sizeof(int) * (size_t)stride_ints * groups);
-        static const int tiled_prof = getenv("NSPARSE_TILED_PROF") ? atoi(getenv("NSPARSE_TILED_PROF")) : 0;
+        static const int tiled_prof = exp_env("NSPARSE_TILED_PROF", 0);
         unsigned long long *d_prof = nullptr;
         if (tiled_prof) {
             d_prof = (unsigned long long *)dev_alloc(32 * sizeof(unsigned long long));
             NSP_CHECK(hipMemsetAsync(d_prof, 0, 32 * sizeof(unsigned long long), st));
-        }
-        // rows with a column list from the symbolic phase (listed.h) first: most of the heavy rows of a
-        // power-law matrix; the cursor kernels below skip them
-        if (list_w > 0) {
-            hipLaunchKernelGGL((k_num_listed<1024>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval, brpt, bcol, bval,
-                               c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows, d_bs, tcol, list_off,
-                               list_w, row_prod, b->nnz, write_col);
-            NSP_LAUNCH_CHECK();
         }
 #define NSP_TILED(BSX, WX)                                                                     \
     hipLaunchKernelGGL((k_num_tiled<BSX, WX>), dim3(groups), dim3(BSX), 0, st, arpt, acol, aval, brpt, \
@@ -639,10 +626,13 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                        d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len, d_prof, ranked_dens, \
                        list_off, list_w, row_prod)
         if (ranked_dens >= 0) {
+#ifdef NSPARSE_EXPERIMENTS
             if (tile_sel == 1) { NSP_TILED(1024, kTileW / 2); }
             else if (tile_sel == 2) { NSP_TILED(512, kTileW / 2); }
             else if (tile_sel == 3) { NSP_TILED(512, kTileW / 4); }
-            else { NSP_TILED(1024, kTileW); }
+            else
+#endif
+            { NSP_TILED(1024, kTileW); }
         }
 #undef NSP_TILED
         NSP_LAUNCH_CHECK();
@@ -652,7 +642,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
             // Matrices wider than 2^20 columns take tiles of 2^19 columns with a smaller value array:
             // their thin rows are bound by the number of tiles (R-MAT-22: -5 %), while on
             // narrower matrices the smaller array costs cuts (R-MAT-18: +4 %).  NSPARSE_RANKED_SEL=0/1 forces.
-            static const int ranked_env = getenv("NSPARSE_RANKED_SEL") ? atoi(getenv("NSPARSE_RANKED_SEL")) : -1;
+            static const int ranked_env = exp_env("NSPARSE_RANKED_SEL", -1);
             const int ranked_sel = ranked_env >= 0 ? ranked_env : (b->N > (1 << 20) ? 1 : 0);
 #define NSP_RANKED(WX, CAPX, LCAPX)                                                             \
     hipLaunchKernelGGL((k_num_ranked<1024, WX, CAPX, LCAPX>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval,  \
@@ -679,29 +669,21 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         }
         L.free_later(slab);
     }
-#define NSP_NUM_TB_GO(BS, TMAX, PMAX, COOPX)                                                    \
-    do {                                                                                       \
-        /* big-table bins: a few workgroups per CU that stride over the rows (numeric.h) */     \
-        const int full_ = 8 * ceil_div(hist[bin_], 8);                                         \
-        const int pers_ = BS >= 512 ? 8 * ceil_div(cx.num_cus * tb_persist, 8) : 0;            \
-        const bool per_ = pers_ > 0 && pers_ < full_;                                          \
-        hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX, COOPX>), dim3(per_ ? pers_ : full_), dim3(BS), tb_pad, st, arpt, \
-                           acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, \
-                           row_prod, row_maxb, off[bin_], hist[bin_], b->nnz,                    \
-                           write_col | (g_flat ? 0 : 4) | (g_flat == 2 ? 8 : 0) | (per_ ? 16 : 0) | (tb_bucket ? 0 : 64), \
-                           tb_prof ? tb_prof + 8 * bin_ : nullptr);                             \
-    } while (0)
+#define NSP_NUM_TB_GO(BS, TMAX, PMAX)                                                           \
+    hipLaunchKernelGGL((k_num_tb<BS, TMAX, PMAX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), tb_pad, st, arpt, \
+                       acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm,    \
+                       row_prod, row_maxb, off[bin_], hist[bin_], b->nnz,                       \
+                       write_col | (g_flat ? 0 : 4) | (g_flat == 2 ? 8 : 0),                    \
+                       tb_prof ? tb_prof + 8 * bin_ : nullptr)
 #define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        if ((g_tb_lean & 2) && g_coop == 0 && !tb_prof)                                        \
+        if ((g_tb_lean & 2) && !tb_prof)                                                       \
             hipLaunchKernelGGL((k_num_lean<BS, TMAX, (BS >= 256 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
                                arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_prod, row_maxb, \
                                off[bin_], hist[bin_], b->nnz, write_col);                      \
-        else if (g_coop == 1) NSP_NUM_TB_GO(BS, TMAX, PMAX, 1);                                \
-        else if (g_coop == 2) NSP_NUM_TB_GO(BS, TMAX, PMAX, 2);                                \
-        else NSP_NUM_TB_GO(BS, TMAX, PMAX, 0);                                                 \
+        else NSP_NUM_TB_GO(BS, TMAX, PMAX);                                                    \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -770,9 +752,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // loads, i.e. by the groups in flight per CU, and does best with 128 threads per group (cant class:
     // 64 / 128 / 256 / 512 threads -> 0.240 / 0.197 / 0.216 / 0.41 ms); the first kernel keeps 256 / 256 / 512
     const bool blk = lean_on && (grp || blk_all);
-    static const int env_nd6 = getenv("NSPARSE_NUMD6_BS") ? atoi(getenv("NSPARSE_NUMD6_BS")) : 0;
-    static const int env_nd7 = getenv("NSPARSE_NUMD7_BS") ? atoi(getenv("NSPARSE_NUMD7_BS")) : 0;
-    static const int env_nd8 = getenv("NSPARSE_NUMD8_BS") ? atoi(getenv("NSPARSE_NUMD8_BS")) : 0;
+    static const int env_nd6 = exp_env("NSPARSE_NUMD6_BS", 0), env_nd7 = exp_env("NSPARSE_NUMD7_BS", 0),
+                     env_nd8 = exp_env("NSPARSE_NUMD8_BS", 0);
     const int tune_nd6 = env_nd6 ? env_nd6 : (blk ? 128 : 256);
     const int tune_nd7 = env_nd7 ? env_nd7 : (blk ? 128 : 256);
     const int tune_nd8 = env_nd8 ? env_nd8 : (blk ? 128 : 512);
@@ -782,8 +763,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // ramp-up less.  Measured on the irregular cant-class stand-in (42 K + 20 K rows), same box, three runs each:
     // 0.377-0.384 ms with two launches side by side, 0.393-0.402 folded.  Two kernels that overlap hide each
     // other's tails better than one.
-    static const bool fold_win = getenv("NSPARSE_FOLD_WIN") && atoi(getenv("NSPARSE_FOLD_WIN")) >= 1;
-    static const bool fold_rev = getenv("NSPARSE_FOLD_WIN") && atoi(getenv("NSPARSE_FOLD_WIN")) == 2;  // bin 7's rows first
+    static const bool fold_win = exp_env("NSPARSE_FOLD_WIN", 0) >= 1;
+    static const bool fold_rev = exp_env("NSPARSE_FOLD_WIN", 0) == 2;  // bin 7's rows first
     const bool fold6 = fold_win && blk && tune_nd7 == 128 && tune_nd6 == 128 && hist[6] > 0 && hist[7] > 0;
     // ranked-window rows (numeric bin 9): always the node-block kernel, windows up to 65536 columns
     if (hist[kRankBin] > 0 && now(kRankBin)) {
@@ -809,30 +790,30 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         NSP_LAUNCH_CHECK();
         L.end(kRankBin);
     }
-    if (tune_nd8 == 128) { NSP_NUM_DENSE(8, 128, 12288) } else if (tune_nd8 == 256) { NSP_NUM_DENSE(8, 256, 12288) } else { NSP_NUM_DENSE(8, 512, 12288) }
+    // (the node-block kernel runs 128 threads per group, the first window kernel 256 / 256 / 512)
+    if (tune_nd8 == 128) { NSP_NUM_DENSE(8, 128, 12288) }
+#ifdef NSPARSE_EXPERIMENTS
+    else if (tune_nd8 == 256) { NSP_NUM_DENSE(8, 256, 12288) }
+#endif
+    else { NSP_NUM_DENSE(8, 512, 12288) }
     if (tune_nd7 == 128) { NSP_NUM_DENSE(7, 128, 4096) } else { NSP_NUM_DENSE(7, 256, 4096) }
-    if (tune_nd6 == 128) { NSP_NUM_DENSE(6, 128, 1536) } else if (tune_nd6 == 64) { NSP_NUM_DENSE(6, 64, 1536) } else if (tune_nd6 == 512) { NSP_NUM_DENSE(6, 512, 1536) } else { NSP_NUM_DENSE(6, 256, 1536) }
-    static const int tune_n2 = getenv("NSPARSE_NUM2_BS") ? atoi(getenv("NSPARSE_NUM2_BS")) : 256;
-    static const int tune_n1 = getenv("NSPARSE_NUM1_BS") ? atoi(getenv("NSPARSE_NUM1_BS")) : 64;
+    if (tune_nd6 == 128) { NSP_NUM_DENSE(6, 128, 1536) }
+#ifdef NSPARSE_EXPERIMENTS
+    else if (tune_nd6 == 64) { NSP_NUM_DENSE(6, 64, 1536) } else if (tune_nd6 == 512) { NSP_NUM_DENSE(6, 512, 1536) }
+#endif
+    else { NSP_NUM_DENSE(6, 256, 1536) }
     NSP_NUM_TB(4, 1024, 8192, 8192)
     NSP_NUM_TB(3, 512, 4096, 4096)
+#ifdef NSPARSE_EXPERIMENTS
+    static const int tune_n2 = exp_env("NSPARSE_NUM2_BS", 256), tune_n1 = exp_env("NSPARSE_NUM1_BS", 64);
     if (tune_n2 == 128) { NSP_NUM_TB(2, 128, 1024, 1024) } else if (tune_n2 == 512) { NSP_NUM_TB(2, 512, 1024, 1024) } else { NSP_NUM_TB(2, 256, 1024, 1024) }
-    // bin 1, NSPARSE_WAVE1=n: n persistent wavefronts per CU with the next rows' loads in flight (numeric.h: k_num_wave).
-    // Off by default: measured slower (27-point stencil numeric 1.87 -> 2.58 ms): the bin is bound by instruction
-    // issue, not by its chain of round trips, and the pipeline costs registers (5 wavefronts per SIMD instead of 8).
-    static const int wave1 = getenv("NSPARSE_WAVE1") ? atoi(getenv("NSPARSE_WAVE1")) : 0;
-    if (wave1 > 0 && g_coop == 0 && !tb_prof && tune_n1 != 128) {
-        if (hist[1] > 0 && now(1)) {
-            hipStream_t st = L.begin(1);
-            const int full_ = 8 * ceil_div(hist[1], 8), pers_ = 8 * ceil_div(cx.num_cus * wave1, 8);
-            hipLaunchKernelGGL((k_num_wave<256, 256>), dim3(pers_ < full_ ? pers_ : full_), dim3(64), 0, st, arpt, acol, aval,
-                               brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_prod, row_maxb, off[1], hist[1],
-                               b->nnz, write_col);
-            NSP_LAUNCH_CHECK();
-            L.end(1);
-        }
-    } else
     if (tune_n1 == 128) { NSP_NUM_TB(1, 128, 256, 256) } else { NSP_NUM_TB(1, 64, 256, 256) }
+#else
+    NSP_NUM_TB(2, 256, 1024, 1024)
+    // (bin 1 with persistent wavefronts and the next rows' loads in flight -- k_num_wave, round 3 -- was measured
+    //  slower: 27-point stencil numeric 1.87 -> 2.58 ms; removed in round 4)
+    NSP_NUM_TB(1, 64, 256, 256)
+#endif
     if (hist[0] > 0 && now(0)) {
         hipStream_t st = L.begin(0);
         constexpr int BS = 256, LPR = 4;
@@ -889,6 +870,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         dev_free(kslab);
     }
     L.join();
+#ifdef NSPARSE_EXPERIMENTS
     if (tb_prof) {
         NSP_CHECK(hipDeviceSynchronize());
         unsigned long long h[8 * NB];
@@ -938,6 +920,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         }
         dev_free(blk_prof);
     }
+#endif
     return L;
 }
 
@@ -1280,7 +1263,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         const bool list_on = list_mode() > 0;
         const bool cursor_sym = h_sym->hist[kBitsBin0 + 1] > 0 && h_sym->max_span[kBitsBin0 + 1] > (1 << 20);  // symbolic_phase's rule
         if (list_on && h_sym->list_total > 0 && h_sym->b_unsorted == 0 &&
-            (list_mode() == 2 ? h_sym->hist[kBitsBin0] + h_sym->hist[kBitsBin0 + 1] > 0 : cursor_sym)) {
+            cursor_sym) {
             size_t free_b = 0, total_b = 0;
             const size_t want = sizeof(int) * (size_t)h_sym->list_total + sizeof(long long) * (size_t)M;
             if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && want <= free_b / 3 + (pooled ? (64u << 20) : 0u) &&
@@ -1409,14 +1392,13 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     if (b_twins_pending) NSP_CHECK(hipStreamWaitEvent(s0, cx.ev_join[kMaxBins - 1], 0));
     // ---- numeric --------------------------------------------------------------------
     // (a numeric-only re-run has the list of every row: C.col itself)
-    const bool list_rerun_on = list_mode() == 2;
     if (!too_big) {
     BinLauncher LN = numeric_phase(a, b, c, row_prod, row_maxb, row_lo, row_span, row_perm, h_num->hist,
                                    h_num->maxv, d_num, cx, S.ms_num_bin,
                                    numeric_only ? 0 : (g_sorted ? 1 : 3), bm_off, bm,
                                    (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor, members, blk_desc, bkey,
                                    numeric_only ? (list_mode() > 0 ? (const int *)c->d_col : (const int *)nullptr) : (const int *)tcol, list_off,
-                                   (numeric_only ? list_rerun_on : (tcol != nullptr && list_mode() == 2)) ? list_work() : 0LL);
+                                   0LL);
     tm.mark(3, s0);
     {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
         const int seq = ++cx.seq;

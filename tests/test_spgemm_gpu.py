@@ -487,16 +487,16 @@ def test_concurrent_callers_serialise(lib_d, oracle_d):
     assert not errs, errs
 
 
-@pytest.mark.parametrize("coop", ["1", "2"])
-def test_wave_cooperative_probe_variants(coop, lib_d, oracle_d):
-    """NSPARSE_COOP=1 / 2: the wave-cooperative probe of BASELINE's north_star (ballot over the slots
-    h .. h+63 of one key, the lane that sees the first empty slot claims it) in every LDS hash bin, with
-    the window bins off so that all rows hash.  A measured alternative, not the default (DESIGN 4.1:
-    1.2-1.8x slower as collision fallback, 4-15x as the only probe) -- but it ships, so it must be right."""
+@pytest.mark.parametrize("lean", ["0", "3"])
+def test_hash_bins_both_kernel_families(lean, lib_d, oracle_d):
+    """NSPARSE_TB_LEAN=3 / 0: the hash bins 1-4 of both phases through the lean kernels of round 4 (lean.h: owner-array
+    product walk, 24-bit multiplicative hash, in-register sort of one-wavefront rows) and through round 3's k_sym_tb /
+    k_num_tb, with the window bins off so that all rows hash: stencil, R-MAT and web-graph rows.  Both ship (one is
+    the default, the other the switch), so both must be right."""
     for kind, p in ((1, (20, 20, 20)), (3, (12, 8, 0)), (4, (30000, 95000, 0))):
         A = synth(lib_d, kind, *p, seed=0x5EED0022)
         ref = oracle_d.spgemm(A, A)
-        got, st = spgemm_subprocess(A, {"NSPARSE_COOP": coop, "NSPARSE_DENSE": "0"})
+        got, st = spgemm_subprocess(A, {"NSPARSE_TB_LEAN": lean, "NSPARSE_DENSE": "0"})
         assert sum(st["sym"][6:]) == 0 and sum(st["num"][6:]) == 0
         assert_parity(oracle_d, got, ref)
 
@@ -670,14 +670,12 @@ def test_non_finite_values_stay_in_their_columns(kind, dims, oracle_d):
     np.testing.assert_allclose(got["val"][ok], ref["val"][ok], rtol=1e-9)
 
 
-@pytest.mark.parametrize("bucket", ["0", "1"])
-def test_bucket_sort_of_the_big_table_bins(bucket, oracle_d):
-    """Rows of the two big-table numeric bins (683 .. 5461 non-zeros): NSPARSE_TB_BUCKET=1 sorts them bucket by
-    bucket (common.h: table_to_sorted; measured slower than the bitonic network on power-law rows, so off by default):
-    buckets of <= 64 keys by counting, <= 128 and <= 512 by the register networks, anything beyond falls back to the
-    full bitonic sort.  B is a diagonal matrix, so a row of C has exactly the columns of its
-    row of A: every path is hit by construction -- a uniform row, rows with 100 / 400 consecutive columns inside one
-    bucket, and a cluster of 3,000 columns plus one far outlier (one bucket holds nearly everything)."""
+@pytest.mark.parametrize("lean", ["0", "3"])
+def test_big_table_bins_on_clustered_columns(lean, oracle_d):
+    """Rows of the two big-table numeric bins (683 .. 5461 non-zeros) through both kernel families (NSPARSE_TB_LEAN).
+    B is a diagonal matrix, so a row of C has exactly the columns of its row of A and every A entry reaches a
+    one-entry row of B (the DIRECT rounds of the lean walk): a uniform row, rows with 100 / 400 consecutive columns
+    (probe clusters of a multiplicative hash), and a cluster of 3,000 consecutive columns plus one far outlier."""
     lib = ns.load("d")
     N = 1 << 20
     rng = np.random.default_rng(17)
@@ -691,25 +689,23 @@ def test_bucket_sort_of_the_big_table_bins(bucket, oracle_d):
     rpt = np.concatenate([[0], np.cumsum([len(r) for r in rows])]).astype(np.int32)
     A = dict(M=len(rows), N=N, rpt=rpt, col=np.concatenate(rows).astype(np.int32), val=rng.random(int(rpt[-1])) + 0.5)
     B = dict(M=N, N=N, rpt=np.arange(N + 1, dtype=np.int32), col=np.arange(N, dtype=np.int32), val=rng.random(N) + 0.5)
-    got, st = spgemm_subprocess(A, {"NSPARSE_TB_BUCKET": bucket}, "d", B=B)
+    got, st = spgemm_subprocess(A, {"NSPARSE_TB_LEAN": lean}, "d", B=B)
     ref = oracle_d.spgemm(A, B)
     assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
     assert oracle_d.check_spgemm(got, ref) == 0
     assert st["num"][3] + st["num"][4] == len(rows), st["num"][:8]
 
 
-@pytest.mark.parametrize("waves", ["32", "3"])
-def test_persistent_wavefront_bin(waves, oracle_d):
-    """NSPARSE_WAVE1=n: the rows of numeric bin 1 (17 .. 170 non-zeros) through k_num_wave -- persistent wavefronts
-    that request the next rows' words, A entries and B extents while they hash the current row (numeric.h; measured
-    slower than one workgroup per row, so off by default).  NSPARSE_SYM_WAVE=n: the same pipeline in symbolic bin 1
-    (symbolic.h: k_sym_wave, the default there with 32 wavefronts per CU).  A 27-point stencil (every row in that bin) with a hub row
-    of B spliced in, so that the parked-row path runs too; 3 wavefronts per CU makes every wavefront take many rows
-    and two batches of row numbers."""
+@pytest.mark.parametrize("lean", ["0", "3"])
+def test_one_wavefront_bin(lean, oracle_d):
+    """The rows of numeric bin 1 (17 .. 170 non-zeros) and symbolic bin 1 through both kernel families
+    (NSPARSE_TB_LEAN): a 27-point stencil (every row in those bins; the lean walk spreads the 189 chunks of a row
+    over three rounds through its owner array, the sort of <= 128 keys runs in registers), then short rows of A
+    that meet a B with 5 % hub rows of 120 entries (owner windows that a long row straddles, partial chunks)."""
     lib = ns.load("d")
     A = synth(lib, 1, 70, 70, 12, seed=5)  # 58,800 rows, windows of 20 K columns: beyond the dense-window bins
     rng = np.random.default_rng(3)
-    got, st = spgemm_subprocess(A, {"NSPARSE_WAVE1": waves, "NSPARSE_SYM_WAVE": waves}, "d")
+    got, st = spgemm_subprocess(A, {"NSPARSE_TB_LEAN": lean}, "d")
     ref = oracle_d.spgemm(A, A)
     assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
     assert oracle_d.check_spgemm(got, ref) == 0
@@ -724,7 +720,7 @@ def test_persistent_wavefront_bin(waves, oracle_d):
     colsB = [np.sort(rng.choice(m, k, replace=False)) for k in lensB]
     rptB = np.concatenate([[0], np.cumsum(lensB)]).astype(np.int32)
     B2 = dict(M=m, N=m, rpt=rptB, col=np.concatenate(colsB).astype(np.int32), val=rng.random(int(rptB[-1])) + 0.5)
-    got, st = spgemm_subprocess(A2, {"NSPARSE_WAVE1": waves, "NSPARSE_SYM_WAVE": waves}, "d", B=B2)
+    got, st = spgemm_subprocess(A2, {"NSPARSE_TB_LEAN": lean}, "d", B=B2)
     ref = oracle_d.spgemm(A2, B2)
     assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
     assert oracle_d.check_spgemm(got, ref) == 0
