@@ -847,25 +847,23 @@ def main():
     # ----------------------------------------------------------- CPU baseline ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
+        # OpenMP placement is read when the runtime starts: one thread per core, spread over the sockets
+        os.environ.setdefault("OMP_PROC_BIND", "spread")
+        os.environ.setdefault("OMP_PLACES", "cores")
         from oracle.oracle import Oracle  # checker / baseline leg only
         orc = Oracle("d")
         cores = os.cpu_count() or 1
-        t = time.perf_counter()
-        ref = orc.spgemm(A_loc, A_full)
-        t1 = time.perf_counter() - t
-        # a bounded sample of about 10 s of single-core work: the same product repeated
-        n1 = 1
+        # a bounded sample of single-core work: the whole product, repeated until about 10 s have gone by
+        ref, t1, _, _ = orc.spgemm_omp_timed(A_loc, A_full, reps=1, threads=1)
+        n1 = int(min(12, max(1, round(10.0 / max(t1, 1e-3))))) if t1 < 5.0 else 0
         t_all = t1
-        while t_all < 10.0 and n1 < 40:
-            t = time.perf_counter()
-            orc.spgemm(A_loc, A_full)
-            t_all += time.perf_counter() - t
-            n1 += 1
-        t1 = t_all / n1
-        t = time.perf_counter()
-        orc.spgemm_omp(A_loc, A_full)
-        tn = time.perf_counter() - t
+        if n1:
+            _, tb, tm, _ = orc.spgemm_omp_timed(A_loc, A_full, reps=n1, threads=1)
+            t_all += tm * n1
+            t1 = min(t1, tb)
+        ref_n, tn, tn_mean, nth = orc.spgemm_omp_timed(A_loc, A_full, reps=5, threads=0)
         assert ref["nnz"] == nnz_c and np.array_equal(ref["rpt"], crpt), "GPU structure != oracle"
+        assert np.array_equal(ref_n["rpt"], crpt) and np.array_equal(ref_n["col"], ref["col"]), "all-cores oracle != 1-core oracle"
         xs = np.random.default_rng(1).random(A_full["N"])
         reps = 20
         orc.csr_spmv(A_loc["rpt"], A_loc["col"], A_loc["val"], xs)
@@ -880,9 +878,13 @@ def main():
         b_csr = nnz_a * (w + 4) + 4 * (a.M + 1) + A_full["N"] * w + a.M * w
         cpu = {
             "value": round(flop.value / t1 / 1e9, 3), "unit": "GFLOPS", "cores": 1, "kind": "port",
-            "sample": f"whole {src} matrix, C=A^2 {n1} times ({t_all:.1f} s), oracle/nsparse_oracle.c "
-                      "(the reference has no CPU SpGEMM)",
-            "all_cores": {"value": round(flop.value / tn / 1e9, 3), "cores": cores},
+            "sample": f"whole {src} matrix, C=A^2 {n1 + 1} times on one core ({t_all:.1f} s, best time), oracle/nsparse_oracle.c: "
+                      "orc_spgemm_omp_timed -- marker-array symbolic + numeric, ascending window sweep instead of a sort for "
+                      "narrow rows (the reference has no CPU SpGEMM)",
+            "all_cores": {"value": round(flop.value / tn / 1e9, 3), "cores": int(nth), "host_cpus": cores,
+                          "speedup_over_one_core": round(t1 / tn, 1), "mean_value": round(flop.value / tn_mean / 1e9, 3),
+                          "how": "the same function on all host cores: rows in dynamic chunks of M / (8 threads), threads "
+                                 "bound to cores (OMP_PROC_BIND=spread, OMP_PLACES=cores), 5 repetitions after a warm-up, best"},
             "spmv": {"value": round(b_csr / ts1 / 1e9, 2), "unit": "GB/s", "cores": 1,
                      "kind": "port", "sample": f"{reps} x csr_kernel loop order (nsparse.cu:240-259) on {src}",
                      "all_cores": {"value": round(b_csr / tsn / 1e9, 2), "cores": cores}},

@@ -228,6 +228,19 @@ void nsparse_spgemm_hash_numeric(sfCSR *a, sfCSR *b, sfCSR *c);
  * each row are unchanged.  Numeric-only re-runs need the sorted structure.  Returns the old value. */
 int nsparse_spgemm_set_sorted(int on);
 
+/* 1: C.val of every later spgemm_kernel_hash / nsparse_spgemm_hash_numeric is summed in ONE FIXED ORDER -- per entry
+ * of C, the products in the order of the A entries of its row -- so two runs on the same inputs give the same bytes
+ * (the default accumulates with LDS atomics in whatever order the lanes arrive, like the reference:
+ * kernel_spgemm_hash_d.cu:829-927, README "relies on warp lock-step").  A debugging aid (hard part 1): the
+ * values are recomputed by a second pass over the finished structure, one binary search per (A entry, C entry).
+ * Returns the previous setting.                                                                                */
+int nsparse_set_deterministic(int on);
+
+/* 1 when roctx ranges are being emitted around the phases of the calls ("nsparse:spgemm" > setup / symbolic /
+ * numeric, "nsparse:csr2amb", "nsparse:spmv_amb"): a profiler is in the process (rocprofv3 --marker-trace) or
+ * NSPARSE_ROCTX=1.  The marker library is dlopen'ed then; the product library never links it.               */
+int nsparse_trace_ranges(void);
+
 /* Statistics of the last spgemm_kernel_hash call. */
 typedef struct {
     long long n_prod;         /* intermediate products                              */

@@ -101,6 +101,22 @@ int nsparse_dist_close_gaps(real *d_y, const real *d_staged, const int *d_cuts, 
  * stream, *us_host = host time per SpMV spent enqueueing (no wait included).  Any may be NULL. */
 int nsparse_dist_spmv_loop(nsparse_dist_t h, real *d_y, const real *d_x, int gather, int iters,
                            double *ms_wall, double *ms_events, double *us_host);
+/* ---- SpGEMM by 1-D row blocks (stretch row) ---------------------------------------
+ * C[rows of rank r, :] = A[rows of rank r, :] * B, B whole on every rank, no collective inside the
+ * algorithm.  work[i] = intermediate products of row i of A * B from the HOST arrays (what the
+ * reference's set_intprod_num counts, kernel_spgemm_hash_d.cu:70-86): feed it to
+ * nsparse_dist_partition_work for product-balanced cuts.                                        */
+int nsparse_dist_spgemm_row_work(const sfCSR *a_host, const sfCSR *b_host, long long *work);
+/* This rank's block: a_block (its rows of A; nsparse_dist_csr_row_block + csr_memcpy) and b with
+ * device arrays valid -> c_block, device arrays only (release_csr), exactly spgemm_kernel_hash on
+ * the block.  0, or the product library's error code.                                            */
+int nsparse_dist_spgemm(nsparse_dist_t h, sfCSR *a_block, sfCSR *b, sfCSR *c_block);
+/* The whole C on every rank: block sizes by one all-reduce, then every rank's rpt / col / val
+ * stretch broadcast straight to its place (no padding).  c_full: device arrays only, release with
+ * nsparse_dist_release_gathered.  Collective; -40 when nnz(C) does not fit int.                  */
+int nsparse_dist_spgemm_gather(nsparse_dist_t h, const int *cuts, const sfCSR *c_block, sfCSR *c_full);
+void nsparse_dist_release_gathered(sfCSR c_full);
+
 /* The rank's AMB matrix and plan (footprint model, tests); owned by the handle.                 */
 const sfAMB *nsparse_dist_amb(nsparse_dist_t h);
 const sfPlan *nsparse_dist_plan(nsparse_dist_t h);

@@ -82,6 +82,8 @@ SIGNATURES = {
     "nsparse_spgemm_hash_numeric": (None, [_P(sfCSR), _P(sfCSR), _P(sfCSR)]),
     "nsparse_get_spgemm_stats": (None, [_P(SpgemmStats)]),
     "nsparse_spgemm_set_sorted": (C.c_int, [C.c_int]),
+    "nsparse_set_deterministic": (C.c_int, [C.c_int]),
+    "nsparse_trace_ranges": (C.c_int, []),
     "nsparse_get_spgemm_bins": (None, [c_int_p, c_int_p]),
     "nsparse_fused_state": (C.c_int, [c_int_p, c_int_p]),
     "nsparse_set_profiling": (None, [C.c_int]),
@@ -135,6 +137,10 @@ DIST_SIGNATURES = {
     "nsparse_dist_barrier": (C.c_int, [C.c_void_p]),
     "nsparse_dist_allreduce_f64": (C.c_int, [C.c_void_p, c_double_p, C.c_int, C.c_int]),
     "nsparse_dist_release_matrix": (C.c_int, [C.c_void_p]),
+    "nsparse_dist_spgemm_row_work": (C.c_int, [_P(sfCSR), _P(sfCSR), C.POINTER(C.c_longlong)]),
+    "nsparse_dist_spgemm": (C.c_int, [C.c_void_p, _P(sfCSR), _P(sfCSR), _P(sfCSR)]),
+    "nsparse_dist_spgemm_gather": (C.c_int, [C.c_void_p, c_int_p, _P(sfCSR), _P(sfCSR)]),
+    "nsparse_dist_release_gathered": (None, [sfCSR]),
 }
 DIST_ID_BYTES = 128
 

@@ -538,6 +538,8 @@ static float tune_thread_block(sfAMB *mat, real *d_x, real *d_y, sfPlan *plan, i
 static void convert(sfAMB *mat, sfCSR *csr_in, real *d_x, sfPlan *plan)
 {
     ApiLock api_lock;
+    CallScope call_scope;
+    TraceRange range("nsparse:csr2amb");
     clear_error();
     Context &cx = ctx();
     // nnz_max sizes the sort keys: a value outside (0, N] (a caller-built sfCSR) means unknown

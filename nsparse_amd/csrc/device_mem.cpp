@@ -4,12 +4,15 @@
 // Replaces (reference file:line):
 //   csr_memcpy / csr_memcpyDtH     cuda-c/src/nsparse.cu:146-168
 //   release_csr / release_amb      cuda-c/src/nsparse.cu:209-235
+#include <dlfcn.h>
+
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "internal.h"
 
@@ -32,6 +35,9 @@ struct Cache {
     std::unordered_map<void *, Live> live;               // blocks handed out
     std::multimap<size_t, void *> idle[kMaxDevices];     // blocks waiting for reuse
     size_t idle_bytes = 0;
+    // stream-ordered blocks released while a call is in flight (CallScope): their hipFreeAsync goes to the null
+    // stream, which is not ordered against the call's non-blocking streams, so it waits for the end of the call
+    std::vector<std::pair<void *, int>> deferred;
     std::mutex mu;
 };
 Cache &cache()
@@ -39,16 +45,28 @@ Cache &cache()
     static Cache c;
     return c;
 }
+// -1: the current device is beyond the library's per-device tables.  Never aliased to device 0 (its streams and
+// scratch live there): dev_alloc refuses, ctx() cannot continue.
 int current_device()
 {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess) d = 0;
     if (d < 0 || d >= kMaxDevices) {
-        // never alias a foreign device to context 0 (its streams and scratch live on device 0)
         set_error(-50, "device id beyond the library's per-device tables (128)", __FILE__, __LINE__);
-        return 0;
+        return -1;
     }
     return d;
+}
+thread_local int t_call_depth = 0;  // > 0: inside a public call that has kernels in flight (CallScope)
+
+// hipFreeAsync on the null stream OF THE DEVICE THE BLOCK CAME FROM (the caller may have another one current)
+void free_async_on(void *p, int dev)
+{
+    int cur = 0;
+    const bool sw = hipGetDevice(&cur) == hipSuccess && cur != dev;
+    if (sw) (void)hipSetDevice(dev);
+    NSP_CHECK(hipFreeAsync(p, 0));
+    if (sw) (void)hipSetDevice(cur);
 }
 void trim_locked(Cache &c)
 {
@@ -72,6 +90,7 @@ void *dev_alloc(size_t bytes)
     Cache &c = cache();
     const size_t want = round_size(bytes);
     const int dev = current_device();
+    if (dev < 0) return nullptr;  // (error -50 is set)
     std::lock_guard<std::mutex> lk(c.mu);
     if (c.enabled) {
         auto &idle = c.idle[dev];
@@ -121,8 +140,10 @@ void dev_free(void *p)
         auto it = c.live.find(p);
         if (it != c.live.end()) {
             if (it->second.async) {
+                const int dev = it->second.dev;
                 c.live.erase(it);
-                NSP_CHECK(hipFreeAsync(p, 0));
+                if (t_call_depth > 0) c.deferred.emplace_back(p, dev);  // kernels of this call may still use it
+                else free_async_on(p, dev);
                 return;
             }
             if (c.enabled) {
@@ -160,6 +181,23 @@ void dev_cache_async(bool on)
     c.async = on;
 }
 
+CallScope::CallScope() { ++t_call_depth; }
+CallScope::~CallScope()
+{
+    if (--t_call_depth > 0) return;
+    Cache &c = cache();
+    std::vector<std::pair<void *, int>> todo;
+    {
+        std::lock_guard<std::mutex> lk(c.mu);
+        todo.swap(c.deferred);
+    }
+    if (todo.empty()) return;
+    // the public calls are synchronous on return, so the device is idle here; the wait costs nothing then and
+    // makes the order explicit for a caller-supplied future path that is not
+    (void)hipDeviceSynchronize();
+    for (auto &pd : todo) free_async_on(pd.first, pd.second);
+}
+
 void dev_cache_trim()
 {
     Cache &c = cache();
@@ -192,11 +230,23 @@ void wait_published(int slot, int seq, hipStream_t st)
 // One context per device, created on first use with that device current: streams, events and the
 // counter / flag blocks belong to the device the caller selected with hipSetDevice (the reference
 // builds its sfBIN and streams inside every call, so it follows the current device as well).
+namespace {
+Context g_per_dev[kMaxDevices];
+}
+static bool ctx_peek(int d) { return g_per_dev[d].ready; }
+
 Context &ctx()
 {
-    static Context per_dev[kMaxDevices];
+    Context *per_dev = g_per_dev;
     static std::mutex mu;
-    Context &c = per_dev[current_device()];
+    const int dev = current_device();
+    if (dev < 0) {
+        // nothing sensible can run without streams and counters of ITS device: this is fatal whatever
+        // NSPARSE_NO_ABORT says (the error word and a message were set by current_device)
+        fprintf(stderr, "nsparse: device beyond the per-device tables (%d): cannot continue\n", kMaxDevices);
+        abort();
+    }
+    Context &c = per_dev[dev];
     std::lock_guard<std::mutex> lk(mu);
     if (!c.ready) {
         // the streams of the big-LDS bins (hash bin 4, heavy bin 5, bit-window bin 10) get the highest
@@ -231,9 +281,66 @@ Context &ctx()
     return c;
 }
 
+bool ctx_ready()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) return false;
+    // (reads a flag of the table ctx() owns: a context that is being created right now counts as "not yet")
+    return ctx_peek(d);
+}
+
+// ---- roctx ranges (tracing) ------------------------------------------------------------------
+// rocprofv3 --marker-trace shows them around the phases of a call, so a kernel trace explains itself.  The
+// marker library is looked up at run time (librocprofiler-sdk-roctx, else the older libroctx64): the product
+// library does not link it, and without a profiler in the process (NSPARSE_ROCTX=1 forces, =0 forbids) nothing
+// is loaded and a range is two predictable branches.
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        const char *e = getenv("NSPARSE_ROCTX");
+        if (e && atoi(e) == 0) return;
+        const char *pre = getenv("LD_PRELOAD");
+        const bool profiled = getenv("ROCP_TOOL_LIBRARIES") || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") ||
+                              (pre && strstr(pre, "rocprofiler")) || (e && atoi(e) == 1);
+        if (!profiled) return;
+        void *h = dlopen("librocprofiler-sdk-roctx.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("libroctx64.so.4", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (!push || !pop) push = nullptr, pop = nullptr;
+    }
+};
+const Roctx &roctx()
+{
+    static Roctx r;
+    return r;
+}
+}  // namespace
+TraceRange::TraceRange(const char *name) : on(roctx().push != nullptr)
+{
+    if (on) roctx().push(name);
+}
+TraceRange::~TraceRange()
+{
+    if (on) roctx().pop();
+}
+void TraceRange::next(const char *name)
+{
+    if (!on) return;
+    roctx().pop();
+    roctx().push(name);
+}
+bool trace_ranges_on() { return roctx().push != nullptr; }
+
 }  // namespace nsp
 
 extern "C" {
+
+int nsparse_trace_ranges(void) { return nsp::trace_ranges_on() ? 1 : 0; }
 
 void nsparse_set_workspace_cache(int on)
 {

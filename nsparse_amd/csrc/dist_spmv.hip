@@ -559,6 +559,115 @@ int nsparse_dist_spmv_loop(nsparse_dist_t h, real *d_y, const real *d_x, int gat
     return 0;
 }
 
+// ---- row-partitioned SpGEMM (stretch row; round 4: native) ------------------------------------------
+// C[rows of rank r, :] = A[rows of rank r, :] * B with B whole on every rank: the single-GPU call on a row block (an
+// A with fewer rows than B takes the library's column-range set-up), NO collective inside the algorithm.  What is
+// new here is the partition (by intermediate products, what the reference's set_intprod_num counts,
+// kernel_spgemm_hash_d.cu:70-86) and the optional assembly of the whole C on every rank.
+int nsparse_dist_spgemm_row_work(const sfCSR *a, const sfCSR *b, long long *work)
+{
+    if (!a || !b || !work || !a->rpt || !a->col || !b->rpt) return g_err = -1;
+    for (int i = 0; i < a->M; i++) {
+        long long w = 0;
+        for (int j = a->rpt[i]; j < a->rpt[i + 1]; j++) {
+            const int k = a->col[j];
+            if (k < 0 || k >= b->M) return g_err = -2;
+            w += b->rpt[k + 1] - b->rpt[k];
+        }
+        work[i] = w;
+    }
+    return 0;
+}
+
+int nsparse_dist_spgemm(nsparse_dist_t h, sfCSR *a_block, sfCSR *b, sfCSR *c_block)
+{
+    g_err = 0;
+    if (!h || !a_block || !b || !c_block) return g_err = -1;
+    const int before = nsparse_last_error();
+    spgemm_kernel_hash(a_block, b, c_block);  // synchronous; an empty block gives an empty C of a_block->M rows
+    const int after = nsparse_last_error();
+    return (after != 0 && after != before) ? (g_err = after) : 0;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void k_shift_rpt(int *__restrict__ rpt, int n, int add)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) rpt[i] += add;
+}
+}  // namespace
+
+// The whole C on every rank (device arrays from hipMalloc: release with nsparse_dist_release_gathered).  One
+// all-reduce of the block sizes, then per rank one broadcast each of its rpt / col / val stretch straight to its
+// place in the full arrays (world broadcasts of 3 messages: no padding, no staging copy; xGMI is point to point, a
+// broadcast from r is r's stretch once over every link).  cuts: the world + 1 row cuts of the partition.
+int nsparse_dist_spgemm_gather(nsparse_dist_t h, const int *cuts, const sfCSR *c_block, sfCSR *c_full)
+{
+    g_err = 0;
+    if (!h || !cuts || !c_block || !c_full) return g_err = -1;
+    const int world = h->world, rank = h->rank;
+    if (world > kReduceMax) return g_err = -1;
+    if (c_block->M != cuts[rank + 1] - cuts[rank]) return g_err = -2;
+    double sizes[kReduceMax] = {};
+    sizes[rank] = (double)c_block->nnz;
+    if (world > 1) {
+        if (!h->comm) return g_err = -4;
+        const int rc = nsparse_dist_allreduce_f64(h, sizes, world, 0);
+        if (rc) return rc;
+    }
+    long long total = 0;
+    std::vector<long long> off((size_t)world + 1, 0);
+    for (int r = 0; r < world; r++) {
+        off[r] = total;
+        total += (long long)sizes[r];
+    }
+    off[world] = total;
+    if (total > 0x7fffffffLL) return g_err = -40;  // sfCSR keeps nnz and rpt in int (as the single-GPU call refuses)
+    const int M = cuts[world];
+    memset(c_full, 0, sizeof(*c_full));
+    c_full->M = M;
+    c_full->N = c_block->N;
+    c_full->nnz = (int)total;
+    c_full->nnz_max = c_block->nnz_max;  // (a hint: the longest row of THIS rank's block)
+    D_HIP(hipMalloc((void **)&c_full->d_rpt, sizeof(int) * ((size_t)M + 1)));
+    D_HIP(hipMalloc((void **)&c_full->d_col, sizeof(int) * (size_t)(total > 0 ? total : 1)));
+    D_HIP(hipMalloc((void **)&c_full->d_val, sizeof(real) * (size_t)(total > 0 ? total : 1)));
+    hipStream_t st = h->stream;
+    for (int r = 0; r < world; r++) {
+        const int m = cuts[r + 1] - cuts[r];
+        const long long z = (long long)sizes[r];
+        int *rpt_dst = c_full->d_rpt + cuts[r];
+        if (world > 1) {
+            // rows of rank r: its m row starts (the end of the last row is the start of the next block's first)
+            if (m > 0) D_NCCL(ncclBroadcast(c_block->d_rpt, rpt_dst, (size_t)m, ncclInt, r, h->comm, st));
+            if (z > 0) {
+                D_NCCL(ncclBroadcast(c_block->d_col, c_full->d_col + off[r], (size_t)z, ncclInt, r, h->comm, st));
+                D_NCCL(ncclBroadcast(c_block->d_val, c_full->d_val + off[r], (size_t)z, kNcclReal, r, h->comm, st));
+            }
+        } else {
+            if (m > 0) D_HIP(hipMemcpyAsync(rpt_dst, c_block->d_rpt, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, st));
+            if (z > 0) {
+                D_HIP(hipMemcpyAsync(c_full->d_col, c_block->d_col, sizeof(int) * (size_t)z, hipMemcpyDeviceToDevice, st));
+                D_HIP(hipMemcpyAsync(c_full->d_val, c_block->d_val, sizeof(real) * (size_t)z, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        if (m > 0 && off[r] > 0) {
+            hipLaunchKernelGGL(k_shift_rpt, dim3((m + 255) / 256), dim3(256), 0, st, rpt_dst, m, (int)off[r]);
+            D_HIP(hipGetLastError());
+        }
+    }
+    const int last = (int)total;
+    D_HIP(hipMemcpyAsync(c_full->d_rpt + M, &last, sizeof(int), hipMemcpyHostToDevice, st));
+    return sync_watch(h);
+}
+
+void nsparse_dist_release_gathered(sfCSR c_full)
+{
+    if (c_full.d_rpt) (void)hipFree(c_full.d_rpt);
+    if (c_full.d_col) (void)hipFree(c_full.d_col);
+    if (c_full.d_val) (void)hipFree(c_full.d_val);
+}
+
 const sfAMB *nsparse_dist_amb(nsparse_dist_t h) { return &h->amb; }
 const sfPlan *nsparse_dist_plan(nsparse_dist_t h) { return &h->plan; }
 void *nsparse_dist_stream(nsparse_dist_t h) { return (void *)h->stream; }

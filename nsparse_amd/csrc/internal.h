@@ -38,6 +38,21 @@ void dev_cache_enable(bool on);
 void dev_cache_async(bool on);
 bool dev_cache_enabled();
 void dev_cache_trim();
+// RAII around a public call that queues kernels on the context's (non-blocking) streams: stream-ordered blocks
+// (nsparse_set_workspace_cache(2)) released inside it are freed when the call has ended, not under its kernels.
+struct CallScope {
+    CallScope();
+    ~CallScope();
+};
+
+// ---- tracing: roctx ranges around the phases of a call (no-ops unless a profiler is in the process) ----
+struct TraceRange {
+    bool on;
+    explicit TraceRange(const char *name);
+    ~TraceRange();
+    void next(const char *name);  // close the current range, open the next one
+};
+bool trace_ranges_on();
 
 // ---- threading ---------------------------------------------------------------------
 // The reference is not thread-safe (global `memory_access`, default stream).  Here every
@@ -74,6 +89,7 @@ struct Context {
     bool ready = false;
 };
 Context &ctx();
+bool ctx_ready();  // the current device has a context already (a query must not create one)
 
 // Block until the GPU has stored `seq` at h_mapped[slot] (see k_publish); falls back to a stream
 // synchronisation after a generous timeout.

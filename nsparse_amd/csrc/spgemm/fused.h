@@ -42,35 +42,46 @@ __device__ __forceinline__ int ld_agent(const int *p)
 }
 
 // Every workgroup of the grid has arrived.  The launch is an ordinary one, so that all workgroups are resident
-// at once is something the HOST has made sure of (Context::coresident: a census at context creation with this
-// block size, under whatever CU mask or partition the process runs in) -- but CUs can still be taken by another
-// tenant between the census and the call.  So the wait is bounded (~50 ms): a workgroup that gives up raises
-// fail_flag AND the publish flag, every workgroup (also one that only starts later) leaves without touching
-// anything behind the barrier, and the host repeats the call with the kernel chains (round 2 trapped here,
-// which poisons the process's HIP context).  Returns false when the barrier failed.
+// at once is something the HOST has made sure of (Context::coresident: a census at context creation with one
+// workgroup per CU, under whatever CU mask or partition the process runs in) -- but CUs can still be taken by
+// another tenant between the census and the call.  So the wait is bounded (50 ms of the 100 MHz wall clock) and its
+// OUTCOME IS ONE AGREED WORD, arrive[1]: 0 open, 1 passed, 2 failed.  Only the last workgroup to arrive can move
+// it from open to passed, only a workgroup whose wait has run out from open to failed, both with a
+// compare-and-swap, and every workgroup -- also one that only starts later -- acts on what it then READS there.
+// (Round 3 let every workgroup decide for itself: a last arrival inside the window between another workgroup's
+// final look at the counter and its "gave up" store could run the tail while that workgroup skipped its rows.)
+// On failure nothing behind the barrier is touched and the host repeats the call with the kernel chains (round 2
+// trapped here, which poisons the process's HIP context).  Returns false when the barrier failed.
 __device__ __forceinline__ bool grid_barrier(const FusedSync &fs, int *s_ok)
 {
     __syncthreads();
     if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(fs.arrive, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        int *state = fs.arrive + 1;
         const int target = (int)gridDim.x;
-        unsigned int spins = 0;
-        bool ok = true;
-        while (__hip_atomic_load(fs.arrive, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 20) || __hip_atomic_load(fs.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                ok = false;
-                break;
+        const int mine = __hip_atomic_fetch_add(fs.arrive, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1;
+        int st;
+        if (mine == target) {
+            int open = 0;
+            __hip_atomic_compare_exchange_strong(state, &open, 1, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            st = __hip_atomic_load(state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            const unsigned long long t0 = wall_clock64();
+            while ((st = __hip_atomic_load(state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (wall_clock64() - t0 > 5000000ull) {  // 50 ms
+                    int open = 0;
+                    __hip_atomic_compare_exchange_strong(state, &open, 2, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    st = __hip_atomic_load(state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
         }
-        if (ok && __hip_atomic_load(fs.arrive + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = false;
-        if (!ok) {
-            __hip_atomic_store(fs.arrive + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st != 1) {  // (every failing workgroup says so: the stores are idempotent)
             __hip_atomic_store(fs.fail_flag, fs.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __threadfence_system();
             __hip_atomic_store(fs.pub_flag, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        *s_ok = ok ? 1 : 0;
+        *s_ok = st == 1 ? 1 : 0;
     }
     __syncthreads();
     return *s_ok != 0;
@@ -79,8 +90,14 @@ __device__ __forceinline__ bool grid_barrier(const FusedSync &fs, int *s_ok)
 // Census for the grid barrier: `grid` workgroups of 1024 threads; every one waits (bounded: ~0.2 ms) until all
 // have arrived and reports whether it saw that happen.  out[0] counts arrivals, out[1] the workgroups that
 // timed out: 0 means `grid` such workgroups are resident together on this device as this process sees it.
+// Launched with kCensusLds bytes of dynamic LDS -- more than half a CU's -- so that the census counts CUs (one
+// workgroup each) and not how many of ITS featherweight workgroups fit a CU: the fused kernels are register-heavy
+// 1024-thread workgroups of which a CU may hold just one.
+constexpr int kCensusLds = 96 * 1024;
 __global__ __launch_bounds__(1024) void k_census(int *out, int limit_ticks)
 {
+    extern __shared__ int s_census_pad[];
+    if (threadIdx.x == 1023 && limit_ticks < 0) s_census_pad[0] = 0;  // (keeps the allocation alive)
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(out, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned long long t0 = wall_clock64();

@@ -318,5 +318,50 @@ __global__ __launch_bounds__(BS) void k_num_global(const int *__restrict__ arpt,
     }
 }
 
+// nsparse_set_deterministic(1): the values of a finished structure once more, in ONE order.  One wavefront per row of
+// C; lane l owns the entries l, l + 64, ... of the row and walks the A entries of the row in their stored order
+// (every lane the same entry: broadcast loads), looking its column up in the B row -- by bisection when the rows of B
+// ascend, else by a scan.  sum += a * b in that order: the result does not depend on scheduling, atomics or the bin a
+// row went through.  The float build multiplies in float and sums in double like the accumulating kernels.
+__global__ __launch_bounds__(256) void k_num_deterministic(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                           const real *__restrict__ aval, const int *__restrict__ brpt,
+                                                           const int *__restrict__ bcol, const real *__restrict__ bval,
+                                                           const int *__restrict__ crpt, const int *__restrict__ ccol,
+                                                           real *__restrict__ cval, int M, int b_sorted)
+{
+#pragma clang fp contract(off)  // multiply, round, add, round: what a sequential CPU loop without FMA computes
+    const int row = (int)((blockIdx.x * 256u + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const int c0 = crpt[row], c1 = crpt[row + 1];
+    const int a0 = arpt[row], a1 = arpt[row + 1];
+    for (int p0 = c0; p0 < c1; p0 += 64) {
+        const int p = p0 + lane;
+        const int col = p < c1 ? ccol[p] : -1;
+        acc_t sum = 0;
+        for (int j = a0; j < a1; j++) {
+            const int k = acol[j];
+            const real av = aval[j];
+            const int b0 = brpt[k], b1 = brpt[k + 1];
+            if (col < 0 || b0 >= b1) continue;
+            int hit = -1;
+            if (b_sorted) {
+                int lo = b0, hi = b1 - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (bcol[mid] < col) lo = mid + 1;
+                    else hi = mid;
+                }
+                if (bcol[lo] == col) hit = lo;
+                if (hit >= 0) sum += (acc_t)(av * bval[hit]);
+            } else {
+                // unsorted B may even hold a column twice in a row: every occurrence counts, in stored order
+                for (int q = b0; q < b1; q++)
+                    if (bcol[q] == col) sum += (acc_t)(av * bval[q]);
+            }
+        }
+        if (p < c1) cval[p] = (real)sum;
+    }
+}
+
 }  // namespace spgemm
 }  // namespace nsp

@@ -134,6 +134,7 @@ static const Thr &sym_ladder()
 static const int g_flat = getenv("NSPARSE_FLAT") ? atoi(getenv("NSPARSE_FLAT")) : 2;
 // round 4: the hash bins 1..4 of both phases run the lean kernels (lean.h); NSPARSE_TB_LEAN=0: round 3's k_sym_tb / k_num_tb,
 // bit 0: symbolic, bit 1: numeric
+static int g_deterministic = 0;  // nsparse_set_deterministic
 static const int g_tb_lean = getenv("NSPARSE_TB_LEAN") ? atoi(getenv("NSPARSE_TB_LEAN")) : 0;  // (off until the fixed 24-bit hash has been measured)
 
 // Column lists (common.h: list_wanted): a heavy row goes to the listed kernel while slices x products stays within
@@ -417,7 +418,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
         constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
         if (g_tb_lean & 1)                                                                     \
-            hipLaunchKernelGGL((k_sym_lean<BS, TMAX, (BS >= 256 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
+            hipLaunchKernelGGL((k_sym_lean<BS, TMAX, (BS >= 512 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
                                arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], hist[bin_], b->nnz, d_bs, \
                                TMAX >= 8192 ? tcol : (int *)nullptr, list_off, row_span, 12, 12288);  \
         else NSP_SYM_TB_GO(BS, TMAX);                                                          \
@@ -680,7 +681,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
         if ((g_tb_lean & 2) && !tb_prof)                                                       \
-            hipLaunchKernelGGL((k_num_lean<BS, TMAX, (BS >= 256 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
+            hipLaunchKernelGGL((k_num_lean<BS, TMAX, (BS >= 512 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
                                arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_prod, row_maxb, \
                                off[bin_], hist[bin_], b->nnz, write_col);                      \
         else NSP_NUM_TB_GO(BS, TMAX, PMAX);                                                    \
@@ -941,9 +942,11 @@ static int census_coresident(Context &cx, hipStream_t st)
 {
     int *d = cx.d_scratch + 8000;  // two ints behind the workgroup records of the fused tails
     int grid = cx.num_cus < kFusedMaxBlocks ? cx.num_cus : kFusedMaxBlocks;
+    static bool big_ok = false;
+    allow_big_lds(k_census, big_ok, kCensusLds);  // one census workgroup per CU (fused.h)
     for (; grid >= 8; grid = grid * 3 / 4) {
         NSP_CHECK(hipMemsetAsync(d, 0, 2 * sizeof(int), st));
-        hipLaunchKernelGGL(k_census, dim3(grid), dim3(1024), 0, st, d, 20000 /* 0.2 ms of 100 MHz ticks */);
+        hipLaunchKernelGGL(k_census, dim3(grid), dim3(1024), kCensusLds, st, d, 20000 /* 0.2 ms of 100 MHz ticks */);
         NSP_LAUNCH_CHECK();
         NSP_CHECK(hipMemcpyAsync(cx.h_pinned + 130, d, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
         NSP_CHECK(hipStreamSynchronize(st));
@@ -978,6 +981,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         return false;
     }
     Timer tm(cx);
+    TraceRange phase_range("setup");
     hipStream_t s0 = cx.stream[0];
     const int M = a->M;
     nsparse_spgemm_stats &S = g_stats.s;
@@ -1211,6 +1215,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     for (int q = 0; q < NB; q++) S.sym_bin_size[q] = h_sym->hist[q];
 
     // ---- symbolic: nnz of every row of C, then C.rpt ----------------------------------
+    phase_range.next("symbolic");
     if (!numeric_only) {
         c->M = M;
         c->N = b->N;
@@ -1313,6 +1318,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     tm.mark(2, s0);
 
     // ---- numeric binning ------------------------------------------------------------
+    phase_range.next("numeric");
     // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
     const int *num_span = numeric_only ? row_span : row_span_num;
     if (!numeric_only && bm == nullptr) num_thr.dense_ratio = num_thr.rank_span = 0;
@@ -1399,6 +1405,13 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
                                    (int)h_sym->max_alen, h_sym->b_unsorted == 0, h_num->max_span, grp, btwin, h_num->cursor, members, blk_desc, bkey,
                                    numeric_only ? (list_mode() > 0 ? (const int *)c->d_col : (const int *)nullptr) : (const int *)tcol, list_off,
                                    0LL);
+    if (g_deterministic && c->nnz > 0) {
+        // (behind the join of the bins on the main stream: it overwrites what they wrote)
+        hipLaunchKernelGGL(k_num_deterministic, dim3(ceil_div((long long)M * 64, 256)), dim3(256), 0, s0, a->d_rpt, a->d_col,
+                           a->d_val, b->d_rpt, b->d_col, b->d_val, (const int *)c->d_rpt, (const int *)c->d_col, c->d_val, M,
+                           h_sym->b_unsorted == 0 ? 1 : 0);
+        NSP_LAUNCH_CHECK();
+    }
     tm.mark(3, s0);
     {   // synchronous on return, like upstream (:1287): poll a flag raised behind the last kernel
         const int seq = ++cx.seq;
@@ -1453,6 +1466,8 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 static void run(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 {
     ApiLock api_lock;
+    CallScope call_scope;
+    TraceRange range(numeric_only ? "nsparse:spgemm_numeric" : "nsparse:spgemm");
     clear_error();
     if (run_once(a_in, b_in, c, numeric_only)) {
         g_stats.fused_fallbacks++;
@@ -1488,9 +1503,22 @@ void nsparse_get_spgemm_stats(nsparse_spgemm_stats *out)
     *out = nsp::spgemm::g_stats.s;
 }
 
+int nsparse_set_deterministic(int on)
+{
+    nsp::ApiLock lk;
+    const int old = nsp::spgemm::g_deterministic;
+    nsp::spgemm::g_deterministic = on ? 1 : 0;
+    return old;
+}
+
 int nsparse_fused_state(int *coresident, int *fallbacks)
 {
     nsp::ApiLock lk;
+    if (!nsp::ctx_ready()) {  // a query creates nothing: no context on this device yet (or no such device)
+        if (coresident) *coresident = -1;
+        if (fallbacks) *fallbacks = nsp::spgemm::g_stats.fused_fallbacks;
+        return -1;
+    }
     nsp::Context &cx = nsp::ctx();
     if (coresident) *coresident = cx.coresident;
     if (fallbacks) *fallbacks = nsp::spgemm::g_stats.fused_fallbacks;

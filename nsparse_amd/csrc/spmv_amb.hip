@@ -343,6 +343,7 @@ void nsparse_spmv_amb_async(real *d_y, sfAMB *mat, real *d_x, sfPlan *plan, void
 void sf_spmv_amb(real *d_y, sfAMB *mat, real *d_x, sfPlan *plan)
 {
     nsp::ApiLock lk;
+    nsp::TraceRange range("nsparse:spmv_amb");
     nsp::clear_error();
     nsp::Context &cx = nsp::ctx();
     if (cx.profiling) NSP_CHECK(hipEventRecord(cx.ev_t[4], 0));

@@ -192,6 +192,27 @@ class Oracle:
         self.lib.orc_free(pv)
         return dict(M=M, N=Nc, nnz=nnz, rpt=crpt, col=col, val=val)
 
+    def spgemm_omp_timed(self, A, B, reps=3, threads=0):
+        """C = A B on all host cores, timed inside C (orc_spgemm_omp_timed: warm thread pool and output arrays, no
+        Python copies in the time).  Returns (result dict, best seconds, mean seconds, threads)."""
+        M, Nc = A["M"], B["N"]
+        crpt = np.empty(M + 1, dtype=np.int32)
+        pc, pv = C.POINTER(C.c_int)(), C.c_void_p()
+        av = np.ascontiguousarray(A["val"], dtype=self.real)
+        bv = np.ascontiguousarray(B["val"], dtype=self.real)
+        best, mean, nth = C.c_double(), C.c_double(), C.c_int(int(threads))
+        fn = self.lib.orc_spgemm_omp_timed
+        fn.restype = C.c_int
+        nnz = fn(M, Nc, _ip(A["rpt"]), _ip(A["col"]), av.ctypes.data_as(C.c_void_p), _ip(B["rpt"]), _ip(B["col"]),
+                 bv.ctypes.data_as(C.c_void_p), _ip(crpt), C.byref(pc), C.byref(pv), int(reps), C.byref(best),
+                 C.byref(mean), C.byref(nth))
+        col = np.ctypeslib.as_array(pc, (max(nnz, 1),))[:nnz].copy()
+        vb = (C.c_byte * (max(nnz, 1) * self.real().itemsize)).from_address(pv.value)
+        val = np.frombuffer(vb, dtype=self.real)[:nnz].copy()
+        self.lib.orc_free(C.cast(pc, C.c_void_p))
+        self.lib.orc_free(pv)
+        return dict(M=M, N=Nc, nnz=nnz, rpt=crpt, col=col, val=val), best.value, mean.value, nth.value
+
     def check_spgemm(self, c, ans):
         cv = np.ascontiguousarray(c["val"], dtype=self.real)
         av = np.ascontiguousarray(ans["val"], dtype=self.real)

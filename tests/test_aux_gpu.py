@@ -1,0 +1,134 @@
+"""Auxiliary subsystems of SURVEY 5 / 7 (verdict r03 item 8): the deterministic-summation mode, the roctx ranges, the
+AddressSanitizer build, and the repaired corners the round-3 advisor listed (stream-ordered frees, the fused-state
+query)."""
+import ctypes as C
+import glob
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import nsparse_amd as ns
+from gpu_util import spgemm, synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("prec", ["d", "s"])
+@pytest.mark.parametrize("kind,dims", [(5, (6, 6, 30)), (3, (13, 8, 0)), (1, (24, 24, 24))])
+def test_deterministic_mode_gives_identical_bytes(prec, kind, dims, oracle_d, oracle_s):
+    """nsparse_set_deterministic(1): two runs -- and a numeric-only re-run -- give the same BYTES of C.val; the values
+    agree with the oracle like the default ones, and the structure is untouched."""
+    lib, orc = ns.load(prec), (oracle_d if prec == "d" else oracle_s)
+    A = synth(lib, kind, *dims, seed=0x5EED0022)
+    ref = orc.spgemm(A, A)
+    old = lib.nsparse_set_deterministic(1)
+    try:
+        g1, _ = spgemm(lib, A)
+        g2, _ = spgemm(lib, A)
+        assert np.array_equal(g1["rpt"], ref["rpt"]) and np.array_equal(g1["col"], ref["col"])
+        assert g1["val"].tobytes() == g2["val"].tobytes()
+        # the sum runs over the A entries of the row in their stored order: that IS the oracle's order for a C entry
+        # whose products come from different A entries, so double-precision results are bit-identical to it
+        if prec == "d":
+            assert np.array_equal(g1["val"], ref["val"])
+        else:
+            from gpu_util import oracle_fp64_accumulated
+            np.testing.assert_allclose(g1["val"], oracle_fp64_accumulated(oracle_d, A)["val"], rtol=2e-6)
+        # numeric-only re-run on the structure: same bytes again
+        a = lib.csr_from_numpy(A["rpt"], A["col"], A["val"], A["N"])
+        lib.csr_memcpy(C.byref(a))
+        c = ns.sfCSR()
+        lib.spgemm_kernel_hash(C.byref(a), C.byref(a), C.byref(c))
+        lib.hip.hipMemset(c.d_val, 0xff, c.nnz * lib.real().itemsize)
+        lib.nsparse_spgemm_hash_numeric(C.byref(a), C.byref(a), C.byref(c))
+        v3 = lib.d2h(c.d_val, (c.nnz,), lib.real)
+        assert v3.tobytes() == g1["val"].tobytes()
+        lib.release_csr(c)
+        lib.release_csr(a)
+    finally:
+        assert lib.nsparse_set_deterministic(old) == 1
+
+
+def test_roctx_ranges_reach_a_marker_trace(tmp_path):
+    """Under rocprofv3 --marker-trace the phases of a call appear as ranges; without a profiler nothing is loaded."""
+    lib = ns.load("d")
+    assert lib.nsparse_trace_ranges() == 0  # this process is not being profiled
+    exe = "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        pytest.skip("no rocprofv3")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import nsparse_amd as ns; from gpu_util import synth, spgemm\n"
+            "lib = ns.load('d'); A = synth(lib, 0, 4, 4, 8, seed=1); spgemm(lib, A); print('RANGES', lib.nsparse_trace_ranges())\n"
+            % (ROOT, os.path.join(ROOT, "tests")))
+    out = str(tmp_path / "trace")
+    r = subprocess.run([exe, "--marker-trace", "--output-format", "csv", "-d", out, "-o", "t", "--", sys.executable, "-c", code],
+                       capture_output=True, text=True, timeout=300, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "RANGES 1" in r.stdout
+    files = glob.glob(os.path.join(out, "**", "*marker*trace*.csv"), recursive=True)
+    assert files, os.listdir(out)
+    text = "".join(open(f).read() for f in files)
+    for name in ("nsparse:spgemm", "setup", "symbolic", "numeric"):
+        assert name in text, name
+
+
+def test_asan_build_runs_clean():
+    """`make -C nsparse_amd/csrc asan` (host + device instrumented, gfx950:xnack+): one small SpGEMM and one AMB SpMV
+    through the instrumented library with the ASan runtime preloaded and HSA_XNACK=1; no report."""
+    libdir = os.path.join(ROOT, "nsparse_amd", "lib_asan")
+    if not os.path.exists(os.path.join(libdir, "libnsparse_d.so")):
+        pytest.skip("lib_asan not built (make -C nsparse_amd/csrc asan)")
+    rt = subprocess.run(["/opt/rocm/bin/hipcc", "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True,
+                        text=True).stdout.strip()
+    if not os.path.exists(rt):
+        pytest.skip("no ASan runtime")
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import numpy as np, nsparse_amd as ns; from gpu_util import synth, spgemm, DeviceAMB\n"
+            "lib = ns.load('d'); A = synth(lib, 0, 4, 4, 8, seed=1); got, st = spgemm(lib, A)\n"
+            "d = DeviceAMB(lib, A); y = d.spmv(np.ones(A['N'])); d.close(); print('DONE', got['nnz'], float(y.sum()) > 0)\n"
+            % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ, LD_PRELOAD=rt, HSA_XNACK="1", NSPARSE_LIB_DIR=libdir,
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
+    assert r.returncode == 0 and "DONE" in r.stdout, (r.returncode, r.stderr[-2000:])
+
+
+def test_stream_ordered_workspace_mode_frees_after_the_call(oracle_d):
+    """nsparse_set_workspace_cache(2): blocks released inside a call wait for its end (their hipFreeAsync goes to the
+    null stream, which the call's non-blocking streams do not order against).  The unsorted-B path frees scratch
+    right behind a segmented sort: same C as with the cache."""
+    lib = ns.load("d")
+    rng = np.random.default_rng(9)
+    A = synth(lib, 3, 12, 8, 0, seed=5)
+    B = dict(A)
+    # rows of B in descending column order: unsorted B -> global table + rocprim segmented sort
+    col = A["col"].copy()
+    val = A["val"].copy()
+    for i in range(A["M"]):
+        lo, hi = A["rpt"][i], A["rpt"][i + 1]
+        col[lo:hi] = col[lo:hi][::-1]
+        val[lo:hi] = val[lo:hi][::-1]
+    B["col"], B["val"] = col, val
+    ref = oracle_d.spgemm(A, B)
+    try:
+        lib.nsparse_set_workspace_cache(2)
+        for _ in range(3):
+            got, _ = spgemm(lib, A, B)
+            assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
+            assert oracle_d.check_spgemm(got, ref) == 0
+    finally:
+        lib.nsparse_set_workspace_cache(1)
+    del rng
+
+
+def test_fused_state_query_creates_nothing():
+    code = ("import sys, ctypes as C; sys.path.insert(0, %r)\nimport nsparse_amd as ns\n"
+            "lib = ns.load('d'); a, b = C.c_int(7), C.c_int(7)\n"
+            "print('STATE', lib.nsparse_fused_state(C.byref(a), C.byref(b)), a.value, b.value)\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert "STATE -1 -1 0" in r.stdout, (r.stdout, r.stderr[-500:])

@@ -72,6 +72,13 @@ def test_against_scipy_vectors(oracle_d, name):
     # OpenMP variant (CPU baseline leg) is the same arithmetic
     Co = oracle_d.spgemm_omp(g, g)
     assert np.array_equal(Co["col"], Cm["col"]) and np.array_equal(Co["val"], Cm["val"])
+    # ... and so is the fast all-cores form the bench times (window sweep instead of a sort for narrow rows), at
+    # one thread and at all of them
+    for nth in (1, 0):
+        Ct, best, mean, used = oracle_d.spgemm_omp_timed(g, g, reps=1, threads=nth)
+        assert used >= 1 and best > 0 and mean >= best
+        assert np.array_equal(Ct["rpt"], Cm["rpt"]) and np.array_equal(Ct["col"], Cm["col"])
+        assert np.array_equal(Ct["val"], Cm["val"])
 
 
 def test_float_oracle(oracle_s):
