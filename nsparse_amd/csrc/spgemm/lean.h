@@ -198,6 +198,38 @@ __device__ __forceinline__ void lean_walk(const int *__restrict__ acol, const re
             }
             sync();
             const int wn = total - w0 < CAP ? total - w0 : CAP;  // chunks of this window
+#ifdef NSP_LEAN_PIPE
+            // one chunk in flight BEHIND the one being hashed (round r + 1 is requested before round r is consumed):
+            // the memory round trip of a round hides behind the probes of the round before, at 12 registers per buffer
+            {
+                IVecT<V> pk[2];
+                RVecT<WITH_VAL ? V : 1> pv[2];
+                int pn[2] = {0, 0};
+                real sc[2] = {0, 0};
+                auto request = [&](int r) {
+                    const int q = r * BS + (int)threadIdx.x, sl = r & 1;
+                    pn[sl] = 0;
+                    if (q < wn) {
+                        const int i = (int)ls->own[q] - 1;
+                        const int2 x = ls->ent[i];
+                        if (WITH_VAL) sc[sl] = ls->av[i];
+                        pn[sl] = fetch_chunk<WITH_VAL, V>(bcol, bval, x.x + (w0 + q) * V, x.y, bnnz, pk[sl], pv[sl]);
+                    }
+                };
+                request(0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (r * BS >= wn) break;  // uniform
+                    const int sl = r & 1;
+                    const IVecT<V> ck = pk[sl];
+                    const RVecT<WITH_VAL ? V : 1> cv = pv[sl];
+                    const int cn = pn[sl];
+                    const real cs = sc[sl];
+                    if (r < 3 && (r + 1) * BS < wn) request(r + 1);
+                    if (cn > 0) consume(ck, cv, cn, cs);
+                }
+            }
+#else
 #pragma unroll
             for (int r0 = 0; r0 < 4; r0 += U) {
                 if (r0 * BS >= wn) break;  // uniform
@@ -221,6 +253,7 @@ __device__ __forceinline__ void lean_walk(const int *__restrict__ acol, const re
                 for (int u = 0; u < U; u++)
                     if (pn[u] > 0) consume(pk[u], pv[u], pn[u], sc[u]);
             }
+#endif
         }
         sync();  // the next batch overwrites the parked entries
     }

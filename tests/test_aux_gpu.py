@@ -77,8 +77,8 @@ def test_roctx_ranges_reach_a_marker_trace(tmp_path):
 
 
 def test_asan_build_runs_clean():
-    """`make -C nsparse_amd/csrc asan` (host + device instrumented, gfx950:xnack+): one small SpGEMM and one AMB SpMV
-    through the instrumented library with the ASan runtime preloaded and HSA_XNACK=1; no report."""
+    """`make -C nsparse_amd/csrc asan` (host code instrumented: loader, plan search, workspace cache, launch paths): one
+    small SpGEMM and one AMB SpMV through that library with the ASan runtime preloaded; no report."""
     libdir = os.path.join(ROOT, "nsparse_amd", "lib_asan")
     if not os.path.exists(os.path.join(libdir, "libnsparse_d.so")):
         pytest.skip("lib_asan not built (make -C nsparse_amd/csrc asan)")
@@ -91,7 +91,7 @@ def test_asan_build_runs_clean():
             "lib = ns.load('d'); A = synth(lib, 0, 4, 4, 8, seed=1); got, st = spgemm(lib, A)\n"
             "d = DeviceAMB(lib, A); y = d.spmv(np.ones(A['N'])); d.close(); print('DONE', got['nnz'], float(y.sum()) > 0)\n"
             % (ROOT, os.path.join(ROOT, "tests")))
-    env = dict(os.environ, LD_PRELOAD=rt, HSA_XNACK="1", NSPARSE_LIB_DIR=libdir,
+    env = dict(os.environ, LD_PRELOAD=rt, NSPARSE_LIB_DIR=libdir,
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
     assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
