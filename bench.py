@@ -266,7 +266,9 @@ def run_config(case, pmc, deadline):
             return {"case": case, "error": f"rc {r.returncode}: {r.stderr[-300:]}"}
         rec = json.loads(lines[-1])
     except subprocess.TimeoutExpired as e:
-        lines = [ln for ln in (e.stdout or b"").decode(errors="replace").splitlines() if ln.startswith("{")]
+        so = e.stdout or ""
+        so = so.decode(errors="replace") if isinstance(so, bytes) else so
+        lines = [ln for ln in so.splitlines() if ln.startswith("{")]
         if not lines:
             return {"case": case, "error": "timed out before the first record"}
         rec = json.loads(lines[-1])

@@ -244,6 +244,81 @@ __global__ __launch_bounds__(1024) void k_spmv_amb_row(real *__restrict__ y, con
     }
 }
 
+// Fourth form (round 4), for matrices that live in the caches: ONE CHUNK PER WORKGROUP of W wavefronts, wavefront w
+// taking the blocks w, w + W, ... of every row of the chunk, partial sums folded through LDS in a fixed order.
+// A cache-resident SpMV is not a bandwidth problem but a chain of dependent round trips with one wavefront per SIMD
+// (cant class: 976 chunks for 1024 SIMDs): a row of 22 blocks of 3 is wider than the 10 blocks the whole-row form
+// keeps in flight, so it ran the pipelined loop -- 6 batches, a dependent x gather each, 15.4 us where rocSPARSE's
+// csrmv takes 13.1.  With W = 4 every wavefront has 6 blocks: chunk words -> column ids -> values + x, three trips
+// whatever the width, and four times the wavefronts to hide them behind.  The traversal, the layout and the
+// single-segment determinism (fixed summation order: blocks of wavefront 0, then the partials of 1 .. W-1) stay.
+template <int BSZ, bool ATOMIC, int NB>
+__global__ __launch_bounds__(512) void k_spmv_amb_split(real *__restrict__ y, const real *__restrict__ val,
+                                                        const unsigned short *__restrict__ col,
+                                                        const unsigned int *__restrict__ cl,
+                                                        const int *__restrict__ cs,
+                                                        const real *__restrict__ x,
+                                                        const unsigned short *__restrict__ perm,
+                                                        const unsigned short *__restrict__ perm_off,
+                                                        int nchunks, int seg_size, int M, int N, int nb8)
+{
+    constexpr int C = 64;
+    __shared__ real part[7][C];
+    const int lb = nb8 > 0 ? (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (lb >= nchunks) return;  // (the whole workgroup: no barrier is skipped by part of it)
+    const int W = (int)(blockDim.x >> 6), w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    const int cs0 = cs[lb];
+    const unsigned int length = cl[lb];
+    const int nblk = (int)(length & SCL_BIT) + 1;
+    const int c_off = (int)(length >> SCL_BORDER) * seg_size;
+    const real *v = val + cs0 + lane;
+    const unsigned short *cp = col + cs0 / BSZ + lane;
+    const int nmax = N - 1;
+    real acc = 0;
+    for (int h0 = w; h0 < nblk; h0 += W * NB) {
+        int cc[NB];
+        real vv[NB][BSZ], xx[NB][BSZ];
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int h = h0 + u * W;
+            cc[u] = h < nblk ? (int)__builtin_nontemporal_load(cp + h * C) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            const int h = h0 + u * W;
+            if (h < nblk) {
+#pragma unroll
+                for (int b = 0; b < BSZ; b++) vv[u][b] = __builtin_nontemporal_load(v + (h * BSZ + b) * C);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            if (h0 + u * W < nblk) {
+                const int c0 = cc[u] + c_off;
+#pragma unroll
+                for (int b = 0; b < BSZ; b++) xx[u][b] = x[c0 + b < nmax ? c0 + b : nmax];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < NB; u++) {
+            if (h0 + u * W < nblk) {
+#pragma unroll
+                for (int b = 0; b < BSZ; b++) acc += vv[u][b] * xx[u][b];
+            }
+        }
+    }
+    if (w > 0) part[w - 1][lane] = acc;
+    __syncthreads();
+    if (w == 0) {
+        for (int q = 0; q < W - 1; q++) acc += part[q][lane];
+        const int row = (int)__builtin_nontemporal_load(perm + (long long)lb * C + lane) + (int)perm_off[lb] * USHORT_MAX;
+        if (row < M) {
+            if (ATOMIC) unsafeAtomicAdd(y + row, acc);
+            else y[row] = acc;
+        }
+    }
+}
+
 template <int BSZ>
 static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipStream_t st)
 {
@@ -280,8 +355,30 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
                        mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
                        mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg, abl)
     static const int abl = getenv("NSPARSE_SPMV_ABL") ? atoi(getenv("NSPARSE_SPMV_ABL")) : 0;
+    constexpr int NB = BSZ >= 12 ? 1 : (BSZ >= 6 ? 3 : (BSZ >= 3 ? 10 : (BSZ == 2 ? 14 : 24)));
+    // cache-resident matrix of few chunks whose rows are wider than the whole-row form keeps in flight: split the
+    // rows over W wavefronts (k_spmv_amb_split; NSPARSE_SPMV_SPLIT=0: never, =W: that many)
+    static const int split_env = getenv("NSPARSE_SPMV_SPLIT") ? atoi(getenv("NSPARSE_SPMV_SPLIT")) : -1;
+    constexpr int NBS = BSZ >= 12 ? 1 : (BSZ >= 6 ? 2 : (BSZ >= 3 ? 6 : (BSZ == 2 ? 8 : 12)));
+    if (mat->chunk == 64 && pipe == 4 && !plain && split_env != 0 && !no_remap && mat->c_size <= 8192) {
+        const double avgb = (double)mat->nnz / ((double)BSZ * (double)rows);  // average blocks per row (= chunk width)
+        int W = 1;
+        if (split_env == 2 || split_env == 4 || split_env == 8) W = split_env;
+        else if (avgb > NB) W = avgb <= 2.0 * NBS ? 2 : (avgb <= 4.0 * NBS ? 4 : 8);
+        if (W > 1) {
+            const int nc = mat->c_size, ncb8 = ceil_div(nc, 8);
+            if (atomic)
+                hipLaunchKernelGGL((k_spmv_amb_split<BSZ, true, NBS>), dim3(ncb8 * 8), dim3(64 * W), 0, st, d_y, mat->d_sellcs_val,
+                                   mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation,
+                                   mat->d_s_write_permutation_offset, nc, (int)mat->seg_size, mat->M, mat->N, ncb8);
+            else
+                hipLaunchKernelGGL((k_spmv_amb_split<BSZ, false, NBS>), dim3(ncb8 * 8), dim3(64 * W), 0, st, d_y, mat->d_sellcs_val,
+                                   mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation,
+                                   mat->d_s_write_permutation_offset, nc, (int)mat->seg_size, mat->M, mat->N, ncb8);
+            return;
+        }
+    }
     if (mat->chunk == 64 && pipe == 4 && !plain) {
-        constexpr int NB = BSZ >= 12 ? 1 : (BSZ >= 6 ? 3 : (BSZ >= 3 ? 10 : (BSZ == 2 ? 14 : 24)));
         if (atomic)
             hipLaunchKernelGGL((k_spmv_amb_row<BSZ, true, NB, UB>), grid, block, 0, st, d_y, mat->d_sellcs_val,
                                mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation,
