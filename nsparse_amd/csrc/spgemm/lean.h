@@ -317,86 +317,105 @@ __device__ __forceinline__ void lean_insert4(int *tab, int mask, int shift, int 
 // Element e of the sequence lives in lane e & 63, register e >> 6.  Flip form of the bitonic network: merge size k
 // starts with the comparator (i, i ^ (k - 1)) and continues with (i, i ^ j), j = k/4 ... 1; the lower index always
 // keeps the minimum.
-template <int CTRL>
-__device__ __forceinline__ int dpp_get(int v)
-{
-    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
-}
-__device__ __forceinline__ void cex(int &x, int q, bool lower)
-{
-    const int lo = x < q ? x : q, hi = x < q ? q : x;
-    x = lower ? lo : hi;
-}
-// S: number of stages wanted, P = pow2 >= 2 elements; r1 is touched only when P == 128
+// Compare-exchange against the partner a DPP pattern names: min and max with the pattern folded into the instruction
+// (the compiler turns update_dpp + min + max into copy, v_mov_dpp, v_min, v_max, v_cndmask: five instructions; here
+// three).  s_nop 1: a DPP operand written by the VALU instruction before needs two wait states on gfx9.
+#define NSP_CEX_DPP(x, lower, CTRL)                                                                          \
+    do {                                                                                                     \
+        int lo_, hi_;                                                                                        \
+        asm("s_nop 1\n\tv_min_i32_dpp %0, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                   \
+            "v_max_i32_dpp %1, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf"                                   \
+            : "=&v"(lo_), "=&v"(hi_)                                                                         \
+            : "v"(x));                                                                                       \
+        x = (lower) ? lo_ : hi_;                                                                             \
+    } while (0)
+// ... against a partner value q fetched through the LDS crossbar (ds_swizzle / ds_bpermute), where the lanes that keep
+// the minimum are whole banks (4 lanes) or rows (16 lanes): the identity DPP pattern with a bank / row mask is a
+// predicated write -- two instructions, no select, no mask register.
+#define NSP_CEX_MASKED(x, q, LO, HI)                                                                         \
+    asm("v_min_i32_dpp %0, %1, %0 quad_perm:[0,1,2,3] " LO "\n\tv_max_i32_dpp %0, %1, %0 quad_perm:[0,1,2,3] " HI \
+        : "+v"(x)                                                                                            \
+        : "v"(q))
+
+// P = pow2 >= 2 elements; r1 is touched only when P == 128
 template <int P>
 __device__ __forceinline__ void wave_sort_regs(int &r0, int &r1, int lane)
 {
-    const bool b0 = (lane & 1) == 0, b1 = (lane & 2) == 0, b2 = (lane & 4) == 0, b3 = (lane & 8) == 0,
-               b4 = (lane & 16) == 0, b5 = (lane & 32) == 0;
+    const bool b0 = (lane & 1) == 0, b1 = (lane & 2) == 0, b2 = (lane & 4) == 0, b3 = (lane & 8) == 0;
     constexpr bool TWO = P == 128;
-    auto x1 = [&]() { cex(r0, dpp_get<0xB1>(r0), b0); if (TWO) cex(r1, dpp_get<0xB1>(r1), b0); };   // quad_perm [1,0,3,2]
-    auto x2 = [&]() { cex(r0, dpp_get<0x4E>(r0), b1); if (TWO) cex(r1, dpp_get<0x4E>(r1), b1); };   // quad_perm [2,3,0,1]
-    auto x4 = [&]() {
-        cex(r0, __builtin_amdgcn_ds_swizzle(r0, (4 << 10) | 0x1f), b2);
-        if (TWO) cex(r1, __builtin_amdgcn_ds_swizzle(r1, (4 << 10) | 0x1f), b2);
-    };
-    auto x8 = [&]() { cex(r0, dpp_get<0x128>(r0), b3); if (TWO) cex(r1, dpp_get<0x128>(r1), b3); };  // row_ror:8
-    auto x16 = [&]() {
-        cex(r0, __builtin_amdgcn_ds_swizzle(r0, (16 << 10) | 0x1f), b4);
-        if (TWO) cex(r1, __builtin_amdgcn_ds_swizzle(r1, (16 << 10) | 0x1f), b4);
-    };
-    auto x32 = [&]() {
-        cex(r0, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, r0), b5);
-        if (TWO) cex(r1, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, r1), b5);
-    };
+    const int a32 = (lane ^ 32) << 2, amir = (63 - lane) << 2;
+    int x0 = r0, x1 = r1;  // (locals, not the references: the asm operands must be registers, not memory)
+#define NSP_BOTH(STMT0, STMT1) do { STMT0; if (TWO) { STMT1; } } while (0)
+#define NSP_X1() NSP_BOTH(NSP_CEX_DPP(x0, b0, "quad_perm:[1,0,3,2]"), NSP_CEX_DPP(x1, b0, "quad_perm:[1,0,3,2]"))
+#define NSP_X2() NSP_BOTH(NSP_CEX_DPP(x0, b1, "quad_perm:[2,3,0,1]"), NSP_CEX_DPP(x1, b1, "quad_perm:[2,3,0,1]"))
+#define NSP_X8() NSP_BOTH(NSP_CEX_DPP(x0, b3, "row_ror:8"), NSP_CEX_DPP(x1, b3, "row_ror:8"))
+    // partner through the LDS crossbar, minimum kept by whole banks / rows (LO / HI: the DPP masks of the two halves)
+#define NSP_XQ(FETCH0, FETCH1, LO, HI)                                                                       \
+    do {                                                                                                     \
+        const int q0_ = FETCH0, q1_ = TWO ? FETCH1 : 0;                                                      \
+        NSP_BOTH(NSP_CEX_MASKED(x0, q0_, LO, HI), NSP_CEX_MASKED(x1, q1_, LO, HI));                          \
+    } while (0)
+#define NSP_X4() NSP_XQ(__builtin_amdgcn_ds_swizzle(x0, (4 << 10) | 0x1f), __builtin_amdgcn_ds_swizzle(x1, (4 << 10) | 0x1f), \
+                        "row_mask:0xf bank_mask:0x5", "row_mask:0xf bank_mask:0xa")  /* bit 2 clear = banks 0, 2 */
+#define NSP_X16() NSP_XQ(__builtin_amdgcn_ds_swizzle(x0, (16 << 10) | 0x1f), __builtin_amdgcn_ds_swizzle(x1, (16 << 10) | 0x1f), \
+                         "row_mask:0x5 bank_mask:0xf", "row_mask:0xa bank_mask:0xf")  /* bit 4 clear = rows 0, 2 */
+#define NSP_X32() NSP_XQ(__builtin_amdgcn_ds_bpermute(a32, x0), __builtin_amdgcn_ds_bpermute(a32, x1),      \
+                         "row_mask:0x3 bank_mask:0xf", "row_mask:0xc bank_mask:0xf")  /* bit 5 clear = rows 0, 1 */
     // k = 2
-    x1();
+    NSP_X1();
     if (P >= 4) {  // flip 4: quad_perm [3,2,1,0]
-        cex(r0, dpp_get<0x1B>(r0), b1);
-        if (TWO) cex(r1, dpp_get<0x1B>(r1), b1);
-        x1();
+        NSP_BOTH(NSP_CEX_DPP(x0, b1, "quad_perm:[3,2,1,0]"), NSP_CEX_DPP(x1, b1, "quad_perm:[3,2,1,0]"));
+        NSP_X1();
     }
     if (P >= 8) {  // flip 8: row_half_mirror
-        cex(r0, dpp_get<0x141>(r0), b2);
-        if (TWO) cex(r1, dpp_get<0x141>(r1), b2);
-        x2();
-        x1();
+        NSP_BOTH(NSP_CEX_DPP(x0, b2, "row_half_mirror"), NSP_CEX_DPP(x1, b2, "row_half_mirror"));
+        NSP_X2();
+        NSP_X1();
     }
     if (P >= 16) {  // flip 16: row_mirror
-        cex(r0, dpp_get<0x140>(r0), b3);
-        if (TWO) cex(r1, dpp_get<0x140>(r1), b3);
-        x4();
-        x2();
-        x1();
+        NSP_BOTH(NSP_CEX_DPP(x0, b3, "row_mirror"), NSP_CEX_DPP(x1, b3, "row_mirror"));
+        NSP_X4();
+        NSP_X2();
+        NSP_X1();
     }
-    if (P >= 32) {  // flip 32: lane ^ 31 (swizzle works inside groups of 32 lanes)
-        cex(r0, __builtin_amdgcn_ds_swizzle(r0, (0x1f << 10) | 0x1f), b4);
-        if (TWO) cex(r1, __builtin_amdgcn_ds_swizzle(r1, (0x1f << 10) | 0x1f), b4);
-        x8();
-        x4();
-        x2();
-        x1();
+    if (P >= 32) {  // flip 32: lane ^ 31 (swizzle works inside groups of 32 lanes); bit 4 clear keeps the minimum
+        NSP_XQ(__builtin_amdgcn_ds_swizzle(x0, (0x1f << 10) | 0x1f), __builtin_amdgcn_ds_swizzle(x1, (0x1f << 10) | 0x1f),
+               "row_mask:0x5 bank_mask:0xf", "row_mask:0xa bank_mask:0xf");
+        NSP_X8();
+        NSP_X4();
+        NSP_X2();
+        NSP_X1();
     }
-    if (P >= 64) {  // flip 64: lane 63 - l
-        cex(r0, __builtin_amdgcn_ds_bpermute((63 - lane) << 2, r0), b5);
-        if (TWO) cex(r1, __builtin_amdgcn_ds_bpermute((63 - lane) << 2, r1), b5);
-        x16();
-        x8();
-        x4();
-        x2();
-        x1();
+    if (P >= 64) {  // flip 64: lane 63 - l; bit 5 clear keeps the minimum
+        NSP_XQ(__builtin_amdgcn_ds_bpermute(amir, x0), __builtin_amdgcn_ds_bpermute(amir, x1),
+               "row_mask:0x3 bank_mask:0xf", "row_mask:0xc bank_mask:0xf");
+        NSP_X16();
+        NSP_X8();
+        NSP_X4();
+        NSP_X2();
+        NSP_X1();
     }
     if (TWO) {  // flip 128: element e against 127 - e = register 1 of lane 63 - l
-        const int m0 = __builtin_amdgcn_ds_bpermute((63 - lane) << 2, r1), m1 = __builtin_amdgcn_ds_bpermute((63 - lane) << 2, r0);
-        r0 = r0 < m0 ? r0 : m0;
-        r1 = r1 > m1 ? r1 : m1;
-        x32();
-        x16();
-        x8();
-        x4();
-        x2();
-        x1();
+        const int m0 = __builtin_amdgcn_ds_bpermute(amir, x1), m1 = __builtin_amdgcn_ds_bpermute(amir, x0);
+        x0 = x0 < m0 ? x0 : m0;
+        x1 = x1 > m1 ? x1 : m1;
+        NSP_X32();
+        NSP_X16();
+        NSP_X8();
+        NSP_X4();
+        NSP_X2();
+        NSP_X1();
     }
+    r0 = x0;
+    if (TWO) r1 = x1;
+#undef NSP_X1
+#undef NSP_X2
+#undef NSP_X4
+#undef NSP_X8
+#undef NSP_X16
+#undef NSP_X32
+#undef NSP_XQ
+#undef NSP_BOTH
 }
 
 __device__ __forceinline__ void wave_sort128(int &r0, int &r1, int P, int lane)
