@@ -369,7 +369,7 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--no-irregular", action="store_true", help="skip the regular brick and the structure sweep")
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs 3 / 5 and the stencil (the `configs` block)")
-    ap.add_argument("--configs-budget", type=float, default=130.0, help="seconds the `configs` block may take")
+    ap.add_argument("--configs-budget", type=float, default=110.0, help="seconds the `configs` block may take")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
