@@ -357,8 +357,9 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
     static const int abl = getenv("NSPARSE_SPMV_ABL") ? atoi(getenv("NSPARSE_SPMV_ABL")) : 0;
     constexpr int NB = BSZ >= 12 ? 1 : (BSZ >= 6 ? 3 : (BSZ >= 3 ? 10 : (BSZ == 2 ? 14 : 24)));
     // cache-resident matrix of few chunks whose rows are wider than the whole-row form keeps in flight: split the
-    // rows over W wavefronts (k_spmv_amb_split; NSPARSE_SPMV_SPLIT=0: never, =W: that many)
-    static const int split_env = getenv("NSPARSE_SPMV_SPLIT") ? atoi(getenv("NSPARSE_SPMV_SPLIT")) : -1;
+    // rows over W wavefronts (k_spmv_amb_split).  NSPARSE_SPMV_SPLIT=1: W chosen from the average row width, =2 / 4 / 8:
+    // that many; default 0 (off) until the kernel has been timed against the whole-row form on the device
+    static const int split_env = getenv("NSPARSE_SPMV_SPLIT") ? atoi(getenv("NSPARSE_SPMV_SPLIT")) : 0;
     constexpr int NBS = BSZ >= 12 ? 1 : (BSZ >= 6 ? 2 : (BSZ >= 3 ? 6 : (BSZ == 2 ? 8 : 12)));
     if (mat->chunk == 64 && pipe == 4 && !plain && split_env != 0 && !no_remap && mat->c_size <= 8192) {
         const double avgb = (double)mat->nnz / ((double)BSZ * (double)rows);  // average blocks per row (= chunk width)

@@ -165,3 +165,30 @@ def test_no_rows(lib_d):
     assert d.amb.c_size == 0 and d.plan.isPlan == 1 and lib_d.nsparse_last_error() == 0
     assert d.spmv(np.ones(500)).shape == (0,)
     d.close()
+
+
+@pytest.mark.parametrize("split", ["1", "2", "8"])
+def test_split_row_spmv_for_cache_resident_matrices(split, oracle_d):
+    """NSPARSE_SPMV_SPLIT (round 4, opt-in): one chunk per workgroup of W wavefronts, wavefront w taking the blocks
+    w, w + W, ... of every row, partial sums folded through LDS -- same y as the CPU loop (ans_check), bit-identical
+    from run to run with one column segment, nothing written past row M, on a brick (rows of 81 entries: wider than
+    the whole-row form holds) and on a power-law matrix (chunks of very different widths, several segments)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import nsparse_amd as ns; from gpu_util import synth, DeviceAMB; from oracle.oracle import Oracle\n"
+            "lib, orc = ns.load('d'), Oracle('d')\n"
+            "for kind, dims, seg in ((0, (6, 6, 40), None), (4, (30000, 95000, 0), None), (3, (13, 8, 0), (2048, 2))):\n"
+            "    A = synth(lib, kind, *dims, seed=11); x = np.random.default_rng(2).random(A['N'])\n"
+            "    d = DeviceAMB(lib, A) if seg is None else DeviceAMB(lib, A, seg[0], seg[1])\n"
+            "    y1 = d.spmv(x); y2 = d.spmv(x)\n"
+            "    ref = orc.csr_spmv(A['rpt'], A['col'], A['val'], x)\n"
+            "    assert orc.ans_check(ref, y1[:A['M']]) == 0, kind\n"
+            "    assert (y1[A['M']:] == 7.0).all(), 'wrote past row M'\n"
+            "    if d.amb.seg_num == 1: assert y1.tobytes() == y2.tobytes(), 'not reproducible'\n"
+            "    d.close()\n"
+            "print('SPLIT_OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
+                       env=dict(os.environ, NSPARSE_SPMV_SPLIT=split))
+    assert r.returncode == 0 and "SPLIT_OK" in r.stdout, r.stderr[-2000:]

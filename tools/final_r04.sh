@@ -19,7 +19,7 @@ tests)
 ab)
   bash tools/ab_lean3.sh stencil webbase1m rmat18 rmat22 2>&1 | tail -24 | tee gpurun_out/r04/ab_lean3.txt ;;
 spmv)
-  for sp in 0 -1 2 8; do
+  for sp in 0 1 2 4 8; do
     echo "== NSPARSE_SPMV_SPLIT=$sp"
     NSPARSE_SPMV_SPLIT=$sp timeout 600 python bench.py --no-cpu --no-pmc --no-irregular --no-configs --no-large --steps 2 2>/dev/null | python -c "
 import json,sys
