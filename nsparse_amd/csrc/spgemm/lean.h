@@ -432,6 +432,162 @@ __device__ __forceinline__ void wave_sort128(int &r0, int &r1, int P, int lane)
     }
 }
 
+// ---- workgroup sort of 1024 .. 8192 keys in LDS, flip form (big-table bins) -------------------------------------------
+// bitonic_sort_lds (common.h) is the direction form of the network: every compare-exchange of its register stages is a
+// ds_swizzle, a direction bit, min, max and two selects.  The flip form lets the register stages use the folded DPP /
+// masked-write compare-exchanges of the one-wavefront sort above: element e = segment * 512 + lane * 8 + i, eight per
+// lane; distances 1 / 2 / 4 stay inside the thread (min + max per pair), 8 .. 256 are lane distances 1 .. 32, and a flip
+// of merge size k <= 512 pairs (lane, i) with (mirror of the lane inside k/8 lanes, 7 - i).  Merge sizes beyond 512 do
+// their flip and their distances >= 512 through LDS with a workgroup barrier each, then the distances 256 .. 1 in
+// registers again.  (numpy model of exactly this decomposition: DESIGN 4.1.)  The round-3 profile of the 8192-slot
+// numeric bin had the sort at 16 of the 41 us of a row.
+#define NSP_CEX_DPP2(out, x, y, lower, CTRL)                                                                 \
+    do {                                                                                                     \
+        int lo_, hi_;                                                                                        \
+        asm("s_nop 1\n\tv_min_i32_dpp %0, %3, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                   \
+            "v_max_i32_dpp %1, %3, %2 " CTRL " row_mask:0xf bank_mask:0xf"                                   \
+            : "=&v"(lo_), "=&v"(hi_)                                                                         \
+            : "v"(x), "v"(y));                                                                               \
+        out = (lower) ? lo_ : hi_;                                                                           \
+    } while (0)
+
+template <int BS>
+__device__ __forceinline__ void flip_sort_lds(int *s, int P)
+{
+    constexpr int NW = BS / 64;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const bool b0 = (lane & 1) == 0, b1 = (lane & 2) == 0, b2 = (lane & 4) == 0, b3 = (lane & 8) == 0;
+    const int a32 = (lane ^ 32) << 2, amir = (63 - lane) << 2;
+    int r[8];
+#define NSP_LOAD8(eb)                                                                                        \
+    do {                                                                                                     \
+        const int4 a_ = *reinterpret_cast<const int4 *>(s + (eb)), b_ = *reinterpret_cast<const int4 *>(s + (eb) + 4); \
+        r[0] = a_.x, r[1] = a_.y, r[2] = a_.z, r[3] = a_.w, r[4] = b_.x, r[5] = b_.y, r[6] = b_.z, r[7] = b_.w; \
+    } while (0)
+#define NSP_STORE8(eb)                                                                                       \
+    do {                                                                                                     \
+        *reinterpret_cast<int4 *>(s + (eb)) = make_int4(r[0], r[1], r[2], r[3]);                             \
+        *reinterpret_cast<int4 *>(s + (eb) + 4) = make_int4(r[4], r[5], r[6], r[7]);                         \
+    } while (0)
+    // inside the thread: pair (i, p), i < p
+#define NSP_PAIR(i, p)                                                                                       \
+    do {                                                                                                     \
+        const int lo_ = r[i] < r[p] ? r[i] : r[p], hi_ = r[i] < r[p] ? r[p] : r[i];                          \
+        r[i] = lo_;                                                                                          \
+        r[p] = hi_;                                                                                          \
+    } while (0)
+#define NSP_TX1() do { NSP_PAIR(0, 1); NSP_PAIR(2, 3); NSP_PAIR(4, 5); NSP_PAIR(6, 7); } while (0)
+#define NSP_TX2() do { NSP_PAIR(0, 2); NSP_PAIR(1, 3); NSP_PAIR(4, 6); NSP_PAIR(5, 7); } while (0)
+#define NSP_TX4() do { NSP_PAIR(0, 4); NSP_PAIR(1, 5); NSP_PAIR(2, 6); NSP_PAIR(3, 7); } while (0)
+#define NSP_TF4() do { NSP_PAIR(0, 3); NSP_PAIR(1, 2); NSP_PAIR(4, 7); NSP_PAIR(5, 6); } while (0)
+#define NSP_TF8() do { NSP_PAIR(0, 7); NSP_PAIR(1, 6); NSP_PAIR(2, 5); NSP_PAIR(3, 4); } while (0)
+    // lane distance L by a DPP pattern: every element against the same element of the partner lane
+#define NSP_LX_DPP(lower, CTRL)                                                                              \
+    do {                                                                                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) NSP_CEX_DPP(r[i_], lower, CTRL);                    \
+    } while (0)
+    // ... through the LDS crossbar, minimum kept by whole banks / rows
+#define NSP_LX_Q(FETCH, LO, HI)                                                                              \
+    do {                                                                                                     \
+        int q_[8];                                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) q_[i_] = FETCH(r[i_]);                              \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) NSP_CEX_MASKED(r[i_], q_[i_], LO, HI);              \
+    } while (0)
+#define NSP_F_SWZ4(v) __builtin_amdgcn_ds_swizzle(v, (4 << 10) | 0x1f)
+#define NSP_F_SWZ16(v) __builtin_amdgcn_ds_swizzle(v, (16 << 10) | 0x1f)
+#define NSP_F_SWZ31(v) __builtin_amdgcn_ds_swizzle(v, (0x1f << 10) | 0x1f)
+#define NSP_F_X32(v) __builtin_amdgcn_ds_bpermute(a32, v)
+#define NSP_F_MIR(v) __builtin_amdgcn_ds_bpermute(amir, v)
+#define NSP_LX1() NSP_LX_DPP(b0, "quad_perm:[1,0,3,2]")
+#define NSP_LX2() NSP_LX_DPP(b1, "quad_perm:[2,3,0,1]")
+#define NSP_LX4() NSP_LX_Q(NSP_F_SWZ4, "row_mask:0xf bank_mask:0x5", "row_mask:0xf bank_mask:0xa")
+#define NSP_LX8() NSP_LX_DPP(b3, "row_ror:8")
+#define NSP_LX16() NSP_LX_Q(NSP_F_SWZ16, "row_mask:0x5 bank_mask:0xf", "row_mask:0xa bank_mask:0xf")
+#define NSP_LX32() NSP_LX_Q(NSP_F_X32, "row_mask:0x3 bank_mask:0xf", "row_mask:0xc bank_mask:0xf")
+    // flip over a mirror group of G lanes: element i against element 7 - i of the mirrored lane
+#define NSP_LF_DPP(lower, CTRL)                                                                              \
+    do {                                                                                                     \
+        int t_[8];                                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) NSP_CEX_DPP2(t_[i_], r[i_], r[7 - i_], lower, CTRL); \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) r[i_] = t_[i_];                                     \
+    } while (0)
+#define NSP_LF_Q(FETCH, LO, HI)                                                                              \
+    do {                                                                                                     \
+        int q_[8];                                                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) q_[i_] = FETCH(r[7 - i_]);                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < 8; i_++) NSP_CEX_MASKED(r[i_], q_[i_], LO, HI);              \
+    } while (0)
+    // the distances 4 .. 1 inside the thread, then nothing left
+#define NSP_TAIL_T() do { NSP_TX4(); NSP_TX2(); NSP_TX1(); } while (0)
+    for (int seg = wid; seg * 512 < P; seg += NW) {
+        const int eb = seg * 512 + lane * 8;
+        NSP_LOAD8(eb);
+        NSP_TX1();                                                            // k = 2
+        NSP_TF4(); NSP_TX1();                                                 // k = 4
+        NSP_TF8(); NSP_TX2(); NSP_TX1();                                      // k = 8
+        NSP_LF_DPP(b0, "quad_perm:[1,0,3,2]"); NSP_TAIL_T();                  // k = 16: 2 lanes
+        NSP_LF_DPP(b1, "quad_perm:[3,2,1,0]"); NSP_LX1(); NSP_TAIL_T();       // k = 32: 4 lanes
+        NSP_LF_DPP(b2, "row_half_mirror"); NSP_LX2(); NSP_LX1(); NSP_TAIL_T();  // k = 64: 8 lanes
+        NSP_LF_DPP(b3, "row_mirror"); NSP_LX4(); NSP_LX2(); NSP_LX1(); NSP_TAIL_T();  // k = 128: 16 lanes
+        NSP_LF_Q(NSP_F_SWZ31, "row_mask:0x5 bank_mask:0xf", "row_mask:0xa bank_mask:0xf");  // k = 256: 32 lanes
+        NSP_LX8(); NSP_LX4(); NSP_LX2(); NSP_LX1(); NSP_TAIL_T();
+        NSP_LF_Q(NSP_F_MIR, "row_mask:0x3 bank_mask:0xf", "row_mask:0xc bank_mask:0xf");    // k = 512: 64 lanes
+        NSP_LX16(); NSP_LX8(); NSP_LX4(); NSP_LX2(); NSP_LX1(); NSP_TAIL_T();
+        NSP_STORE8(eb);
+    }
+    __syncthreads();
+    for (int k = 1024; k <= P; k <<= 1) {
+        {   // flip through LDS: t-th pair = (lo, lo ^ (k - 1)), lo = t with a zero inserted at bit log2(k / 2)
+            const int hb = (k >> 1) - 1;
+            for (int t = threadIdx.x; t < P / 2; t += BS) {
+                const int lo = ((t & ~hb) << 1) | (t & hb), hi = lo ^ (k - 1);
+                const int a = s[lo], b = s[hi];
+                if (a > b) { s[lo] = b; s[hi] = a; }
+            }
+            __syncthreads();
+        }
+        for (int j = k >> 2; j >= 512; j >>= 1) {
+            for (int t = threadIdx.x; t < P / 2; t += BS) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const int a = s[lo], b = s[hi];
+                if (a > b) { s[lo] = b; s[hi] = a; }
+            }
+            __syncthreads();
+        }
+        for (int seg = wid; seg * 512 < P; seg += NW) {
+            const int eb = seg * 512 + lane * 8;
+            NSP_LOAD8(eb);
+            NSP_LX32(); NSP_LX16(); NSP_LX8(); NSP_LX4(); NSP_LX2(); NSP_LX1(); NSP_TAIL_T();
+            NSP_STORE8(eb);
+        }
+        __syncthreads();
+    }
+#undef NSP_LOAD8
+#undef NSP_STORE8
+#undef NSP_PAIR
+#undef NSP_TX1
+#undef NSP_TX2
+#undef NSP_TX4
+#undef NSP_TF4
+#undef NSP_TF8
+#undef NSP_LX_DPP
+#undef NSP_LX_Q
+#undef NSP_F_SWZ4
+#undef NSP_F_SWZ16
+#undef NSP_F_SWZ31
+#undef NSP_F_X32
+#undef NSP_F_MIR
+#undef NSP_LX1
+#undef NSP_LX2
+#undef NSP_LX4
+#undef NSP_LX8
+#undef NSP_LX16
+#undef NSP_LX32
+#undef NSP_LF_DPP
+#undef NSP_LF_Q
+#undef NSP_TAIL_T
+}
+
 // ---- symbolic, bins 1..4 (set_row_nz_bin_each_tb :399-472) -----------------------------------------------------------
 // LIST: big-table bins may leave the sorted column list of a heavy row for the ranked numeric kernel (symbolic.h).
 template <int BS, int TMAX, int U>
@@ -510,7 +666,8 @@ __global__ __launch_bounds__(BS) void k_sym_lean(const int *__restrict__ arpt, c
             const int P = pow2_ceil(nz);  // <= T: the table was sized for the products
             for (int i = nz + threadIdx.x; i < P; i += BS) tab[i] = 0x7fffffff;
             __syncthreads();
-            bitonic_sort_lds<BS>(tab, P);
+            if (P >= 1024) flip_sort_lds<BS>(tab, P);
+            else bitonic_sort_lds<BS>(tab, P);
             int *dst = tcol + s_off;
             for (int i = threadIdx.x; i < nz; i += BS) dst[i] = tab[i];
         }
@@ -612,7 +769,10 @@ __global__ __launch_bounds__(BS) void k_num_lean(const int *__restrict__ arpt, c
     }
     for (int i = n + threadIdx.x; i < P; i += BS) srt[i] = 0x7fffffff;
     __syncthreads();
-    if (P > 1 && !(write_col & 2)) bitonic_sort_lds<BS>(srt, P);
+    if (P > 1 && !(write_col & 2)) {
+        if (BS >= 512 && P >= 1024) flip_sort_lds<BS>(srt, P);  // (flip form: DPP / masked-write register stages)
+        else bitonic_sort_lds<BS>(srt, P);
+    }
     for (int i = threadIdx.x; i < n; i += BS) {
         const int key = srt[i];
         int h = lean_slot(key, shift, bits);
