@@ -14,6 +14,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+# GPU tests written in round 4 while the device pool was closed to this repository: they have never run on the
+# device.  They are scheduled BEHIND the tests that have (a stable partition of the collection order), so that under
+# `-x` a defect in a new test cannot hide the verdict of the 229 proven ones.
+ROUND4_UNPROVEN = ("test_bench_gpu.py", "test_aux_gpu.py", "test_native_row_partitioned_spgemm",
+                   "test_split_row_spmv_for_cache_resident_matrices", "test_hash_bins_both_kernel_families[3]",
+                   "test_big_table_bins_on_clustered_columns[3]", "test_one_wavefront_bin[3]")
+
+
+def pytest_collection_modifyitems(config, items):
+    new = [it for it in items if any(tag in it.nodeid for tag in ROUND4_UNPROVEN)]
+    if new:
+        old = [it for it in items if it not in new]
+        items[:] = old + new
+
+
 @pytest.fixture(scope="session")
 def oracle_d():
     from oracle.oracle import Oracle
