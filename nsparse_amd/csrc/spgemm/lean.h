@@ -770,7 +770,7 @@ __global__ __launch_bounds__(BS) void k_num_lean(const int *__restrict__ arpt, c
     for (int i = n + threadIdx.x; i < P; i += BS) srt[i] = 0x7fffffff;
     __syncthreads();
     if (P > 1 && !(write_col & 2)) {
-        if (BS >= 512 && P >= 1024) flip_sort_lds<BS>(srt, P);  // (flip form: DPP / masked-write register stages)
+        if (P >= 1024) flip_sort_lds<BS>(srt, P);  // (flip form: DPP / masked-write register stages)
         else bitonic_sort_lds<BS>(srt, P);
     }
     for (int i = threadIdx.x; i < n; i += BS) {
