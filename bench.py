@@ -279,17 +279,28 @@ def run_config(case, pmc, deadline):
     tot = {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         left = deadline - time.time()
-        if left < 25 or not os.path.exists(exe):
+        if left < 25 or not (os.path.exists(exe) or os.environ.get("NSPARSE_BENCH_DRYRUN") == "1"):
             rec["traffic"] = None
             rec["traffic_note"] = "PMC pass skipped: " + ("time budget" if left < 25 else "no rocprofv3")
             return rec
         td = tempfile.mkdtemp(prefix="nsp_pmc_", dir="/tmp")
         try:
-            rr = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "p", "--",
-                                 sys.executable, script, case, "--pmc-child"], cwd="/tmp",
-                                env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=min(left, 90.0))
-            if rr.returncode != 0:
-                raise RuntimeError(f"rc {rr.returncode}: {rr.stderr[-200:]}")
+            if os.environ.get("NSPARSE_BENCH_DRYRUN") == "1":
+                # what rocprofv3 leaves behind, in its layout: two launches per kernel (two calls were made)
+                os.makedirs(os.path.join(td, "host", "1"))
+                with open(os.path.join(td, "host", "1", "p_counter_collection.csv"), "w") as f:
+                    f.write('"Correlation_Id","Dispatch_Id","Agent_Id","Queue_Id","Process_Id","Thread_Id","Grid_Size",'
+                            '"Kernel_Id","Kernel_Name","Workgroup_Size","LDS_Block_Size","Scratch_Size","VGPR_Count",'
+                            '"Accum_VGPR_Count","SGPR_Count","Counter_Name","Counter_Value","Start_Timestamp","End_Timestamp"\n')
+                    for i, kn in enumerate(("void nsp::spgemm::k_num_tb<64, 256, 256, 0>(int const*, int)",
+                                            "void nsp::spgemm::k_sym_tb<64, 1024, 0>(int const*, int)") * 2):
+                        f.write(f'{i},{i},1,1,1,1,4096,{i % 2},"{kn}",64,0,0,32,0,16,"{counter}",{1000.0 + i},1,2\n')
+            else:
+                rr = subprocess.run([exe, "--pmc", counter, "--output-format", "csv", "-d", td, "-o", "p", "--",
+                                     sys.executable, script, case, "--pmc-child"], cwd="/tmp",
+                                    env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=min(left, 90.0))
+                if rr.returncode != 0:
+                    raise RuntimeError(f"rc {rr.returncode}: {rr.stderr[-200:]}")
             import csv
             per = {}
             for f in glob.glob(os.path.join(td, "**", "*counter_collection.csv"), recursive=True):
@@ -385,13 +396,26 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    t_start = time.time()
     import nsparse_amd as ns
     from nsparse_amd.dist import csr_row_block, row_partition, row_partition_nnz
     from nsparse_amd.rendezvous import Rendezvous
     assert "torch" not in sys.modules, "the measuring process must not import torch (it brings its own HIP / RCCL)"
-    lib = ns.load("d")
-    dl = ns.load_dist("d")
+    # NSPARSE_BENCH_DRYRUN=1 (tests, never a measurement): the whole control flow of this script on a box without a
+    # GPU -- tools/bench_dry.py stands in for everything that needs the device, on small matrices
+    dry = os.environ.get("NSPARSE_BENCH_DRYRUN") == "1"
+    if dry:
+        from tools import bench_dry
+        lib = bench_dry.DryLib("d")
+        dl = bench_dry.DryDist(lib)
+        args.no_vendor = True
+        log("[bench] NSPARSE_BENCH_DRYRUN=1: no device, made-up times -- a test of the harness, not a measurement")
+    else:
+        lib = ns.load("d")
+        dl = ns.load_dist("d")
     w = 8
+    planes = 5 if dry else 257            # mesh planes of the cant-class brick per rank (cant: 62,451 = 3 * 9 * 9 * 257 rows)
+    rows_rank = 3 * 9 * 9 * planes
     # NSPARSE_BENCH_EMULATE=1: the multi-rank control flow on fewer GPUs than ranks (tests; never a measurement)
     emulate = os.environ.get("NSPARSE_BENCH_EMULATE") == "1"
     ndev = int(dl.nsparse_dist_device_count())
@@ -403,13 +427,16 @@ def main():
             "configuration (RCCL refuses two ranks on one device).  NSPARSE_BENCH_EMULATE=1 runs the control flow "
             "of the multi-rank path on the GPUs that exist, as a test, without a communicator.")
         sys.exit(3)
-    lib.hip.hipSetDevice.argtypes = [C.c_int]
+    if not dry:
+        lib.hip.hipSetDevice.argtypes = [C.c_int]
     assert lib.hip.hipSetDevice(local_rank % ndev) == 0
     lib.nsparse_set_bin_timing(0)
     dl.nsparse_dist_set_timeout(float(os.environ.get("NSPARSE_DIST_TIMEOUT_S", "90")))
 
     # ---- ranks: rendezvous (host), then ONE communicator for the whole run -------------------------------------
     rdv = Rendezvous(rank, world, timeout=float(os.environ.get("NSPARSE_RDV_TIMEOUT_S", "120")))
+    if dry:
+        dl.attach(rdv)
     h = C.c_void_p()
     if world > 1 and not emulate:
         idb = C.create_string_buffer(ns.DIST_ID_BYTES)
@@ -454,9 +481,9 @@ def main():
         return reduce_ranks(x, 0)
 
     # ------------------------------------------------------------------ workload ----
-    nz = 257 * world
+    nz = planes * world
     M_glob = 9 * 9 * nz * 3
-    rows = (rank * 62451, (rank + 1) * 62451)
+    rows = (rank * rows_rank, (rank + 1) * rows_rank)
     t0 = time.time()
     kind, _, seed = STANDINS["cant"]
     A_full, src = load_or_synth(lib, "cant", kind, (9, 9, nz), seed) if world == 1 else \
@@ -523,7 +550,7 @@ def main():
     traffic_all = None
     if rank == 0 and world == 1 and not args.no_pmc:
         t0 = time.time()
-        traffic_all = pmc_traffic("bench")
+        traffic_all = bench_dry.pmc_traffic("bench") if dry else pmc_traffic("bench")
         log(f"[pmc] two passes in {time.time() - t0:.0f}s: {'ok' if traffic_all else 'unavailable'}")
     pats = NUM_KERNEL.get(dom, [f"numeric bin {dom}"])
     kname, tr = find_kernel(traffic_all, pats)
@@ -616,6 +643,7 @@ def main():
     regular = sweep = None
     if world == 1 and rank == 0 and not args.no_irregular:
         kind_b, dims_b, seed_b = STANDINS["cant_brick"]
+        dims_b = (9, 9, planes)
         regular = one_matrix(kind_b, dims_b, seed_b)
         regular["workload"] = ("synthetic cant-class, REGULAR: 9x9x257 brick of 3-dof nodes, natural numbering "
                                "(nsparse_synth_csr kind 0) -- round 2's headline matrix: every row in the narrowest "
@@ -628,10 +656,12 @@ def main():
                          "NSPARSE_TWINS=0 (no twin detection, no node-block kernel: the floor)",
                  "points": []}
         for pm in (0, 100, 300, 1000):
-            r6 = one_matrix(6, (9, 9, 257 + (pm << 32)), 0x5EED0022, phases=False)
+            r6 = one_matrix(6, (9, 9, planes + (pm << 32)), 0x5EED0022, phases=False)
             sweep["points"].append({"p": pm / 1000.0, "gflops": r6["value"], "ms": r6["ms_per_step"],
                                     "twin_rows": r6["twin_rows"], "nnz_A": r6["nnz_A"], "n_prod": r6["n_prod"]})
         try:
+            if dry:
+                raise RuntimeError("dry run: tools/one_gflops.py needs the device")
             r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "one_gflops.py"), "5", "9", "9", "257",
                                 str(args.steps)], env=dict(os.environ, NSPARSE_TWINS="0"), capture_output=True,
                                text=True, timeout=300, cwd=ROOT)
@@ -785,6 +815,8 @@ def main():
     spmv_hbm = None
     if not args.no_large:
         kind2, (gx, gy, gz), seed2 = STANDINS["nlpkkt120"]
+        if dry:
+            gx, gy, gz = 16, 16, 8
         M2 = gx * gy * gz
         # the stand-in has the same 27 entries in every interior row, so equal row counts ARE the
         # nnz-balanced cut; a file would be cut by its row pointers
@@ -902,6 +934,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if "synthetic" in src else "file",
             **({"emulated_ranks": "NSPARSE_BENCH_EMULATE=1: ranks share the GPUs that exist, no communicator -- a "
                                   "control-flow test, NOT a measurement"} if emulate and world > 1 else {}),
+            **({"dry_run": "NSPARSE_BENCH_DRYRUN=1: no device, every time and counter is made up (tools/bench_dry.py) -- "
+                           "a test of this script's control flow, NOT a measurement"} if dry else {}),
             "runtime": runtime_report(),
             "config": {"workload": f"{src}: 3-dof 27-pt FEM brick 9x9x{nz}, {M_glob} rows, C=A^2 by 1-D row blocks of 62451 rows"
                                    if "synthetic" in src else src,
@@ -933,6 +967,7 @@ def main():
             "vendor_baseline": vendor,
             "spmv": spmv,
             "spmv_hbm": spmv_hbm,
+            "wall_s": round(time.time() - t_start, 1),
         }
         C.CDLL(None).fflush(None)  # the library's own stdio lines ("Read mtx file: ...") go out first
         sys.stdout.flush()

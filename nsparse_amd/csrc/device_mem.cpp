@@ -275,7 +275,8 @@ Context &ctx()
         NSP_CHECK(hipHostMalloc((void **)&c.h_mapped, 256 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
         memset(c.h_mapped, 0, 256 * sizeof(int));
         NSP_CHECK(hipHostGetDevicePointer((void **)&c.d_mapped, c.h_mapped, 0));
-        NSP_CHECK(hipDeviceGetAttribute(&c.num_cus, hipDeviceAttributeMultiprocessorCount, current_device()));
+        c.device = dev;
+        NSP_CHECK(hipDeviceGetAttribute(&c.num_cus, hipDeviceAttributeMultiprocessorCount, dev));
         c.ready = true;
     }
     return c;

@@ -104,6 +104,8 @@ struct nsparse_dist {
     // barrier / small reductions among the ranks (device scratch: kReduceMax doubles + one int)
     double *d_red = nullptr;
     int *d_tick = nullptr;
+    double *h_red = nullptr;  // pinned twin of d_red (+ one int): copies to and from it are truly asynchronous, so
+                              // the host reaches the watchdog instead of blocking inside a pageable-memory copy
 };
 
 namespace {
@@ -190,6 +192,7 @@ void free_handle(nsparse_dist *h)
     if (h->ev[0]) (void)hipEventDestroy(h->ev[0]);
     if (h->ev[1]) (void)hipEventDestroy(h->ev[1]);
     if (h->d_red) (void)hipFree(h->d_red);
+    if (h->h_red) (void)hipHostFree(h->h_red);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -209,6 +212,7 @@ int new_handle(nsparse_dist **out, ncclComm_t comm, int rank, int world, int dev
     if (e == hipSuccess) e = hipEventCreate(&h->ev[1]);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_red, sizeof(double) * kReduceMax + sizeof(int) * 2);
     if (e == hipSuccess) e = hipMemset(h->d_red, 0, sizeof(double) * kReduceMax + sizeof(int) * 2);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h->h_red, sizeof(double) * (kReduceMax + 1), hipHostMallocDefault);
     if (e != hipSuccess) {
         if (comm) (void)ncclCommDestroy(comm);
         free_handle(h);
@@ -319,17 +323,20 @@ int nsparse_dist_init_all(nsparse_dist_t *handles, int world)
 {
     g_err = 0;
     if (!handles || world < 1) return g_err = -1;
+    int before = 0;
+    D_HIP(hipGetDevice(&before));  // (before the communicators exist: an early return owns nothing)
     std::vector<ncclComm_t> comms((size_t)world, nullptr);
     if (world > 1) D_NCCL(ncclCommInitAll(comms.data(), world, nullptr));  // devices 0 .. world-1
-    int before = 0;
-    D_HIP(hipGetDevice(&before));
     int rc = 0;
     for (int r = 0; r < world; r++) handles[r] = nullptr;
     for (int r = 0; r < world && rc == 0; r++) {
         const hipError_t e = hipSetDevice(r);
-        rc = e != hipSuccess ? fail_hip(e, "hipSetDevice", __LINE__) : new_handle(&handles[r], comms[r], r, world, r);
-        if (rc == 0) comms[r] = nullptr;  // owned by the handle now (new_handle destroys it when it fails)
-        else if (e != hipSuccess && comms[r]) (void)ncclCommDestroy(comms[r]), comms[r] = nullptr;
+        if (e != hipSuccess) {
+            rc = fail_hip(e, "hipSetDevice", __LINE__);
+            break;  // comms[r] is still ours: destroyed below
+        }
+        rc = new_handle(&handles[r], comms[r], r, world, r);
+        comms[r] = nullptr;  // new_handle owns the communicator whatever it returns (it destroys it when it fails)
     }
     if (rc) {  // nothing half-built survives: handles made so far, communicators not yet handed over
         for (int r = 0; r < world; r++) {
@@ -406,12 +413,11 @@ int nsparse_dist_spmv_setup(nsparse_dist_t h, sfCSR *a_local, const int *cuts, r
         }
     }
     if (m_local > 0) {
-        // synchronous; takes the product library's API lock.  Its error word is per THREAD-OF-CALL state of that
-        // library: compare before / after instead of reading a value another rank's thread may have left there
-        const int before = nsparse_last_error();
+        // synchronous; takes the product library's API lock.  The callee clears its error word (per calling thread)
+        // on entry, so anything but 0 afterwards is THIS call's failure -- also when it repeats an earlier code
         sf_csr2amb(&h->amb, a_local, d_x_any, plan);
         const int after = nsparse_last_error();
-        if (after != 0 && after != before) {
+        if (after != 0) {
             if (staged) (void)hipFree(staged);
             if (d_cuts) (void)hipFree(d_cuts);
             memset(&h->amb, 0, sizeof(h->amb));
@@ -523,10 +529,13 @@ int nsparse_dist_allreduce_f64(nsparse_dist_t h, double *vals, int n, int op)
 {
     if (!h || !vals || n < 0 || n > kReduceMax || (op != 0 && op != 1)) return g_err = -1;
     if (!h->comm || h->world == 1 || n == 0) return h->world == 1 || n == 0 ? 0 : (g_err = -4);
-    D_HIP(hipMemcpyAsync(h->d_red, vals, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+    memcpy(h->h_red, vals, sizeof(double) * (size_t)n);
+    D_HIP(hipMemcpyAsync(h->d_red, h->h_red, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, h->stream));
     D_NCCL(ncclAllReduce(h->d_red, h->d_red, (size_t)n, ncclDouble, op == 0 ? ncclSum : ncclMax, h->comm, h->stream));
-    D_HIP(hipMemcpyAsync(vals, h->d_red, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
-    return sync_watch(h);
+    D_HIP(hipMemcpyAsync(h->h_red, h->d_red, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    const int rc = sync_watch(h);  // pinned on both sides: nothing above blocks the host, a missing peer ends here (-7)
+    if (rc == 0) memcpy(vals, h->h_red, sizeof(double) * (size_t)n);
+    return rc;
 }
 
 int nsparse_dist_spmv_loop(nsparse_dist_t h, real *d_y, const real *d_x, int gather, int iters,
@@ -583,10 +592,14 @@ int nsparse_dist_spgemm(nsparse_dist_t h, sfCSR *a_block, sfCSR *b, sfCSR *c_blo
 {
     g_err = 0;
     if (!h || !a_block || !b || !c_block) return g_err = -1;
-    const int before = nsparse_last_error();
     spgemm_kernel_hash(a_block, b, c_block);  // synchronous; an empty block gives an empty C of a_block->M rows
+    // the callee clears its (per-thread) error word on entry: non-zero now = this call failed, c_block is not a result
     const int after = nsparse_last_error();
-    return (after != 0 && after != before) ? (g_err = after) : 0;
+    if (after != 0) {
+        memset(c_block, 0, sizeof(*c_block));
+        return g_err = after;
+    }
+    return 0;
 }
 
 namespace {
@@ -625,40 +638,83 @@ int nsparse_dist_spgemm_gather(nsparse_dist_t h, const int *cuts, const sfCSR *c
     if (total > 0x7fffffffLL) return g_err = -40;  // sfCSR keeps nnz and rpt in int (as the single-GPU call refuses)
     const int M = cuts[world];
     memset(c_full, 0, sizeof(*c_full));
+    // Every array exists on every rank BEFORE the first broadcast: the ranks agree on that with one more all-reduce,
+    // so an allocation failure anywhere is an error everywhere instead of peers parked inside ncclBroadcast.
+    int *f_rpt = nullptr, *f_col = nullptr;
+    real *f_val = nullptr;
+    hipError_t ae = hipMalloc((void **)&f_rpt, sizeof(int) * ((size_t)M + 1));
+    if (ae == hipSuccess) ae = hipMalloc((void **)&f_col, sizeof(int) * (size_t)(total > 0 ? total : 1));
+    if (ae == hipSuccess) ae = hipMalloc((void **)&f_val, sizeof(real) * (size_t)(total > 0 ? total : 1));
+    auto drop = [&]() {
+        if (f_rpt) (void)hipFree(f_rpt);
+        if (f_col) (void)hipFree(f_col);
+        if (f_val) (void)hipFree(f_val);
+        memset(c_full, 0, sizeof(*c_full));
+    };
+    double bad = ae == hipSuccess ? 0.0 : 1.0;
+    if (world > 1) {
+        const int rc = nsparse_dist_allreduce_f64(h, &bad, 1, 1);
+        if (rc) {
+            drop();
+            return rc;
+        }
+    }
+    if (bad != 0.0) {
+        drop();
+        return ae != hipSuccess ? fail_hip(ae, "hipMalloc of the gathered C", __LINE__) : (g_err = -2);  // -2: a peer could not
+    }
+    hipStream_t st = h->stream;
+    int rc = 0;
+#define G_HIP(x)                                                              \
+    do {                                                                      \
+        hipError_t e_ = (x);                                                  \
+        if (rc == 0 && e_ != hipSuccess) rc = fail_hip(e_, #x, __LINE__);     \
+    } while (0)
+#define G_NCCL(x)                                                             \
+    do {                                                                      \
+        ncclResult_t r_ = (x);                                                \
+        if (rc == 0 && r_ != ncclSuccess) rc = fail_nccl(r_, #x, __LINE__);   \
+    } while (0)
+    for (int r = 0; r < world && rc == 0; r++) {
+        const int m = cuts[r + 1] - cuts[r];
+        const long long z = (long long)sizes[r];
+        int *rpt_dst = f_rpt + cuts[r];
+        if (world > 1) {
+            // rows of rank r: its m row starts (the end of the last row is the start of the next block's first)
+            if (m > 0) G_NCCL(ncclBroadcast(c_block->d_rpt, rpt_dst, (size_t)m, ncclInt, r, h->comm, st));
+            if (z > 0 && rc == 0) G_NCCL(ncclBroadcast(c_block->d_col, f_col + off[r], (size_t)z, ncclInt, r, h->comm, st));
+            if (z > 0 && rc == 0) G_NCCL(ncclBroadcast(c_block->d_val, f_val + off[r], (size_t)z, kNcclReal, r, h->comm, st));
+        } else {
+            if (m > 0) G_HIP(hipMemcpyAsync(rpt_dst, c_block->d_rpt, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, st));
+            if (z > 0) {
+                G_HIP(hipMemcpyAsync(f_col, c_block->d_col, sizeof(int) * (size_t)z, hipMemcpyDeviceToDevice, st));
+                G_HIP(hipMemcpyAsync(f_val, c_block->d_val, sizeof(real) * (size_t)z, hipMemcpyDeviceToDevice, st));
+            }
+        }
+        if (m > 0 && off[r] > 0 && rc == 0) {
+            hipLaunchKernelGGL(k_shift_rpt, dim3((m + 255) / 256), dim3(256), 0, st, rpt_dst, m, (int)off[r]);
+            G_HIP(hipGetLastError());
+        }
+    }
+    int *h_last = reinterpret_cast<int *>(h->h_red + kReduceMax);  // pinned: the copy below reads it after we return from the call
+    *h_last = (int)total;
+    G_HIP(hipMemcpyAsync(f_rpt + M, h_last, sizeof(int), hipMemcpyHostToDevice, st));
+#undef G_HIP
+#undef G_NCCL
+    const int wrc = sync_watch(h);  // also after an enqueue error: what was queued must be off the arrays before they go
+    if (rc == 0) rc = wrc;
+    if (rc) {  // a broadcast that failed half-way: nothing half-filled is handed out (peers end by their watchdog)
+        drop();
+        return rc;
+    }
     c_full->M = M;
     c_full->N = c_block->N;
     c_full->nnz = (int)total;
     c_full->nnz_max = c_block->nnz_max;  // (a hint: the longest row of THIS rank's block)
-    D_HIP(hipMalloc((void **)&c_full->d_rpt, sizeof(int) * ((size_t)M + 1)));
-    D_HIP(hipMalloc((void **)&c_full->d_col, sizeof(int) * (size_t)(total > 0 ? total : 1)));
-    D_HIP(hipMalloc((void **)&c_full->d_val, sizeof(real) * (size_t)(total > 0 ? total : 1)));
-    hipStream_t st = h->stream;
-    for (int r = 0; r < world; r++) {
-        const int m = cuts[r + 1] - cuts[r];
-        const long long z = (long long)sizes[r];
-        int *rpt_dst = c_full->d_rpt + cuts[r];
-        if (world > 1) {
-            // rows of rank r: its m row starts (the end of the last row is the start of the next block's first)
-            if (m > 0) D_NCCL(ncclBroadcast(c_block->d_rpt, rpt_dst, (size_t)m, ncclInt, r, h->comm, st));
-            if (z > 0) {
-                D_NCCL(ncclBroadcast(c_block->d_col, c_full->d_col + off[r], (size_t)z, ncclInt, r, h->comm, st));
-                D_NCCL(ncclBroadcast(c_block->d_val, c_full->d_val + off[r], (size_t)z, kNcclReal, r, h->comm, st));
-            }
-        } else {
-            if (m > 0) D_HIP(hipMemcpyAsync(rpt_dst, c_block->d_rpt, sizeof(int) * (size_t)m, hipMemcpyDeviceToDevice, st));
-            if (z > 0) {
-                D_HIP(hipMemcpyAsync(c_full->d_col, c_block->d_col, sizeof(int) * (size_t)z, hipMemcpyDeviceToDevice, st));
-                D_HIP(hipMemcpyAsync(c_full->d_val, c_block->d_val, sizeof(real) * (size_t)z, hipMemcpyDeviceToDevice, st));
-            }
-        }
-        if (m > 0 && off[r] > 0) {
-            hipLaunchKernelGGL(k_shift_rpt, dim3((m + 255) / 256), dim3(256), 0, st, rpt_dst, m, (int)off[r]);
-            D_HIP(hipGetLastError());
-        }
-    }
-    const int last = (int)total;
-    D_HIP(hipMemcpyAsync(c_full->d_rpt + M, &last, sizeof(int), hipMemcpyHostToDevice, st));
-    return sync_watch(h);
+    c_full->d_rpt = f_rpt;
+    c_full->d_col = f_col;
+    c_full->d_val = f_val;
+    return 0;
 }
 
 void nsparse_dist_release_gathered(sfCSR c_full)

@@ -20,8 +20,10 @@
 
 namespace nsp {
 
-static int g_err = 0;
-static std::string g_err_msg;
+// The error side channel is per calling thread: a caller reads the word of ITS last call, whatever other threads
+// (one per GPU in amb_dist) did in between.  The product library starts no threads of its own.
+static thread_local int g_err = 0;
+static thread_local std::string g_err_msg;
 
 void set_error(int code, const char *what, const char *file, int line)
 {

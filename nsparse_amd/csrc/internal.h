@@ -79,6 +79,7 @@ struct Context {
     int *h_mapped = nullptr;            // 256 ints of mapped, coherent host memory (GPU writes, host polls)
     int *d_mapped = nullptr;            // device address of h_mapped
     int seq = 0;                        // publish sequence number
+    int device = -1;                    // the device this context belongs to
     int num_cus = 0;                    // compute units of the device
     int coresident = -1;                // 1024-thread workgroups resident together as this process sees the device
                                         // (census on first use: CU masks, partitions); grid barriers need every one resident

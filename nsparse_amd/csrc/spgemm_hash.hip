@@ -347,14 +347,25 @@ struct BinLauncher {
     }
 };
 
-// Dynamic LDS above 64 KiB has to be allowed per kernel function, once.
+// Dynamic LDS above 64 KiB has to be allowed per kernel function, once -- per DEVICE: the attribute belongs to the
+// function as loaded on the device that is current (one process driving several GPUs, nsparse_dist_init_all, sets it
+// on each).  One bit per device of the per-device tables; callers hold the API lock.
+struct DevOnce {
+    unsigned long long w[2] = {0, 0};
+    bool test_and_set(int d)
+    {
+        const unsigned long long bit = 1ULL << (d & 63);
+        const bool was = (w[(d >> 6) & 1] & bit) != 0;
+        w[(d >> 6) & 1] |= bit;
+        return was;
+    }
+};
 template <typename K>
-static void allow_big_lds(K kernel, bool &done, int bytes_max)
+static void allow_big_lds(K kernel, DevOnce &done, int bytes_max, int device)
 {
-    if (done) return;
+    if (done.test_and_set(device)) return;
     NSP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   bytes_max));
-    done = true;
 }
 
 static int global_slab_groups(long long slice_elems, size_t bytes_per_elem, int rows)
@@ -428,8 +439,8 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
 #define NSP_SYM_DENSE(BIN, BS, SPAN)                                                            \
     if (hist[BIN] > 0 && now(BIN)) {                                                                       \
         hipStream_t st = L.begin(BIN);                                                         \
-        static bool big_ok = false;                                                            \
-        allow_big_lds(k_sym_dense<BS, SPAN>, big_ok, SPAN + 64);                               \
+        static DevOnce big_ok;                                                                   \
+        allow_big_lds(k_sym_dense<BS, SPAN>, big_ok, SPAN + 64, cx.device);                               \
         const int span_b = max_span[BIN] < SPAN ? max_span[BIN] : SPAN;                        \
         const size_t lds = sizeof(int) * (size_t)((span_b + 63) / 64 * 16 + 16);               \
         hipLaunchKernelGGL((k_sym_dense<BS, SPAN>), dim3(8 * ceil_div(hist[BIN], 8)), dim3(BS), lds, st, \
@@ -692,8 +703,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     {                                                                                          \
         /* the first kernel keeps at most two bitmap words per lane: widest windows need 512 threads */ \
         constexpr int BSO = (SPAN / (BS / 64) + 2047) / 2048 <= 2 ? BS : 512;                  \
-        static bool big_ok = false;                                                            \
-        allow_big_lds(k_num_dense<BSO, SPAN, MODEX>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
+        static DevOnce big_ok;                                                                   \
+        allow_big_lds(k_num_dense<BSO, SPAN, MODEX>, big_ok, (int)sizeof(acc_t) * (SPAN + 64), cx.device); \
         hipLaunchKernelGGL((k_num_dense<BSO, SPAN, MODEX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BSO), \
                            lds, st, arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col,      \
                            c->d_val, row_perm, row_prod, row_maxb, row_lo, row_span, off[bin_],  \
@@ -701,8 +712,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     }
 #define NSP_NUM_BLOCK_GO2(BS, SPAN, MODEX, KEYEDX)                                               \
     {                                                                                          \
-        static bool big_ok = false;                                                            \
-        allow_big_lds(k_num_block<BS, SPAN, MODEX, kBlkU, KEYEDX>, big_ok, (int)sizeof(acc_t) * (SPAN + 64)); \
+        static DevOnce big_ok;                                                                   \
+        allow_big_lds(k_num_block<BS, SPAN, MODEX, kBlkU, KEYEDX>, big_ok, (int)sizeof(acc_t) * (SPAN + 64), cx.device); \
         /* followers of a group head are not listed (k_bin_scatter): listed[bin] heads */        \
         const int heads = grp ? listed[bin_] : hist[bin_];                                     \
         /* fold6_: the rows of bin 6 ride along (their stretch of the list first) */             \
@@ -942,8 +953,8 @@ static int census_coresident(Context &cx, hipStream_t st)
 {
     int *d = cx.d_scratch + 8000;  // two ints behind the workgroup records of the fused tails
     int grid = cx.num_cus < kFusedMaxBlocks ? cx.num_cus : kFusedMaxBlocks;
-    static bool big_ok = false;
-    allow_big_lds(k_census, big_ok, kCensusLds);  // one census workgroup per CU (fused.h)
+    static DevOnce big_ok;       
+    allow_big_lds(k_census, big_ok, kCensusLds, cx.device);  // one census workgroup per CU (fused.h)
     for (; grid >= 8; grid = grid * 3 / 4) {
         NSP_CHECK(hipMemsetAsync(d, 0, 2 * sizeof(int), st));
         hipLaunchKernelGGL(k_census, dim3(grid), dim3(1024), kCensusLds, st, d, 20000 /* 0.2 ms of 100 MHz ticks */);

@@ -79,6 +79,108 @@ def test_a_rank_that_stops_answering_times_out(tmp_path):
     assert errs and "second barrier" in errs[0]
 
 
+def test_strangers_are_dropped_at_the_door(tmp_path):
+    """Advisor r04: the socket is on localhost and anyone can connect.  A connection without the job's token, with a
+    rank outside 1..world-1, with a rank that has already joined, or with bytes that are not a message must be
+    dropped without disturbing the rendezvous; nothing received is unpickled (a pickle is just malformed JSON)."""
+    import json
+    import pickle
+    import socket
+    import struct
+    d = str(tmp_path / "rdv")
+    res = {}
+
+    def rank0():
+        rdv = Rendezvous(0, 2, directory=d, timeout=20.0)
+        res["sum"] = rdv.allreduce([1.0], "sum")
+        res["rejected"] = rdv.rejected
+        rdv.close()
+    t = threading.Thread(target=rank0)
+    t.start()
+    port_file = os.path.join(d, "port")
+    for _ in range(2000):
+        if os.path.exists(port_file):
+            break
+        time.sleep(0.005)
+    port, token = open(port_file).read().split()
+    assert os.stat(d).st_mode & 0o077 == 0 and os.stat(port_file).st_mode & 0o077 == 0
+
+    def knock(payload):
+        c = socket.create_connection(("127.0.0.1", int(port)), timeout=5)
+        c.sendall(struct.pack("<I", len(payload)) + payload)
+        try:
+            assert c.recv(1) == b""  # closed by rank 0, nothing sent back
+        except (ConnectionResetError, socket.timeout):
+            pass
+        c.close()
+
+    class Boom:
+        def __reduce__(self):
+            return (os.system, ("touch %s" % (tmp_path / "pwned"),))
+    knock(pickle.dumps(Boom()))
+    knock(json.dumps({"rank": 1, "token": "0" * 32}).encode())
+    knock(json.dumps({"rank": 7, "token": token}).encode())
+    knock(json.dumps({"rank": 0, "token": token}).encode())
+    knock(json.dumps({"rank": True, "token": token}).encode())
+    knock(json.dumps([1, token]).encode())
+    c = socket.create_connection(("127.0.0.1", int(port)), timeout=5)
+    c.sendall(struct.pack("<I", 1 << 30))  # an absurd length is refused before anything is buffered
+    c.close()
+    rdv1 = Rendezvous(1, 2, directory=d, timeout=20.0)
+    assert rdv1.allreduce([2.0], "sum") == [3.0]
+    rdv1.close()
+    t.join(30)
+    assert res["sum"] == [3.0] and res["rejected"] == 7
+    assert not (tmp_path / "pwned").exists()
+
+
+def test_a_duplicate_rank_is_dropped(tmp_path):
+    """Two processes claiming rank 1: the first joins, the second is dropped and times out instead of replacing it."""
+    d = str(tmp_path / "rdv")
+    got = {}
+
+    def rank0():
+        try:
+            Rendezvous(0, 3, directory=d, timeout=2.0)
+        except RendezvousError as e:
+            got["e"] = str(e)
+    t = threading.Thread(target=rank0)
+    t.start()
+    a = Rendezvous(1, 3, directory=d, timeout=5.0)
+    b = Rendezvous(1, 3, directory=d, timeout=5.0)  # connects; rank 0 closes it
+    t.join(10)
+    assert "ranks [2]" in got["e"]
+    a.close()
+    b.close()
+
+
+def test_a_directory_of_somebody_else_is_refused(tmp_path):
+    """A rendezvous directory that others can enter (pre-created 0777, or a symlink) is an error on every rank."""
+    loose = tmp_path / "loose"
+    loose.mkdir()
+    os.chmod(loose, 0o777)
+    with pytest.raises(RendezvousError, match="not a private directory"):
+        Rendezvous(0, 2, directory=str(loose), timeout=1.0)
+    (loose / "port").write_text("1 x")
+    with pytest.raises(RendezvousError, match="not a private directory"):
+        Rendezvous(1, 2, directory=str(loose), timeout=1.0)
+    real = tmp_path / "real"
+    real.mkdir(mode=0o700)
+    link = tmp_path / "link"
+    link.symlink_to(real)
+    with pytest.raises(RendezvousError, match="not a private directory"):
+        Rendezvous(0, 2, directory=str(link), timeout=1.0)
+
+
+def test_only_plain_data_travels():
+    from nsparse_amd import rendezvous as R
+    src = open(R.__file__).read()
+    assert "pickle" not in src.replace("unpickled", "").replace("(a pickle", "")
+    assert R._dec(R._enc([b"\x00\xff", 1.5, True, None, "s", [1, 2]])) == [b"\x00\xff", 1.5, True, None, "s", [1, 2]]
+    with pytest.raises(TypeError):
+        R._enc(object())
+
+
 def test_bench_is_torch_free():
     src = open(os.path.join(ROOT, "bench.py")).read()
     code = "\n".join(ln for ln in src.splitlines() if not ln.lstrip().startswith("#"))

@@ -62,6 +62,15 @@ def matrix(lib, name):
 def main():
     name = sys.argv[1]
     pmc_child = "--pmc-child" in sys.argv
+    if os.environ.get("NSPARSE_BENCH_DRYRUN") == "1":
+        # bench.py's dry run (tools/bench_dry.py): the sub-process plumbing with a canned record, no device
+        from tools.bench_dry import CANNED_CONFIG
+        if not pmc_child:
+            rec = dict(CANNED_CONFIG, case=name, baseline_config=CASES[name][4], workload=f"dry run {name}",
+                       dtype="f64" if CASES[name][0] == "d" else "f32")
+            print(json.dumps(dict(rec, structure_check=None)), flush=True)
+            print(json.dumps(rec), flush=True)
+        return
     steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 0
     prec = CASES[name][0]
     w = 8 if prec == "d" else 4
