@@ -600,7 +600,11 @@ __device__ __forceinline__ int wave_incl_scan(int v)
 
 __device__ __forceinline__ void lds_barrier()
 {
+#ifndef NSP_EMU
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#else
+    __syncthreads();  // tests/emu: the CPU emulation knows one workgroup barrier
+#endif
 }
 
 // ---- column lists (round 3) -----------------------------------------------------------------------------

@@ -96,7 +96,11 @@ __device__ __forceinline__ bool grid_barrier(const FusedSync &fs, int *s_ok)
 constexpr int kCensusLds = 96 * 1024;
 __global__ __launch_bounds__(1024) void k_census(int *out, int limit_ticks)
 {
+#ifndef NSP_EMU
     extern __shared__ int s_census_pad[];
+#else
+    int *s_census_pad = reinterpret_cast<int *>(::emu::t_dyn_lds);  // tests/emu
+#endif
     if (threadIdx.x == 1023 && limit_ticks < 0) s_census_pad[0] = 0;  // (keeps the allocation alive)
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(out, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
@@ -182,9 +186,13 @@ __device__ __forceinline__ void fused_tail(int *s_base, int *s_pref /* kFusedRec
         static_assert(words <= 64, "one word per lane");
         const int *s = reinterpret_cast<const int *>(bs);
         if (lane < words) fs.pub_dst[lane] = ld_agent(s + lane);
+        // program order of this wavefront, said aloud (scheduling barriers: no instruction; the sync points of
+        // tests/emu): lane 0's word lands after the copy of the same word, the flag after every lane's word
+        __builtin_amdgcn_wave_barrier();
         if (set_nnz && lane == 0)
             reinterpret_cast<BinState *>(fs.pub_dst)->nnz = ld_agent(reinterpret_cast<const int *>(&bs->total));
         __threadfence_system();
+        __builtin_amdgcn_wave_barrier();
         if (lane == 0) __hip_atomic_store(fs.pub_flag, fs.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();

@@ -320,6 +320,7 @@ __device__ __forceinline__ void lean_insert4(int *tab, int mask, int shift, int 
 // Compare-exchange against the partner a DPP pattern names: min and max with the pattern folded into the instruction
 // (the compiler turns update_dpp + min + max into copy, v_mov_dpp, v_min, v_max, v_cndmask: five instructions; here
 // three).  s_nop 1: a DPP operand written by the VALU instruction before needs two wait states on gfx9.
+#ifndef NSP_EMU
 #define NSP_CEX_DPP(x, lower, CTRL)                                                                          \
     do {                                                                                                     \
         int lo_, hi_;                                                                                        \
@@ -336,6 +337,38 @@ __device__ __forceinline__ void lean_insert4(int *tab, int mask, int shift, int 
     asm("v_min_i32_dpp %0, %1, %0 quad_perm:[0,1,2,3] " LO "\n\tv_max_i32_dpp %0, %1, %0 quad_perm:[0,1,2,3] " HI \
         : "+v"(x)                                                                                            \
         : "v"(q))
+// ... of x against the DPP partner of a SECOND register y (the eight-per-lane LDS sort below)
+#define NSP_CEX_DPP2(out, x, y, lower, CTRL)                                                                 \
+    do {                                                                                                     \
+        int lo_, hi_;                                                                                        \
+        asm("s_nop 1\n\tv_min_i32_dpp %0, %3, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                   \
+            "v_max_i32_dpp %1, %3, %2 " CTRL " row_mask:0xf bank_mask:0xf"                                   \
+            : "=&v"(lo_), "=&v"(hi_)                                                                         \
+            : "v"(x), "v"(y));                                                                               \
+        out = (lower) ? lo_ : hi_;                                                                           \
+    } while (0)
+#else
+// tests/emu (lane-by-lane CPU emulation of the kernels, test infrastructure): the SAME operand strings, interpreted
+// with the instruction's rules (a lane the masks disable or whose DPP source is invalid is not written: 0x7fffdead
+// shows up in the result if the sort ever relied on one)
+#define NSP_CEX_DPP(x, lower, CTRL)                                                                          \
+    do {                                                                                                     \
+        const int lo_ = emu_dpp_asm(false, 0x7fffdead, x, x, CTRL " row_mask:0xf bank_mask:0xf");             \
+        const int hi_ = emu_dpp_asm(true, 0x7fffdead, x, x, CTRL " row_mask:0xf bank_mask:0xf");              \
+        x = (lower) ? lo_ : hi_;                                                                             \
+    } while (0)
+#define NSP_CEX_MASKED(x, q, LO, HI)                                                                         \
+    do {                                                                                                     \
+        x = emu_dpp_asm(false, x, q, x, "quad_perm:[0,1,2,3] " LO);                                           \
+        x = emu_dpp_asm(true, x, q, x, "quad_perm:[0,1,2,3] " HI);                                            \
+    } while (0)
+#define NSP_CEX_DPP2(out, x, y, lower, CTRL)                                                                 \
+    do {                                                                                                     \
+        const int lo_ = emu_dpp_asm(false, 0x7fffdead, y, x, CTRL " row_mask:0xf bank_mask:0xf");             \
+        const int hi_ = emu_dpp_asm(true, 0x7fffdead, y, x, CTRL " row_mask:0xf bank_mask:0xf");              \
+        out = (lower) ? lo_ : hi_;                                                                           \
+    } while (0)
+#endif
 
 // P = pow2 >= 2 elements; r1 is touched only when P == 128
 template <int P>
@@ -441,16 +474,6 @@ __device__ __forceinline__ void wave_sort128(int &r0, int &r1, int P, int lane)
 // their flip and their distances >= 512 through LDS with a workgroup barrier each, then the distances 256 .. 1 in
 // registers again.  (numpy model of exactly this decomposition: DESIGN 4.1.)  The round-3 profile of the 8192-slot
 // numeric bin had the sort at 16 of the 41 us of a row.
-#define NSP_CEX_DPP2(out, x, y, lower, CTRL)                                                                 \
-    do {                                                                                                     \
-        int lo_, hi_;                                                                                        \
-        asm("s_nop 1\n\tv_min_i32_dpp %0, %3, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                   \
-            "v_max_i32_dpp %1, %3, %2 " CTRL " row_mask:0xf bank_mask:0xf"                                   \
-            : "=&v"(lo_), "=&v"(hi_)                                                                         \
-            : "v"(x), "v"(y));                                                                               \
-        out = (lower) ? lo_ : hi_;                                                                           \
-    } while (0)
-
 template <int BS>
 __device__ __forceinline__ void flip_sort_lds(int *s, int P)
 {

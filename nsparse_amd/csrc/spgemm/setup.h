@@ -612,6 +612,9 @@ __global__ __launch_bounds__(64) void k_publish(const BinState *__restrict__ src
 {
     const int *s = reinterpret_cast<const int *>(src);
     for (int i = threadIdx.x; i < words; i += 64) dst[i] = s[i];
+    // lane 0's store below must land after the copy of the same word by another lane of this (one) wavefront: program
+    // order of the wavefront -- said aloud (no instruction: a scheduling barrier, and the sync point of tests/emu)
+    __builtin_amdgcn_wave_barrier();
     if (nnz_src && threadIdx.x == 0) reinterpret_cast<BinState *>(dst)->nnz = *nnz_src;
     __threadfence_system();
     __syncthreads();

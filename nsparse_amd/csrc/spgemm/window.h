@@ -6,7 +6,11 @@
 namespace nsp {
 namespace spgemm {
 
+#ifndef NSP_EMU
 extern __shared__ __attribute__((aligned(16))) unsigned char nsp_dyn_lds[];
+#else
+#define nsp_dyn_lds (::emu::t_dyn_lds)  // tests/emu: the dynamic LDS of the workgroup the CPU emulation is running
+#endif
 
 // ===================================================================================
 //  dense-window rows (bins 6..8)
