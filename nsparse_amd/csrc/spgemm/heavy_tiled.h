@@ -199,6 +199,9 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                     if (fresh[s]) {  // chunk A used up: B moves in, the one after B is requested
                         const int i = w + s * NW;
                         int4 mt = l_meta[i];
+                        // every lane has read the record before lane 0 advances it: program order of the wavefront,
+                        // said aloud (a scheduling barrier, no instruction; the sync point of tests/emu)
+                        __builtin_amdgcn_wave_barrier();
                         mt.x += mt.z;
                         if (lane == 0) l_meta[i].x = mt.x;
                         pa_col[s] = pb_col[s];

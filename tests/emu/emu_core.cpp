@@ -20,6 +20,11 @@
 #include <unistd.h>
 #include <sys/mman.h>
 
+struct ihipStream_t {
+    bool capturing = false;
+    std::shared_ptr<std::vector<std::function<void()>>> rec;  // operations recorded while capturing
+};
+
 namespace emu {
 
 thread_local Idx t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
@@ -420,8 +425,23 @@ static void worker_main()
     }
 }
 
-void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, std::function<void()> body)
+bool capture_record(hipStream_t st, std::function<void()> fn)
 {
+    if (!st || !st->capturing) return false;
+    st->rec->push_back(std::move(fn));
+    return true;
+}
+
+// kernels of different host threads (one per fake device in samples/amb_dist.cpp) run one after the other
+static std::mutex &g_launch_mu = *new std::mutex;
+
+void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream, std::function<void()> body)
+{
+    if (stream && stream->capturing) {
+        stream->rec->push_back([=] { launch(name, grid, block, lds_bytes, nullptr, body); });
+        return;
+    }
+    std::lock_guard<std::mutex> launch_lk(g_launch_mu);
     install_trap();
     if (grid.y != 1 || grid.z != 1) {
         fprintf(stderr, "emu: only 1-D grids are modelled\n");
@@ -464,10 +484,10 @@ struct Ev {
 };
 thread_local int t_device = 0;
 }  // namespace
-struct ihipStream_t { int id; };
+
 struct ihipEvent_t { std::chrono::steady_clock::time_point t; };
-struct ihipGraph { int x; };
-struct ihipGraphExec { int x; };
+struct ihipGraph { std::shared_ptr<std::vector<std::function<void()>>> ops; };
+struct ihipGraphExec { std::shared_ptr<std::vector<std::function<void()>>> ops; };
 struct ihipMemPool { int x; };
 
 constexpr size_t kGuard = 256;
@@ -534,14 +554,33 @@ hipError_t hipHostMalloc(void **p, size_t n, unsigned) { return hipMalloc(p, n);
 hipError_t hipHostFree(void *p) { return hipFree(p); }
 hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
 hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { if (n) memmove(d, s, n); return hipSuccess; }
-hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t) { return hipMemcpy(d, s, n, k); }
+hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind k, hipStream_t st)
+{
+    if (emu::capture_record(st, [=] { (void)hipMemcpy(d, s, n, k); })) return hipSuccess;
+    return hipMemcpy(d, s, n, k);
+}
 hipError_t hipMemset(void *d, int v, size_t n) { if (n) memset(d, v, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { return hipMemset(d, v, n); }
+hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t st)
+{
+    if (emu::capture_record(st, [=] { (void)hipMemset(d, v, n); })) return hipSuccess;
+    return hipMemset(d, v, n);
+}
 hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = (size_t)8 << 30; *t = (size_t)16 << 30; return hipSuccess; }
 hipError_t hipDeviceSynchronize(void) { return hipSuccess; }
-hipError_t hipSetDevice(int d) { if (d != 0) return hipErrorInvalidDevice; t_device = d; return hipSuccess; }
+static int emu_devices()
+{
+    static const int n = [] {
+        const char *e = getenv("EMU_DEVICES");
+        const int v = e ? atoi(e) : 8;
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    return n;
+}
+// EMU_DEVICES fake devices (default 8): all of them are this host's memory and the one worker pool -- what differs
+// is the library's per-device state (contexts, block caches, communicators), which is what the tests are after
+hipError_t hipSetDevice(int d) { if (d < 0 || d >= emu_devices()) return hipErrorInvalidDevice; t_device = d; return hipSuccess; }
 hipError_t hipGetDevice(int *d) { *d = t_device; return hipSuccess; }
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+hipError_t hipGetDeviceCount(int *n) { *n = emu_devices(); return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int)
 {
     *v = a == hipDeviceAttributeMultiprocessorCount ? emu::workers() : 0;
@@ -550,18 +589,44 @@ hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int)
 hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = -1; return hipSuccess; }
 hipError_t hipDeviceGetDefaultMemPool(hipMemPool_t *p, int) { static ihipMemPool pool; *p = &pool; return hipSuccess; }
 hipError_t hipMemPoolSetAttribute(hipMemPool_t, hipMemPoolAttr, void *) { return hipSuccess; }
-hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new ihipStream_t{1}; return hipSuccess; }
-hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = new ihipStream_t{1}; return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new ihipStream_t; return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = new ihipStream_t; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-hipError_t hipStreamBeginCapture(hipStream_t, hipStreamCaptureMode) { return hipErrorNotSupported; }
-hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t *g) { *g = nullptr; return hipErrorNotSupported; }
-hipError_t hipGraphInstantiate(hipGraphExec_t *, hipGraph_t, void *, void *, size_t) { return hipErrorNotSupported; }
-hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
-hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
-hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+// stream capture: what is queued on a capturing stream (kernels, async copies / fills, the collectives of the RCCL
+// stand-in) is recorded as closures and replayed in order by hipGraphLaunch
+hipError_t hipStreamBeginCapture(hipStream_t s, hipStreamCaptureMode)
+{
+    if (!s || s->capturing) return hipErrorInvalidValue;
+    s->capturing = true;
+    s->rec = std::make_shared<std::vector<std::function<void()>>>();
+    return hipSuccess;
+}
+hipError_t hipStreamEndCapture(hipStream_t s, hipGraph_t *g)
+{
+    *g = nullptr;
+    if (!s || !s->capturing) return hipErrorInvalidValue;
+    s->capturing = false;
+    *g = new ihipGraph{s->rec};
+    s->rec.reset();
+    return hipSuccess;
+}
+hipError_t hipGraphInstantiate(hipGraphExec_t *e, hipGraph_t g, void *, void *, size_t)
+{
+    if (!g) return hipErrorInvalidValue;
+    *e = new ihipGraphExec{g->ops};
+    return hipSuccess;
+}
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t)
+{
+    if (!e) return hipErrorInvalidValue;
+    for (auto &op : *e->ops) op();
+    return hipSuccess;
+}
+hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new ihipEvent_t{std::chrono::steady_clock::now()}; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
