@@ -83,7 +83,9 @@ __device__ __forceinline__ void lean_walk(const int *__restrict__ acol, const re
         const int alen = a_end - a_beg, nb = (alen + BS - 1) / BS, mbc = (maxb + V - 1) >> 2;
         const int ce = (np >> 2) + (alen >> 1);  // chunks, roughly: a partial one for every other entry
         if (2 * nb * mbc <= 2 * ((ce + BS - 1) / BS) + 3 * nb) {
-            if (NW > 1) __syncthreads();  // the caller's tables are cleared by all wavefronts
+            // the caller's tables are cleared by all lanes before the first probe: a workgroup barrier, or -- one
+            // wavefront -- its program order, said aloud (LDS fence + scheduling barrier; the sync point of tests/emu)
+            if (NW > 1) __syncthreads(); else wave_lds_sync();
             for (int b0 = a_beg; b0 < a_end; b0 += BS) {
                 int b = 0, e = 0;
                 real av = 0;
@@ -771,7 +773,8 @@ __global__ __launch_bounds__(BS) void k_num_lean(const int *__restrict__ arpt, c
             const int i = lane + 64 * q, key = q ? r1 : r0;
             if (i < n) {
                 int h = lean_slot(key, shift, bits);
-                while (keys[h] != key) h = (h + 1) & mask;
+                // (bounded: a key that is not in the table -- a defect elsewhere -- must be a wrong value, not a hung device)
+                for (int g = 0; keys[h] != key && g < T; g++) h = (h + 1) & mask;
                 if (write_col & 1) ccol[off + i] = key;
                 cval[off + i] = (real)vals[h];
             }
@@ -799,7 +802,7 @@ __global__ __launch_bounds__(BS) void k_num_lean(const int *__restrict__ arpt, c
     for (int i = threadIdx.x; i < n; i += BS) {
         const int key = srt[i];
         int h = lean_slot(key, shift, bits);
-        while (keys[h] != key) h = (h + 1) & mask;
+        for (int g = 0; keys[h] != key && g < T; g++) h = (h + 1) & mask;  // (bounded, as above)
         if (write_col & 1) ccol[off + i] = key;
         cval[off + i] = (real)vals[h];
     }

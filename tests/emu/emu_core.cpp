@@ -14,6 +14,7 @@
 #include <vector>
 
 #include <execinfo.h>
+#include <pthread.h>
 #include <sched.h>
 #include <signal.h>
 #include <ucontext.h>
@@ -367,6 +368,16 @@ static void on_fault(int sig, siginfo_t *si, void *uc_)
     backtrace_symbols_fd(bt, k, 2);
     _exit(139);
 }
+static void on_watchdog(int, siginfo_t *, void *)
+{
+    char buf[256];
+    const int n = snprintf(buf, sizeof buf, "emu: watchdog: kernel %s, workgroup %u, work-item %u is here:\n", t_kernel, t_blockIdx.x,
+                           t_threadIdx.x);
+    (void)!write(2, buf, (size_t)n);
+    void *bt[16];
+    const int k = backtrace(bt, 16);
+    backtrace_symbols_fd(bt, k, 2);
+}
 static void install_trap()
 {
     static std::once_flag once;
@@ -378,6 +389,11 @@ static void install_trap()
         sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
         sigaction(SIGSEGV, &sa, nullptr);
         sigaction(SIGBUS, &sa, nullptr);
+        struct sigaction sw;
+        memset(&sw, 0, sizeof sw);
+        sw.sa_sigaction = on_watchdog;
+        sw.sa_flags = SA_SIGINFO | SA_ONSTACK;
+        sigaction(SIGUSR1, &sw, nullptr);
     });
 }
 
@@ -390,10 +406,15 @@ int workers()
     return g_workers;
 }
 
+static std::vector<pthread_t> &g_worker_ids = *new std::vector<pthread_t>;
 static void worker_main()
 {
     Worker self;
     t_w = &self;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_worker_ids.push_back(pthread_self());
+    }
     {
         // faults are reported from an alternate stack: the faulting stack may be a lane's, and may be exhausted
         stack_t ss;
@@ -471,7 +492,19 @@ void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, hipStream
     }
     g_cv.notify_all();
     std::unique_lock<std::mutex> lk(g_mu);
-    g_cv_done.wait(lk, [&] { return job->finished.load() == job->total; });
+    // EMU_WATCHDOG_S (default 120): a kernel that runs longer has every worker say where it is (SIGUSR1: kernel,
+    // workgroup, work-item, backtrace) and the process ends -- a lane spinning without a sync point cannot be
+    // interrupted any other way
+    static const double limit = getenv("EMU_WATCHDOG_S") ? atof(getenv("EMU_WATCHDOG_S")) : 120.0;
+    if (!g_cv_done.wait_for(lk, std::chrono::duration<double>(limit), [&] { return job->finished.load() == job->total; })) {
+        fprintf(stderr, "emu: kernel %s <<<%u, %u>>> has been running for %.0f s (%u of %u workgroups done)\n", name, grid.x,
+                block.x * block.y * block.z, limit, job->finished.load(), job->total);
+        for (pthread_t t : g_worker_ids) {
+            pthread_kill(t, SIGUSR1);
+            usleep(200000);
+        }
+        _exit(124);
+    }
     g_job.reset();
 }
 
