@@ -1,0 +1,132 @@
+"""The product's kernels on the CPU emulation of the device model (tests/emu, see its README): the SAME `-m gpu` tests,
+the SAME ctypes binding, pointed at tests/emu/lib -- libraries built from nsparse_amd/csrc with the host compiler
+against a lane-by-lane emulation of wavefronts, LDS, DPP / swizzle / bpermute, barriers and atomics.
+
+This is how the logic of every kernel is checked against the oracle on a box without a GPU (the device pool was closed
+for most of rounds 4 and 5).  It does not replace the device run -- timing, hazards and the memory model are out of its
+reach -- and nothing under nsparse_amd/ ever loads these libraries.  The selections below are sized for the CPU suite
+(about three minutes together); the whole -m gpu corpus takes ~50 minutes on the emulation:
+    NSPARSE_LIB_DIR=$PWD/tests/emu/lib python -m pytest tests -m gpu -q
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu")
+LIB = os.path.join(EMU, "lib")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    """tests/emu/lib, built on demand (`make -C tests/emu`, ~4 min on 8 cores; __graft_entry__.build() does it too)."""
+    need = ["libnsparse_d.so", "libnsparse_s.so", "libnsparse_dist_d.so", "amb_dist_d", "selftest"]
+    r = subprocess.run(["make", "-C", EMU, "-j", str(min(8, os.cpu_count() or 1)), "-s"], capture_output=True, text=True,
+                       timeout=3000)
+    assert r.returncode == 0, r.stderr[-3000:]
+    for n in need:
+        assert os.path.exists(os.path.join(LIB, n)), n
+    return LIB
+
+
+def _gpu_tests_on_emu(emu_lib, args, env=None, timeout=900, expect_min=1):
+    e = dict(os.environ, NSPARSE_LIB_DIR=emu_lib, **(env or {}))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + args, cwd=ROOT,
+                       env=e, capture_output=True, text=True, timeout=timeout)
+    tail = (r.stdout + r.stderr)[-4000:]
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert r.returncode == 0 and m and "failed" not in r.stdout.splitlines()[-1], tail
+    assert int(m.group(1)) >= expect_min, tail
+    return int(m.group(1))
+
+
+def test_emulated_instructions_against_hand_checked_kernels(emu_lib):
+    """tests/emu/selftest.cpp: DPP scans (row_shr / row_bcast with row masks), shuffles of every kind and width, ballot
+    under divergence, swizzle, bpermute, readlane, the v_min / v_max_i32_dpp of the asm sorts parsed from their operand
+    strings, LDS + barriers, dynamic LDS, global atomics across workgroups, a grid barrier of co-resident workgroups."""
+    r = subprocess.run([os.path.join(emu_lib, "selftest")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "selftest: 0 failures" in r.stdout, r.stdout + r.stderr
+
+
+def test_the_library_loaded_is_the_emulation_and_not_the_product(emu_lib):
+    """The emulation exports emu_get_stats; the product library must not (nothing CPU-side hides behind the product's
+    name in nsparse_amd/lib), and nsparse_amd.load() without NSPARSE_LIB_DIR never looks at tests/emu."""
+    emu = C.CDLL(os.path.join(emu_lib, "libnsparse_d.so"), mode=C.RTLD_LOCAL)
+    assert hasattr(emu, "emu_get_stats")
+    prod = C.CDLL(os.path.join(ROOT, "nsparse_amd", "lib", "libnsparse_d.so"), mode=C.RTLD_LOCAL)
+    assert not hasattr(prod, "emu_get_stats") and not hasattr(prod, "emu_reset_stats")
+    src = open(os.path.join(ROOT, "nsparse_amd", "capi.py")).read()
+    assert "emu" not in src.replace("enumerate", "")
+
+
+def test_random_products_on_the_emulation(emu_lib):
+    """tests/test_fuzz_gpu.py (random rectangular / node-block / general-B products, both precisions) vs the oracle."""
+    n = _gpu_tests_on_emu(emu_lib, ["tests/test_fuzz_gpu.py"],
+                          env={"NSPARSE_FUZZ_SEEDS": "10", "NSPARSE_FUZZ_SQ_SEEDS": "6", "NSPARSE_FUZZ_AB_SEEDS": "4"})
+    assert n == 20
+
+
+def test_both_hash_kernel_families_on_the_emulation(emu_lib):
+    """The lean kernels of round 4 (owner-array walk, 24-bit hash, in-register DPP sort, flip-form LDS sort) had never
+    run anywhere after their hash fix; here every hash bin of both phases goes through them (NSPARSE_TB_LEAN=3) and
+    through round 3's kernels: stencil, R-MAT and web-graph rows, one-wavefront rows, clustered columns in the big
+    tables.  (First run on the emulation found the cleared table of one-wavefront rows unpublished before the direct
+    rounds -- correct on the device by the wavefront's program order, now a wave_lds_sync().)"""
+    n = _gpu_tests_on_emu(emu_lib, ["tests/test_spgemm_gpu.py", "-k", "both_kernel_families or one_wavefront_bin or big_table_bins"])
+    assert n == 6
+
+
+def test_spgemm_paths_on_the_emulation(emu_lib):
+    """Known answers, golden vectors, fused tails vs kernel chains (a real grid barrier among 8 workgroup threads), twin
+    rows and keyed runs of the node-block kernel, non-finite values, rectangular / empty inputs, unsorted B, the
+    numeric-only and unsorted-output modes, the chained product that found k_num_tiled's sweep record."""
+    k = ("known_answer or golden or rectangular or empty or no_rows or unsorted or fused_tails_match or fused_tails_at "
+         "or twin_rows or keyed_runs or non_finite or node_block_kernel or workspace_cache or chained or wide_windows "
+         "or window_wider")
+    n = _gpu_tests_on_emu(emu_lib, ["tests/test_spgemm_gpu.py", "-k", k], timeout=1200)
+    assert n >= 25
+
+
+def test_amb_conversion_and_spmv_on_the_emulation(emu_lib):
+    """tests/test_amb_gpu.py: the seven AMB arrays bit for bit against the oracle (both chunk sizes, both precisions),
+    the plan search, sigma windows, and the split-row SpMV kernel of round 4 (never run on a device)."""
+    n = _gpu_tests_on_emu(emu_lib, ["tests/test_amb_gpu.py"])
+    assert n >= 30
+
+
+def test_aux_modes_on_the_emulation(emu_lib):
+    """Deterministic summation (bytes identical to the sequential oracle), stream-ordered workspace, fused-state query."""
+    n = _gpu_tests_on_emu(emu_lib, ["tests/test_aux_gpu.py", "-k", "deterministic or stream_ordered or fused_state"])
+    assert n >= 8
+
+
+def test_native_multi_rank_library_on_the_emulation(emu_lib):
+    """libnsparse_dist on the in-process RCCL stand-in: one-rank end to end with graph replay, ragged partitions, gap
+    closing, the native row-partitioned SpGEMM with its gather (never run on a device), the CLI samples."""
+    n = _gpu_tests_on_emu(emu_lib, ["tests/test_dist_native_gpu.py", "tests/test_partition_gpu.py", "tests/test_samples_gpu.py",
+                                    "-k", "not cant_class and not webbase_class"])
+    assert n >= 25
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_row_sharded_spmv_at_world_gt_1_one_thread_per_device(world, emu_lib, tmp_path):
+    """samples/amb_dist.cpp as it runs on an 8-GPU node -- ncclCommInitAll, one thread per device, nnz-balanced 64-aligned
+    row blocks, per-rank conversion, all-gather in place (equal blocks) or staged + gap closing (ragged), rank 0's y
+    checked against csr_kernel by the reference's own rule -- on EMU_DEVICES fake devices with threads as ranks.  The
+    first executions of the native path at world > 1 anywhere."""
+    sys.path.insert(0, ROOT)
+    import nsparse_amd as ns
+    lib = ns.load("d")  # host entry points only: generator + Matrix Market writer
+    m = ns.sfCSR()
+    lib.nsparse_synth_csr(C.byref(m), 3, 12, 8, 0, 0x5EED0022, 0, 0)  # R-MAT scale 12: ragged nnz-balanced blocks
+    path = str(tmp_path / "rmat12.mtx")
+    assert lib.nsparse_write_mtx(C.byref(m), path.encode(), 0) == 0
+    lib.release_cpu_csr(m)
+    r = subprocess.run([os.path.join(emu_lib, "amb_dist_d"), path, str(world)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert f"on {world} GPUs" in r.stdout and "Calculation Result is Correct" in r.stdout
+    assert len(re.findall(r"^rank \d+: rows", r.stdout, flags=re.M)) == world
