@@ -130,3 +130,48 @@ def test_row_sharded_spmv_at_world_gt_1_one_thread_per_device(world, emu_lib, tm
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert f"on {world} GPUs" in r.stdout and "Calculation Result is Correct" in r.stdout
     assert len(re.findall(r"^rank \d+: rows", r.stdout, flags=re.M)) == world
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_row_partitioned_spgemm_with_gather_at_world_gt_1(world, emu_lib):
+    """tools/emu_ranks_spgemm.py: ranks as threads on the fake devices, ONE communicator by unique id, product-balanced
+    row blocks through nsparse_dist_spgemm, nsparse_dist_barrier / _allreduce_f64, then nsparse_dist_spgemm_gather (size
+    all-reduce, allocation agreed among the ranks, one broadcast per rank and array, row-pointer shift): every rank ends
+    up with the whole C = the oracle's, structure bit for bit."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_ranks_spgemm.py"), str(world), "3", "11", "8", "0"],
+                       env=dict(os.environ, NSPARSE_LIB_DIR=emu_lib), capture_output=True, text=True, timeout=600, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and lines, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads(lines[-1])
+    assert not d["errors"] and len(d["ranks"]) == world
+    for q in d["ranks"]:
+        assert q["rpt_ok"] and q["col_ok"] and q["val_fails"] == 0
+        assert q["nnz_sum"] == d["nnz_C"] and q["rank_sum"] == world * (world - 1) // 2
+    assert sum(q["block_rows"] for q in d["ranks"]) == d["M"]
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_py_itself_on_the_emulated_device(gpus, emu_lib):
+    """The REAL bench.py (not its dry run): every library call of the timed protocol executes, on the emulated device,
+    at full size (cant-class 62,451 rows: ~2.5 s per product here).  N = 2: NSPARSE_BENCH_EMULATE=1, two rank PROCESSES
+    sharing the device, barriers / reductions over the rendezvous socket, the all-gather replaced by staging + gap closing
+    with the landed rows compared.  Numbers from such a run are emulation speed -- what is checked is that the line
+    comes out, complete, with the answers right."""
+    import json
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "1", "--spmv-steps", "2",
+           "--no-pmc", "--no-vendor", "--no-configs", "--no-large", "--no-irregular", "--no-cpu"]
+    env = dict(os.environ, NSPARSE_LIB_DIR=emu_lib, **({"NSPARSE_BENCH_EMULATE": "1"} if gpus > 1 else {}))
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[:400]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == gpus and d["value"] > 0 and "dry_run" not in d
+    assert d["config"]["rows_per_gpu"] == 62451 and d["roofline"]["bytes_per_launch"] > 0
+    assert d["spmv"]["ans_check_fails"] == 0
+    if gpus > 1:
+        assert "emulated_ranks" in d and d["spmv"]["emulated_gather"]["landed_equal"] is True
+    else:
+        assert "k_num_block<128, 1536" in d["roofline"]["kernel"] and d["spmv"]["hipgraph"]["ms_per_spmv"] > 0
