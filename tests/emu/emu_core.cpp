@@ -275,14 +275,35 @@ static void run_block(Worker *w, const std::function<void()> &body, dim3 grid, d
         t_threadIdx = {l.tid % block.x, (l.tid / block.x) % block.y, l.tid / (block.x * block.y)};
         emu_switch(&w->sched_sp, l.sp);
     };
+    // EMU_ORDER: the order in which the waves of a workgroup, and the lanes of a wave, are run between sync points --
+    // 0 ascending (default), 1 descending, 2 a different pseudo-random order per workgroup and scheduling round.  A
+    // program without races gives the same results under every order: running the tests under 1 and 2 is how a missing
+    // barrier (a wave reading what another has not written yet) shows up here instead of once a week on the device.
+    static const int order_mode = getenv("EMU_ORDER") ? atoi(getenv("EMU_ORDER")) : 0;
+    unsigned long long rng = 0x9E3779B97F4A7C15ull * (bx + 1) + 12345;
+    auto next_rand = [&]() {
+        rng ^= rng << 13;
+        rng ^= rng >> 7;
+        rng ^= rng << 17;
+        return rng;
+    };
+    std::vector<unsigned> worder(nw);
+    int lorder[64];
     for (;;) {
         unsigned at_barrier = 0, done = 0;
-        for (unsigned wv = 0; wv < nw; wv++) {
+        for (unsigned i = 0; i < nw; i++) worder[i] = order_mode == 1 ? nw - 1 - i : i;
+        for (int i = 0; i < 64; i++) lorder[i] = order_mode == 1 ? 63 - i : i;
+        if (order_mode == 2) {
+            for (unsigned i = nw; i > 1; i--) std::swap(worder[i - 1], worder[next_rand() % i]);
+            for (int i = 64; i > 1; i--) std::swap(lorder[i - 1], lorder[next_rand() % (unsigned)i]);
+        }
+        for (unsigned wi = 0; wi < nw; wi++) {
+            const unsigned wv = worder[wi];
             Lane *wl[64];
             for (int i = 0; i < 64; i++) wl[i] = wv * 64 + i < nt ? &w->lanes[wv * 64 + i] : nullptr;
             for (;;) {
                 bool ran = false;
-                for (int i = 0; i < 64; i++)
+                for (int li = 0, i = lorder[0]; li < 64; li++, i = lorder[li & 63])
                     if (wl[i] && (wl[i]->st == RUN || wl[i]->st == YIELD)) {
                         const bool was_yield = wl[i]->st == YIELD;
                         wl[i]->st = RUN;
