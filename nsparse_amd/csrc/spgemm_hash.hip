@@ -428,7 +428,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        if (g_tb_lean & 1)                                                                     \
+        if ((g_tb_lean & 1) && b->N <= (1 << 24)) /* lean_slot hashes 24 bits of the column */    \
             hipLaunchKernelGGL((k_sym_lean<BS, TMAX, (BS >= 512 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
                                arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], hist[bin_], b->nnz, d_bs, \
                                TMAX >= 8192 ? tcol : (int *)nullptr, list_off, row_span, 12, 12288);  \
@@ -691,7 +691,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        if ((g_tb_lean & 2) && !tb_prof)                                                       \
+        if ((g_tb_lean & 2) && !tb_prof && b->N <= (1 << 24))                                  \
             hipLaunchKernelGGL((k_num_lean<BS, TMAX, (BS >= 512 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
                                arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_prod, row_maxb, \
                                off[bin_], hist[bin_], b->nnz, write_col);                      \
