@@ -142,3 +142,52 @@ def test_random_node_block_products_with_another_b(seed, lib_d, oracle_d, lib_s,
             assert oracle_d.check_spgemm(got, oracle_fp64_accumulated(Oracle("d"), X, Y)) == 0
         else:
             assert oracle_d.check_spgemm(got, ref) == 0
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("NSPARSE_FUZZ_AMB_SEEDS", "24"))))
+def test_random_amb_plans(seed, lib_d, oracle_d, lib_s, oracle_s):
+    """sf_csr2amb + sf_spmv_amb under random plans (segment size, block size 1..20, chunk 32 / 64, both precisions) on
+    random matrices of every shape the SpGEMM sweep uses, unsorted rows included: the seven AMB arrays bit for bit
+    against the oracle (convert_amb.cu:22-929), the footprint model, and y against csr_kernel by the reference's rule
+    (kernel_spmv_amb.cu:21-79; nsparse.cu:261-297).  Round 5: written and first run on the CPU emulation."""
+    import ctypes as C
+
+    from gpu_util import DeviceAMB
+    from test_amb_gpu import assert_same_format
+    rng = np.random.default_rng(int(os.environ.get("NSPARSE_FUZZ_BASE", "1000")) + 15485863 * seed)
+    lib, orc = (lib_d, oracle_d) if rng.integers(0, 2) == 0 else (lib_s, oracle_s)
+    m = int(rng.choice([1, 5, 63, 64, 65, 300, 1000, 2500]))
+    n = int(rng.choice([1, 7, 64, 300, 5000, 70000, 140000]))
+    A = _rand_csr(rng, m, n, int(rng.choice([0, 1, 3, 4])))
+    if rng.integers(0, 4) == 0 and A["rpt"][-1] > 0:  # unsorted rows: the conversion sorts internally
+        col, val = A["col"].copy(), A["val"].copy()
+        for i in range(m):
+            lo, hi = A["rpt"][i], A["rpt"][i + 1]
+            p = rng.permutation(hi - lo)
+            col[lo:hi], val[lo:hi] = col[lo:hi][p], val[lo:hi][p]
+        A = dict(A, col=col, val=val)
+    A = dict(A, val=(A["val"] * rng.choice([-1.0, 1.0], size=A["val"].size) if rng.integers(0, 3) == 0 else A["val"]).astype(lib.real))
+    seg = int(rng.choice([1, 3, 64, 300, 1024, 4096, 65536]))
+    # the segment number lives in the upper 16 bits of `cl` (nsparse.h: SCL_BORDER; convert_amb.cu:313-346): a plan with
+    # more than 65536 segments wraps -- in the reference, in the oracle and here alike (the arrays still agree; y is then
+    # not A x).  The reference's own search never gets there (seg_size 65536, or 1..4 when N < 100); neither does this.
+    seg = max(seg, -(-n // 65536))
+    bs = int(rng.integers(1, 21))
+    chunk = int(rng.choice([32, 64]))
+    d = DeviceAMB(lib, A, seg, bs, chunk=chunk)
+    try:
+        srt = A
+        if m and A["rpt"][-1] > 0:  # the oracle is handed sorted rows (what the conversion works on)
+            S = sp.csr_matrix((A["val"], A["col"], A["rpt"]), shape=(m, n))
+            S.sort_indices()
+            srt = dict(A, col=S.indices.astype(np.int32), val=S.data.astype(lib.real))
+        ora = orc.csr2amb(srt, int(d.plan.seg_size), int(d.plan.block_size), chunk)
+        assert_same_format(d.arrays(), ora)
+        assert lib.nsparse_amb_footprint_bytes(C.byref(d.amb)) == ora.footprint
+        x = (rng.random(n) + 0.5).astype(lib.real)
+        y = d.spmv(x)
+        y_ref = orc.csr_spmv(srt["rpt"], srt["col"], srt["val"], x)
+        mag = orc.csr_spmv(srt["rpt"], srt["col"], np.abs(srt["val"]), np.abs(x))
+        assert (np.abs(y - y_ref) <= (1e-12 if lib.real == np.float64 else 2e-5) * (mag + 1e-300)).all()
+    finally:
+        d.close()
