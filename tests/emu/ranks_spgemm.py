@@ -5,7 +5,7 @@ collective half of include/nsparse_dist.h (communicator by unique id, nsparse_di
 agreed allocation, per-rank broadcasts, row-pointer shift) can execute at world > 1 without 2+ GPUs.  On a real
 multi-GPU box the same script runs one thread per GPU.
 
-    python tools/emu_ranks_spgemm.py <world> <kind> <p0> <p1> <p2> [d|s]   -> one JSON line
+    python tests/emu/ranks_spgemm.py <world> <kind> <p0> <p1> <p2> [d|s]   -> one JSON line
 """
 import ctypes as C
 import json
@@ -15,7 +15,7 @@ import threading
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import nsparse_amd as ns  # noqa: E402

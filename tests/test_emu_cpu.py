@@ -134,12 +134,12 @@ def test_row_sharded_spmv_at_world_gt_1_one_thread_per_device(world, emu_lib, tm
 
 @pytest.mark.parametrize("world", [3, 8])
 def test_row_partitioned_spgemm_with_gather_at_world_gt_1(world, emu_lib):
-    """tools/emu_ranks_spgemm.py: ranks as threads on the fake devices, ONE communicator by unique id, product-balanced
+    """tests/emu/ranks_spgemm.py: ranks as threads on the fake devices, ONE communicator by unique id, product-balanced
     row blocks through nsparse_dist_spgemm, nsparse_dist_barrier / _allreduce_f64, then nsparse_dist_spgemm_gather (size
     all-reduce, allocation agreed among the ranks, one broadcast per rank and array, row-pointer shift): every rank ends
     up with the whole C = the oracle's, structure bit for bit."""
     import json
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emu_ranks_spgemm.py"), str(world), "3", "11", "8", "0"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "ranks_spgemm.py"), str(world), "3", "11", "8", "0"],
                        env=dict(os.environ, NSPARSE_LIB_DIR=emu_lib), capture_output=True, text=True, timeout=600, cwd=ROOT)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and lines, r.stdout[-1500:] + r.stderr[-1500:]
