@@ -48,16 +48,25 @@ def oracle_s():
     return Oracle("s")
 
 
+def _with_test_switches(lib):
+    # NSPARSE_TEST_WS_CACHE=0|1|2: the workspace mode for the whole session (0: every array of a call is its own
+    # hipMalloc -- what the AddressSanitizer build of the emulation wants, tests/emu/README.md)
+    m = os.environ.get("NSPARSE_TEST_WS_CACHE")
+    if m is not None:
+        lib.nsparse_set_workspace_cache(int(m))
+    return lib
+
+
 @pytest.fixture(scope="session")
 def lib_d():
     import nsparse_amd
-    return nsparse_amd.load("d")
+    return _with_test_switches(nsparse_amd.load("d"))
 
 
 @pytest.fixture(scope="session")
 def lib_s():
     import nsparse_amd
-    return nsparse_amd.load("s")
+    return _with_test_switches(nsparse_amd.load("s"))
 
 
 def load_golden(name):

@@ -423,6 +423,9 @@ int workers()
     if (g_workers == 0) {
         const char *e = getenv("EMU_WORKERS");
         g_workers = e && atoi(e) > 0 ? atoi(e) : 8;
+#ifdef EMU_SHARED_STATIC
+        g_workers = 1;  // LDS is one static per kernel in this build: one workgroup at a time
+#endif
     }
     return g_workers;
 }
@@ -544,7 +547,9 @@ struct ihipGraph { std::shared_ptr<std::vector<std::function<void()>>> ops; };
 struct ihipGraphExec { std::shared_ptr<std::vector<std::function<void()>>> ops; };
 struct ihipMemPool { int x; };
 
-constexpr size_t kGuard = 256;
+// EMU_NO_GUARD=1: no guard bytes -- for the AddressSanitizer build of the emulation (make OUT=lib_asan EXTRA=-fsanitize=address
+// ...), whose own redzones then sit right behind the block and catch an out-of-bounds READ as well
+static const size_t kGuard = getenv("EMU_NO_GUARD") ? 0 : 256;
 static std::mutex &g_blocks_mu = *new std::mutex;
 static std::map<uintptr_t, size_t> &g_blocks = *new std::map<uintptr_t, size_t>;
 extern "C" void emu_describe_address(const void *a)

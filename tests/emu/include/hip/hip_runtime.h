@@ -106,7 +106,13 @@ void emu_reset_stats(void);
 #define __launch_bounds__(...)
 #define amdgpu_waves_per_eu(...)          /* __attribute__((amdgpu_waves_per_eu(..))) -> __attribute__(()) */
 #define amdgpu_flat_work_group_size(...)
+#ifdef EMU_SHARED_STATIC
+// LDS as plain statics: AddressSanitizer puts redzones around globals (not around thread-locals), so an out-of-bounds
+// LDS index is reported -- at the price of ONE workgroup at a time (EMU_WORKERS is forced to 1: no grid barriers)
+#define __shared__ static
+#else
 #define __shared__ static thread_local
+#endif
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
 #define __HIP_MEMORY_SCOPE_WORKGROUP 3
