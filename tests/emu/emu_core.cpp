@@ -480,10 +480,36 @@ bool capture_record(hipStream_t st, std::function<void()> fn)
 // kernels of different host threads (one per fake device in samples/amb_dist.cpp) run one after the other
 static std::mutex &g_launch_mu = *new std::mutex;
 
-void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream, std::function<void()> body)
+// what hipFuncSetAttribute(hipFuncAttributeMaxDynamicSharedMemorySize) has allowed, per (function, device)
+static std::map<std::pair<const void *, int>, int> &g_dyn_lds_allowed = *new std::map<std::pair<const void *, int>, int>;
+static std::mutex &g_attr_mu = *new std::mutex;
+int current_device();
+
+void launch(const char *name, const void *func, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream, std::function<void()> body)
 {
+    // the launch-time rules a real device enforces and a CPU would not: workgroup size, and dynamic LDS above 64 KiB only
+    // for a function that was given the attribute ON THE CURRENT DEVICE (the runtime returns hipErrorInvalidValue)
+    const unsigned nt = block.x * block.y * block.z;
+    if (nt == 0 || nt > 1024) {
+        fprintf(stderr, "emu: kernel %s launched with %u work-items per workgroup\n", name, nt);
+        abort();
+    }
+    if (lds_bytes > 160 * 1024) {
+        fprintf(stderr, "emu: kernel %s asks for %zu bytes of dynamic LDS (a CU has 160 KiB)\n", name, lds_bytes);
+        abort();
+    }
+    if (lds_bytes > 64 * 1024) {
+        std::lock_guard<std::mutex> lk(g_attr_mu);
+        auto it = g_dyn_lds_allowed.find({func, current_device()});
+        if (it == g_dyn_lds_allowed.end() || (size_t)it->second < lds_bytes) {
+            fprintf(stderr, "emu: kernel %s launched on device %d with %zu bytes of dynamic LDS without "
+                            "hipFuncAttributeMaxDynamicSharedMemorySize >= that on THIS device (allowed: %d)\n",
+                    name, current_device(), lds_bytes, it == g_dyn_lds_allowed.end() ? 65536 : it->second);
+            abort();
+        }
+    }
     if (stream && stream->capturing) {
-        stream->rec->push_back([=] { launch(name, grid, block, lds_bytes, nullptr, body); });
+        stream->rec->push_back([=] { launch(name, func, grid, block, lds_bytes, nullptr, body); });
         return;
     }
     std::lock_guard<std::mutex> launch_lk(g_launch_mu);
@@ -541,6 +567,9 @@ struct Ev {
 };
 thread_local int t_device = 0;
 }  // namespace
+namespace emu {
+int current_device() { return t_device; }
+}
 
 struct ihipEvent_t { std::chrono::steady_clock::time_point t; };
 struct ihipGraph { std::shared_ptr<std::vector<std::function<void()>>> ops; };
@@ -710,7 +739,15 @@ const char *hipGetErrorString(hipError_t e)
     default: return "unknown error";
     }
 }
-hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t hipFuncSetAttribute(const void *f, hipFuncAttribute a, int v)
+{
+    if (a == hipFuncAttributeMaxDynamicSharedMemorySize) {
+        if (v < 0 || v > 160 * 1024) return hipErrorInvalidValue;
+        std::lock_guard<std::mutex> lk(emu::g_attr_mu);
+        emu::g_dyn_lds_allowed[{f, t_device}] = v;
+    }
+    return hipSuccess;
+}
 void emu_get_stats(long long out[8])
 {
     for (int i = 0; i < 8; i++) out[i] = emu::g_stats[i].load();

@@ -157,7 +157,7 @@ struct Res {
 Res collective(const Req &rq) __attribute__((noinline));  // the call site = its return address
 void block_barrier() __attribute__((noinline));
 void yield_lane() __attribute__((noinline));
-void launch(const char *name, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream, std::function<void()> body);
+void launch(const char *name, const void *func, dim3 grid, dim3 block, size_t lds_bytes, hipStream_t stream, std::function<void()> body);
 bool capture_record(hipStream_t st, std::function<void()> fn);  // true: `st` is being captured, fn was recorded instead of run
 
 template <typename T>
@@ -183,7 +183,7 @@ static inline T from_bits(unsigned long long u)
 #define gridDim (::emu::t_gridDim)
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-    ::emu::launch(#kernel, (grid), (block), (size_t)(lds), (hipStream_t)(stream), [=]() { (kernel)(__VA_ARGS__); })
+    ::emu::launch(#kernel, reinterpret_cast<const void *>(+(kernel)), (grid), (block), (size_t)(lds), (hipStream_t)(stream), [=]() { (kernel)(__VA_ARGS__); })
 
 static __forceinline__ void __syncthreads() { ::emu::block_barrier(); }
 static __forceinline__ void __threadfence() {}

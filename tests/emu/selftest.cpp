@@ -126,6 +126,8 @@ int main()
     CHECK(d[4096] == 4096);
 
     hipLaunchKernelGGL(k_dyn, dim3(3), dim3(128), 4000, nullptr, d, 1000);
+    hipFuncSetAttribute(reinterpret_cast<const void *>(k_dyn), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+    hipLaunchKernelGGL(k_dyn, dim3(1), dim3(128), 100 * 1024, nullptr, d, 1000);  // above 64 KiB: needs the attribute
     for (int i = 0; i < 3 * 128; i++) CHECK(d[i] == 999 * 1000);
 
     int ncu = 0;

@@ -64,10 +64,12 @@ def test_the_library_loaded_is_the_emulation_and_not_the_product(emu_lib):
 
 
 def test_random_products_on_the_emulation(emu_lib):
-    """tests/test_fuzz_gpu.py (random rectangular / node-block / general-B products, both precisions) vs the oracle."""
+    """tests/test_fuzz_gpu.py (random rectangular / node-block / general-B products, random AMB plans, both precisions)
+    vs the oracle."""
     n = _gpu_tests_on_emu(emu_lib, ["tests/test_fuzz_gpu.py"],
-                          env={"NSPARSE_FUZZ_SEEDS": "10", "NSPARSE_FUZZ_SQ_SEEDS": "6", "NSPARSE_FUZZ_AB_SEEDS": "4"})
-    assert n == 20
+                          env={"NSPARSE_FUZZ_SEEDS": "10", "NSPARSE_FUZZ_SQ_SEEDS": "6", "NSPARSE_FUZZ_AB_SEEDS": "4",
+                               "NSPARSE_FUZZ_AMB_SEEDS": "8"})
+    assert n == 28
 
 
 def test_both_hash_kernel_families_on_the_emulation(emu_lib):
