@@ -24,7 +24,7 @@ tests)
   if [ -s $O/failed.txt ]; then
     : > $O/bisect.txt
     while read -r t; do
-      for v in $(ls -d nsparse_amd/lib_[0-9a-f]*/ 2>/dev/null); do
+      for v in $(ls -d nsparse_amd/lib_*/ 2>/dev/null | grep -E 'lib_[0-9a-f]{7}/$'); do
         NSPARSE_LIB_DIR=$PWD/${v%/} timeout 600 python -m pytest "$t" -m gpu -q -x -p no:cacheprovider 2>&1 | grep -vE "$FILTER" | tail -1 \
           | sed "s|^|$t @ $v: |" >> $O/bisect.txt
       done
