@@ -156,7 +156,7 @@ def test_row_partitioned_spgemm_with_gather_at_world_gt_1(world, emu_lib):
     assert sum(q["block_rows"] for q in d["ranks"]) == d["M"]
 
 
-@pytest.mark.parametrize("gpus", [1, 2])
+@pytest.mark.parametrize("gpus", [int(g) for g in os.environ.get("NSPARSE_EMU_BENCH_GPUS", "2").split(",")])  # (1,2: both)
 def test_bench_py_itself_on_the_emulated_device(gpus, emu_lib):
     """The REAL bench.py (not its dry run): every library call of the timed protocol executes, on the emulated device,
     at full size (cant-class 62,451 rows per rank: ~2.5 s per product here).  N = 2 is the command the driver's scaling
