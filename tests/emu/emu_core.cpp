@@ -460,6 +460,17 @@ static void worker_main()
             const unsigned b = job->next.fetch_add(1);
             if (b >= job->total) break;
             t_kernel = job->name;
+            // EMU_STALL="<kernel name substring>:<workgroup>:<ms>" (tests): that workgroup starts late -- what a tenant
+            // that takes a CU away between the census and the call does to a grid barrier
+            {
+                static const char *stall = getenv("EMU_STALL");
+                if (stall) {
+                    char pat[128];
+                    unsigned blk = 0, ms = 0;
+                    if (sscanf(stall, "%127[^:]:%u:%u", pat, &blk, &ms) == 3 && b == blk && strstr(job->name, pat))
+                        std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+                }
+            }
             run_block(&self, job->body, job->grid, job->block, b, job->lds);
             t_w = &self;
             if (job->finished.fetch_add(1) + 1 == job->total) {

@@ -184,3 +184,25 @@ def test_bench_py_itself_on_the_emulated_device(gpus, emu_lib):
         assert d["config"]["parallelism"].startswith("row-partition x2") and d["spmv"]["ms_per_spmv"] > 0
     else:
         assert "k_num_block<128, 1536" in d["roofline"]["kernel"] and d["spmv"]["hipgraph"]["ms_per_spmv"] > 0
+
+
+@pytest.mark.parametrize("stall,tails_run", [("", 6), ("k_setup_tail:2:400", 1), ("k_numeric_setup:1:400", 2)])
+def test_grid_barrier_that_times_out_falls_back_to_the_chains(stall, tails_run, emu_lib):
+    """fused.h: the grid barrier of the fused tails has ONE agreed outcome word (open / passed / failed by compare-and-swap,
+    50 ms bound) -- re-written in round 4 without a device.  Here the census is skipped (NSPARSE_FUSED_FORCE=1), the
+    tails run as 5 workgroups on 5 threads, and EMU_STALL holds one workgroup of the first or of the second tail back for
+    400 ms: the others time out, the late one READS "failed" and leaves its rows alone, the host sees the flag, repeats
+    the call with the kernel chains (same C as the oracle), counts one fallback and stops fusing on that context."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "stalled_workgroup.py")], capture_output=True, text=True,
+                       timeout=600, cwd=ROOT,
+                       env=dict(os.environ, NSPARSE_LIB_DIR=emu_lib, NSPARSE_FUSED_FORCE="1", EMU_STALL=stall, EMU_TRACE="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    calls = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("[")][-1])
+    assert len(calls) == 3 and all(c["equal"] and c["err"] == 0 for c in calls), calls
+    fused_launches = sum(("k_setup_tail" in ln or "k_numeric_setup" in ln) for ln in r.stderr.splitlines() if ln.startswith("emu: "))
+    assert fused_launches == tails_run, r.stderr[-1500:]
+    if stall:
+        assert all(c["fallbacks"] == 1 and c["fused_ok"] == 0 for c in calls), calls
+    else:
+        assert all(c["fallbacks"] == 0 and c["fused_ok"] == 1 for c in calls), calls
