@@ -8,11 +8,13 @@
 #include <chrono>
 #include <condition_variable>
 #include <map>
+#include <set>
 #include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
 #include <execinfo.h>
 #include <pthread.h>
 #include <sched.h>
@@ -517,6 +519,30 @@ void launch(const char *name, const void *func, dim3 grid, dim3 block, size_t ld
                             "hipFuncAttributeMaxDynamicSharedMemorySize >= that on THIS device (allowed: %d)\n",
                     name, current_device(), lds_bytes, it == g_dyn_lds_allowed.end() ? 65536 : it->second);
             abort();
+        }
+    }
+    // EMU_COVERAGE=<file>: which kernel instantiations were launched (mangled names, appended at exit) -- compared with
+    // the kernels the library contains by tools/emu_kernel_coverage.py
+    {
+        static const char *cov = getenv("EMU_COVERAGE");
+        if (cov) {
+            static std::set<const void *> &seen = *new std::set<const void *>;
+            static std::mutex &mu = *new std::mutex;
+            static bool hooked = false;
+            std::lock_guard<std::mutex> lk(mu);
+            seen.insert(func);
+            if (!hooked) {
+                hooked = true;
+                atexit([] {
+                    FILE *f = fopen(getenv("EMU_COVERAGE"), "a");
+                    if (!f) return;
+                    for (const void *p : seen) {
+                        Dl_info di;
+                        if (dladdr(p, &di) && di.dli_sname) fprintf(f, "%s\n", di.dli_sname);
+                    }
+                    fclose(f);
+                });
+            }
         }
     }
     if (stream && stream->capturing) {
