@@ -420,6 +420,16 @@ static void install_trap()
     });
 }
 
+unsigned long long clock_div()
+{
+    static const unsigned long long d = [] {
+        const char *e = getenv("EMU_CLOCK_DIV");
+        const long long v = e ? atoll(e) : 20;
+        return (unsigned long long)(v > 0 ? v : 20);
+    }();
+    return d;
+}
+
 int workers()
 {
     if (g_workers == 0) {

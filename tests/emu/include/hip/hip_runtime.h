@@ -311,9 +311,15 @@ static __forceinline__ unsigned __builtin_amdgcn_ubfe(unsigned v, unsigned off, 
     return width == 0 ? 0u : (v >> off) & ((1u << width) - 1u);
 }
 static __forceinline__ float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
+// ~100 MHz ticks of real time (EMU_CLOCK_DIV = host cycles per tick, default 20).  A larger divisor slows the device's
+// clock down: the bounded waits of the census and of the grid barriers (0.2 ms / 50 ms of it) then survive a host whose
+// cores are shared with other work -- tools/emu_corpus.sh runs with 2000
+namespace emu {
+unsigned long long clock_div();
+}
 static __forceinline__ unsigned long long wall_clock64()
 {
-    return (unsigned long long)__builtin_readcyclecounter() / 20;  // ~100 MHz ticks
+    return (unsigned long long)__builtin_readcyclecounter() / ::emu::clock_div();
 }
 static __forceinline__ long long clock64() { return (long long)__builtin_readcyclecounter(); }
 

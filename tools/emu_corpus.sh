@@ -15,7 +15,7 @@ TAG=${1:-r05}; ORDER=${2:-0}
 OUT=profiles/${TAG}_emu_corpus$([ "$ORDER" != 0 ] && echo _order$ORDER).txt
 make -C tests/emu -j8 -s || exit 1
 LOG=$(mktemp /tmp/emu_corpus.XXXXXX)
-EMU_ORDER=$ORDER EMU_WATCHDOG_S=3000 NSPARSE_LIB_DIR=$PWD/tests/emu/lib timeout 14000 python -u -m pytest tests -m gpu -q -p no:cacheprovider --timeout 3600 -rf \
+EMU_CLOCK_DIV=2000 EMU_ORDER=$ORDER EMU_WATCHDOG_S=3000 NSPARSE_LIB_DIR=$PWD/tests/emu/lib timeout 14000 python -u -m pytest tests -m gpu -q -p no:cacheprovider --timeout 3600 -rf \
   --ignore=tests/test_vendor_gpu.py \
   --deselect tests/test_aux_gpu.py::test_asan_build_runs_clean \
   --deselect tests/test_spgemm_gpu.py::test_fused_tails_under_a_cu_mask \
