@@ -206,3 +206,19 @@ def test_grid_barrier_that_times_out_falls_back_to_the_chains(stall, tails_run, 
         assert all(c["fallbacks"] == 1 and c["fused_ok"] == 0 for c in calls), calls
     else:
         assert all(c["fallbacks"] == 0 and c["fused_ok"] == 1 for c in calls), calls
+
+
+def test_fused_tails_with_four_rows_per_thread_and_a_65_way_grid_barrier(emu_lib):
+    """Above 256 K rows the fused tails take four rows per thread (k_setup_tail<4>, k_numeric_setup<4>): M = 262,144 is
+    65 workgroups of 1024.  72 emulated compute units (72 OS threads), the census skipped and the device clock slowed
+    down so that the 50 ms bound of the barrier outlasts an oversubscribed host: both tails must have run, and C must
+    be the oracle's (tests/test_spgemm_gpu.py::test_fused_tails_at_their_size_limits[262144])."""
+    cov = os.path.join(emu_lib, "cov_fused4.txt")
+    if os.path.exists(cov):
+        os.remove(cov)
+    n = _gpu_tests_on_emu(emu_lib, ["tests/test_spgemm_gpu.py", "-k", "fused_tails_at_their_size_limits and 262144"],
+                          env={"NSPARSE_FUSED_FORCE": "1", "EMU_WORKERS": "72", "EMU_CLOCK_DIV": "20000", "EMU_COVERAGE": cov})
+    assert n == 1
+    launched = set(open(cov).read().split())
+    os.remove(cov)
+    assert any("k_setup_tailILi4" in k for k in launched) and any("k_numeric_setupILi4" in k for k in launched), launched
