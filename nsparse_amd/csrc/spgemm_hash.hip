@@ -746,10 +746,17 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
             blk_elems = want > nz1 ? want : nz1;                                               \
         }                                                                                      \
         const size_t lds_blk = sizeof(acc_t) * (size_t)blk_elems + (size_t)blk_pad;            \
+        /* product builds: the node-block kernel runs with 128 threads and the first kernel never does (tune_nd*   \
+           below), so each (bin, workgroup size) pair instantiates ONE of the two kernels -- the discarded branch of \
+           an `if constexpr` is not odr-used (round 5: twelve kernel instantiations nobody could launch) */           \
         if (lean_on && (grp || blk_all)) {                                                     \
-            if (write_col & 1) NSP_NUM_BLOCK_GO(BS, SPAN, 1) else NSP_NUM_BLOCK_GO(BS, SPAN, 2) \
+            if constexpr ((BS) == 128 || kExperiments) {                                       \
+                if (write_col & 1) NSP_NUM_BLOCK_GO(BS, SPAN, 1) else NSP_NUM_BLOCK_GO(BS, SPAN, 2) \
+            }                                                                                  \
         } else {                                                                               \
-            if (write_col & 1) NSP_NUM_DENSE_GO(BS, SPAN, 1) else NSP_NUM_DENSE_GO(BS, SPAN, 2) \
+            if constexpr ((BS) != 128 || kExperiments) {                                       \
+                if (write_col & 1) NSP_NUM_DENSE_GO(BS, SPAN, 1) else NSP_NUM_DENSE_GO(BS, SPAN, 2) \
+            }                                                                                  \
         }                                                                                      \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \

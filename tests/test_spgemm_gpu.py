@@ -767,3 +767,21 @@ def test_keyed_runs_for_a_general_b(oracle_d):
     assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
     assert oracle_d.check_spgemm(got, ref) == 0
     assert st.twin_rows > 0
+
+
+@pytest.mark.parametrize("prec", ["d", "s"])
+def test_numeric_rerun_of_ranked_window_rows(prec, lib_d, lib_s):
+    """nsparse_spgemm_hash_numeric on power-law rows: without the bitmaps of the symbolic phase the
+    re-run bins MORE rows into the ranked window (numeric bin 9), whose kernel then rebuilds its bitmap from C.col
+    (k_num_block<128, 65536, MODE 2>) -- an instantiation no other test reached (round 5: kernel coverage on the CPU
+    emulation, profiles/r05_emu_kernel_coverage_d.txt).  Same columns, same values as the full call."""
+    lib = lib_d if prec == "d" else lib_s
+    for p in ((10, 8, 0), (12, 8, 0)):
+        A = synth(lib, 3, *p, seed=3)
+        A = dict(A, val=A["val"].astype(lib.real))
+        got, st = spgemm(lib, A, numeric_again=True)
+        st2 = ns.SpgemmStats()
+        lib.nsparse_get_spgemm_stats(C.byref(st2))
+        assert st2.num_bin_size[9] > st.num_bin_size[9] > 0
+        assert np.array_equal(got["col_again"], got["col"])
+        np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9 if prec == "d" else 2e-6)
