@@ -319,6 +319,12 @@ __global__ __launch_bounds__(512) void k_spmv_amb_split(real *__restrict__ y, co
     }
 }
 
+#ifdef NSPARSE_EXPERIMENTS
+constexpr bool kSpmvExperiments = true;
+#else
+constexpr bool kSpmvExperiments = false;
+#endif
+
 template <int BSZ>
 static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipStream_t st)
 {
@@ -335,21 +341,34 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
     static const int env_remap = getenv("NSPARSE_SPMV_REMAP") ? 1 : 0;
     const long long stream_bytes = (long long)mat->nnz * (long long)sizeof(real) + (long long)mat->nnz / mat->block_size * 2;
     const int no_remap = env_noremap || (!env_remap && stream_bytes > (128LL << 20));
+    // (the forms below the whole-row kernel -- NSPARSE_SPMV_PIPE=0 / 1 / 2, NSPARSE_SPMV_PLAIN -- are round 1 / 2's kernels,
+    //  kept for the before / after counters of tools/pmc_spmv.sh: instantiated in -DNSPARSE_EXPERIMENTS builds only
+    //  (round 5: 200 of the 320 SpMV instantiations were reachable through those switches alone))
+#ifdef NSPARSE_EXPERIMENTS
     static const int plain = getenv("NSPARSE_SPMV_PLAIN") ? 1 : 0;
+#else
+    constexpr int plain = 0;
+#endif
     const dim3 grid(no_remap ? nb : nb8 * 8), block(tb);
     const int nb8_arg = no_remap ? 0 : nb8;
 #define NSP_GO(CC, AT)                                                                          \
-    if (plain)                                                                                  \
-        hipLaunchKernelGGL((k_spmv_amb<BSZ, CC, AT, false>), grid, block, 0, st, d_y, mat->d_sellcs_val, \
-                           mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
-                           mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg); \
-    else                                                                                        \
+    if constexpr (kSpmvExperiments) {                                                           \
+        if (plain)                                                                              \
+            hipLaunchKernelGGL((k_spmv_amb<BSZ, CC, AT, false>), grid, block, 0, st, d_y, mat->d_sellcs_val, \
+                               mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
+                               mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg); \
+    }                                                                                           \
+    if (!plain)                                                                                 \
         hipLaunchKernelGGL((k_spmv_amb<BSZ, CC, AT, true>), grid, block, 0, st, d_y, mat->d_sellcs_val, \
                            mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
                            mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg)
     // blocks of one batch of the pipelined form: as many as keep values + x within ~48 registers
     constexpr int UB = BSZ >= 12 ? 1 : (BSZ >= 6 ? 2 : (BSZ >= 3 ? 4 : 8));
+#ifdef NSPARSE_EXPERIMENTS
     static const int pipe = getenv("NSPARSE_SPMV_PIPE") ? atoi(getenv("NSPARSE_SPMV_PIPE")) : 4;  // 0: first form, 1 / 2: pipelined, 4: whole row in flight
+#else
+    constexpr int pipe = 4;
+#endif
 #define NSP_PIPE(AT, UBX)                                                                       \
     hipLaunchKernelGGL((k_spmv_amb_pipe<BSZ, AT, UBX>), grid, block, 0, st, d_y, mat->d_sellcs_val, \
                        mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
@@ -388,14 +407,16 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
             hipLaunchKernelGGL((k_spmv_amb_row<BSZ, false, NB, UB>), grid, block, 0, st, d_y, mat->d_sellcs_val,
                                mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation,
                                mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg);
-    } else if (mat->chunk == 64 && pipe && !plain) {
-        if (pipe == 2) {
-            if (atomic) { NSP_PIPE(true, 2 * UB); } else { NSP_PIPE(false, 2 * UB); }
-        } else {
-            if (atomic) { NSP_PIPE(true, UB); } else { NSP_PIPE(false, UB); }
-        }
     } else if (mat->chunk == 64) {
-        if (atomic) { NSP_GO(64, true); } else { NSP_GO(64, false); }
+        if constexpr (kSpmvExperiments) {
+            if (pipe == 2 && !plain) {
+                if (atomic) { NSP_PIPE(true, 2 * UB); } else { NSP_PIPE(false, 2 * UB); }
+            } else if (pipe && !plain) {
+                if (atomic) { NSP_PIPE(true, UB); } else { NSP_PIPE(false, UB); }
+            } else {
+                if (atomic) { NSP_GO(64, true); } else { NSP_GO(64, false); }
+            }
+        }
     } else {
         if (atomic) { NSP_GO(32, true); } else { NSP_GO(32, false); }
     }

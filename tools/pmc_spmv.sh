@@ -1,4 +1,5 @@
 #!/bin/bash
+# (NSPARSE_SPMV_PIPE / NSPARSE_SPMV_PLAIN: the library must be built with EXTRA=-DNSPARSE_EXPERIMENTS, see csrc/Makefile)
 # Counters of the AMB SpMV kernel on the nlpkkt-class matrix, round-1 form (NSPARSE_SPMV_PIPE=0 with the
 # XCD remap) against the round-2 default: memory traffic (FETCH_SIZE / WRITE_SIZE in their own passes),
 # L2 hits / misses, SQ wave cycles and wait cycles.  Output: gpurun_out/spmv_counters.json

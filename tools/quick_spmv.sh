@@ -1,4 +1,5 @@
 #!/bin/bash
+# (NSPARSE_SPMV_PIPE / NSPARSE_SPMV_PLAIN: the library must be built with EXTRA=-DNSPARSE_EXPERIMENTS, see csrc/Makefile)
 # usage: bash tools/quick_spmv.sh "NSPARSE_SPMV_PIPE=0" "NSPARSE_SPMV_PIPE=1" ...  (one bench run per setting)
 run() { echo "== $*"; env "$@" timeout 600 python bench.py --no-cpu --no-pmc --no-irregular --no-vendor --steps 2 2>/dev/null | python -c "
 import json,sys
