@@ -186,17 +186,18 @@ def test_bench_py_itself_on_the_emulated_device(gpus, emu_lib):
         assert "k_num_block<128, 1536" in d["roofline"]["kernel"] and d["spmv"]["hipgraph"]["ms_per_spmv"] > 0
 
 
-@pytest.mark.parametrize("stall,tails_run", [("", 6), ("k_setup_tail:2:400", 1), ("k_numeric_setup:1:400", 2)])
+@pytest.mark.parametrize("stall,tails_run", [("", 6), ("k_setup_tail:2:1500", 1), ("k_numeric_setup:1:1500", 2)])
 def test_grid_barrier_that_times_out_falls_back_to_the_chains(stall, tails_run, emu_lib):
     """fused.h: the grid barrier of the fused tails has ONE agreed outcome word (open / passed / failed by compare-and-swap,
     50 ms bound) -- re-written in round 4 without a device.  Here the census is skipped (NSPARSE_FUSED_FORCE=1), the
     tails run as 5 workgroups on 5 threads, and EMU_STALL holds one workgroup of the first or of the second tail back for
-    400 ms: the others time out, the late one READS "failed" and leaves its rows alone, the host sees the flag, repeats
+    1.5 s: the others time out, the late one READS "failed" and leaves its rows alone, the host sees the flag, repeats
     the call with the kernel chains (same C as the oracle), counts one fallback and stops fusing on that context."""
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "stalled_workgroup.py")], capture_output=True, text=True,
                        timeout=600, cwd=ROOT,
-                       env=dict(os.environ, NSPARSE_LIB_DIR=emu_lib, NSPARSE_FUSED_FORCE="1", EMU_STALL=stall, EMU_TRACE="1"))
+                       env=dict(os.environ, NSPARSE_LIB_DIR=emu_lib, NSPARSE_FUSED_FORCE="1", EMU_STALL=stall, EMU_TRACE="1",
+                                EMU_CLOCK_DIV="200"))  # (the 50 ms bound is ~0.5 s of a busy host's time)
     assert r.returncode == 0, r.stderr[-2000:]
     calls = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("[")][-1])
     assert len(calls) == 3 and all(c["equal"] and c["err"] == 0 for c in calls), calls
