@@ -20,7 +20,8 @@ def pytest_configure(config):
 ROUND4_UNPROVEN = ("test_bench_gpu.py", "test_aux_gpu.py", "test_native_row_partitioned_spgemm",
                    "test_split_row_spmv_for_cache_resident_matrices", "test_hash_bins_both_kernel_families[3]",
                    "test_big_table_bins_on_clustered_columns[3]", "test_one_wavefront_bin[3]",
-                   "test_random_amb_plans", "test_exotic_gpu.py", "test_numeric_rerun_of_ranked_window_rows")  # (round 5: first run on the CPU emulation, tests/emu)
+                   "test_random_amb_plans", "test_exotic_gpu.py", "test_numeric_rerun_of_ranked_window_rows",
+                   "test_config5_code_paths_at_a_fifth_of_the_edges")  # (round 5: first run on the CPU emulation, tests/emu)
 
 
 # ... and behind those, the tests whose verdict also depends on tools of the box (rocprofv3 marker traces, the ASan

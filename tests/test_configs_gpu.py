@@ -194,3 +194,20 @@ def test_config5_rmat22(lib_d, oracle_d):
     _structure_exact(got, ref)
     assert oracle_d.check_spgemm(got, dict(ref, M=A["M"])) == 0
     assert st.nnz_c == ref["nnz"] and got["flop"] == 2 * st.n_prod
+
+
+def test_config5_code_paths_at_a_fifth_of_the_edges(lib_d, oracle_d):
+    """The machinery that only a matrix wider than 2^20 columns switches on -- the cursor SYMBOLIC twin of the ranked
+    kernel (symbolic bin 10 over windows of up to 4 M columns), column lists written by the symbolic phase, list-driven
+    tiles of the numeric ranked kernel, dense tiles for the thick heavy rows -- on R-MAT scale 22 with 1.5 M edges:
+    99 M non-zeros in C instead of 1.96 G, so it also fits a 64 GB host (round 5: kernel coverage on the CPU emulation
+    showed that nothing but config 5 itself reached these lines, and config 5 needs the device's memory)."""
+    A = synth(lib_d, 3, 22, 0, 1500000, seed=0x5EED0022)
+    assert A["M"] == 4194304
+    got, st = spgemm(lib_d, A, numeric_again=True)
+    assert st.sym_bin_size[10] > 100 and st.num_bin_size[5] > 500 and st.max_nnz_row > 65536
+    ref = oracle_d.spgemm_omp(A, A)
+    _structure_exact(got, ref)
+    assert oracle_d.check_spgemm(got, dict(ref, M=A["M"])) == 0
+    assert np.array_equal(got["col_again"], got["col"])
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9)

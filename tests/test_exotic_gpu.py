@@ -51,6 +51,13 @@ def _cases():
                       (np.array([], int), [])])
     yield "a row of A with 200 K entries", hub, _from_scipy(sp.random(n, 5000, density=2e-4, format="csr", random_state=rng, dtype=np.float64))
     yield "rows of B with 200 K entries", _from_scipy(sp.random(600, 3, density=0.3, format="csr", random_state=rng, dtype=np.float64)), hub
+    # a thin heavy row of C (12 K non-zeros over 3 M columns: the ranked kernel) from a row of A with 6,000 entries -- more
+    # than the 4 x 1024 cursors the kernel keeps in registers, the rest live in its global slice (heavy_ranked.h)
+    nb, wide = 7000, 3_000_000
+    Bthin = _csr(nb, wide, [(np.sort(rng.choice(wide, 2, replace=False)), rng.random(2) + 0.1) for _ in range(nb)])
+    Along = _csr(4, nb, [(np.sort(rng.choice(nb, 6000, replace=False)), rng.random(6000) + 0.1), (np.array([3, 9]), [1.0, 2.0]),
+                         (np.sort(rng.choice(nb, 4500, replace=False)), rng.random(4500) + 0.1), (np.array([], int), [])])
+    yield "thin heavy rows from rows of A beyond the register cursors", Along, Bthin
     yield "1 x 1", _csr(1, 1, [(np.array([0]), [2.0])]), None
     col_v = _csr(400, 1, [(np.array([0]), [1.0 + i]) for i in range(400)])
     row_v = _csr(1, 400, [(np.arange(400), np.arange(400) + 1.0)])
