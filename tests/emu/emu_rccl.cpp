@@ -300,6 +300,10 @@ ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int
             delete c;
             return ncclSystemError;
         }
+        if (rank == 0) {  // everybody has both objects open: the names can go now, so that a rank killed later leaks nothing
+            shm_unlink(c->shm->name.c_str());
+            shm_unlink((c->shm->name + "-data").c_str());
+        }
     }
     *comm = c;
     return ncclSuccess;
