@@ -374,7 +374,13 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
                        mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
                        mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg, abl)
     static const int abl = getenv("NSPARSE_SPMV_ABL") ? atoi(getenv("NSPARSE_SPMV_ABL")) : 0;
-    constexpr int NB = BSZ >= 12 ? 1 : (BSZ >= 6 ? 3 : (BSZ >= 3 ? 10 : (BSZ == 2 ? 14 : 24)));
+    // blocks of the whole-row form: values + x of NB blocks are live at once = NB * BSZ * 2 operands, two registers
+    // each in double.  __launch_bounds__(1024) caps a lane at 128 VGPRs; past ~100 operand registers the compiler
+    // spills (round 5: NB = 10 for BSZ 4 / 5 cost 148 / 316 B of scratch per lane, NB = 3 for BSZ 11 36 B -- an
+    // HBM-bound kernel writing and re-reading its own operands).  BSZ <= 3 keep the measured settings (120 operand
+    // registers at BSZ 3, 124 VGPRs, no scratch); above that NB comes from a budget of 96.  The float build uses the
+    // same NB (half the registers).  tests/test_kernel_resources.py fails the build on any scratch.
+    constexpr int NB = BSZ == 1 ? 24 : (BSZ == 2 ? 14 : (BSZ == 3 ? 10 : (96 / (BSZ * 4) > 0 ? 96 / (BSZ * 4) : 1)));
     // cache-resident matrix of few chunks whose rows are wider than the whole-row form keeps in flight: split the
     // rows over W wavefronts (k_spmv_amb_split).  NSPARSE_SPMV_SPLIT=1: W chosen from the average row width, =2 / 4 / 8:
     // that many; default 0 (off) until the kernel has been timed against the whole-row form on the device
@@ -416,6 +422,9 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
             } else {
                 if (atomic) { NSP_GO(64, true); } else { NSP_GO(64, false); }
             }
+        } else {
+            // product builds instantiate the whole-row form only; reaching this means the invariant pipe == 4 && !plain broke
+            set_error(-21, "AMB SpMV: kernel form not instantiated in this build", __FILE__, __LINE__);
         }
     } else {
         if (atomic) { NSP_GO(32, true); } else { NSP_GO(32, false); }

@@ -44,6 +44,8 @@ def test_test_mtx_layout_chunk32(lib_d, oracle_d):
     ("rmat_s10", 65536, 1), ("rmat_s10", 256, 4),
     ("wide_seg", 65536, 1), ("wide_seg", 4096, 5), ("wide_seg", 65536, 2),
     ("banded_signed1k", 65536, 2),
+    # block sizes whose whole-row depth NB is derived from the register budget (spmv_amb.hip launch_bs, round 6)
+    ("banded2k", 2048, 11), ("banded2k", 65536, 12), ("rmat_s10", 65536, 6), ("wide_seg", 65536, 9),
 ])
 def test_manual_plan_bit_exact(name, seg, bs, prec, chunk, lib_d, lib_s, oracle_d, oracle_s):
     lib, orc = (lib_d, oracle_d) if prec == "d" else (lib_s, oracle_s)

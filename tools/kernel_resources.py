@@ -1,49 +1,106 @@
 #!/usr/bin/env python3
-"""Registers, scratch and occupancy of every kernel of the hash SpGEMM translation unit, from the compiler's
-own remarks (-Rpass-analysis=kernel-resource-usage; no GPU needed):
-    python tools/kernel_resources.py [d|s] [filter ...]      e.g.  python tools/kernel_resources.py d k_num_tb k_num_block
-A kernel with ScratchSize > 0 spills: in the latency-bound row kernels that has always cost more than it bought."""
+"""Registers, scratch, LDS and occupancy of every kernel of every HIP translation unit of the product, from the
+compiler's own remarks (-Rpass-analysis=kernel-resource-usage; no GPU needed):
+    python tools/kernel_resources.py [d|s] [--unit spgemm_hash|spmv_amb|amb_convert|dist_spmv|all] [--own] [filter ...]
+e.g. python tools/kernel_resources.py d --unit spmv_amb k_spmv_amb_row
+A kernel with ScratchSize > 0 spills: in the latency-bound row kernels that has always cost more than it bought, and
+an HBM-bound kernel that spills writes and re-reads its own operands.  tests/test_kernel_resources.py gates on it."""
 import os
 import re
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+UNITS = ("spgemm_hash", "spmv_amb", "amb_convert", "dist_spmv")
 
 
-def main():
-    prec = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1] in ("d", "s") else "d"
-    filt = [a for a in sys.argv[1:] if a not in ("d", "s")]
+def unit_resources(prec, unit, extra=()):
+    """[{name (demangled), own, vgpr, agpr, sgpr, scratch, occ, lds, vspill, sspill}] of one unit's device code."""
     src = os.path.join(ROOT, "nsparse_amd", "csrc")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", '-DNSPARSE_SRC_HASH="x"',
            "-munsafe-fp-atomics", "-I" + os.path.join(ROOT, "include"), "-I" + src,
-           "-DDOUBLE" if prec == "d" else "-DFLOAT", "--cuda-device-only", "-c", os.path.join(src, "spgemm_hash.hip"),
+           "-DDOUBLE" if prec == "d" else "-DFLOAT", *extra, "--cuda-device-only", "-c", os.path.join(src, unit + ".hip"),
            "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
-    err = subprocess.run(cmd, capture_output=True, text=True).stderr
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    if p.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s" % (unit, p.stderr[-2000:]))
     cur = None
     rows = []
-    for ln in err.splitlines():
+    for ln in p.stderr.splitlines():
         m = re.search(r"remark:\s+(.*?) \[-Rpass-analysis", ln)
         if not m:
             continue
         t = m.group(1).strip()
         if t.startswith("Function Name:"):
-            mangled = t.split(":", 1)[1].strip()
-            cur = {"name": mangled}
+            cur = {"mangled": t.split(":", 1)[1].strip()}
             rows.append(cur)
         elif cur is not None and ":" in t:
             k, v = t.split(":", 1)
             cur[k.strip()] = v.strip()
-    names = subprocess.run(["c++filt"], input="\n".join(r["name"] for r in rows),
+    names = subprocess.run(["c++filt"], input="\n".join(r["mangled"] for r in rows),
                            capture_output=True, text=True).stdout.splitlines()
-    print("%-64s %5s %5s %7s %4s %7s %6s %6s" % ("kernel", "VGPR", "SGPR", "scratch", "occ", "LDS", "vspill", "sspill"))
+    out = []
     for r, n in zip(rows, names):
-        short = re.sub(r"\(.*$", "", n).replace("void ", "").replace("nsp::spgemm::", "")
-        if filt and not any(f in short for f in filt):
-            continue
-        print("%-64s %5s %5s %7s %4s %7s %6s %6s" % (short[:64], r.get("VGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize [bytes/lane]"),
-                                                     r.get("Occupancy [waves/SIMD]"), r.get("LDS Size [bytes/block]"),
-                                                     r.get("VGPRs Spill"), r.get("SGPRs Spill")))
+        n = n.replace("void ", "", 1) if n.startswith("void ") else n
+        # template arguments stay (they tell the instantiations apart), the parameter list goes
+        depth, cut = 0, len(n)
+        for i, ch in enumerate(n):
+            if ch == "<":
+                depth += 1
+            elif ch == ">":
+                depth -= 1
+            elif ch == "(" and depth == 0:
+                cut = i
+                break
+        full = n[:cut]
+        own = full.startswith("nsp::") or full.startswith("k_")
+
+        def num(key):
+            try:
+                return int(r.get(key, "0"))
+            except ValueError:
+                return 0
+        out.append({"name": full, "own": own, "unit": unit, "vgpr": num("VGPRs"), "agpr": num("AGPRs"),
+                    "sgpr": num("TotalSGPRs"), "scratch": num("ScratchSize [bytes/lane]"),
+                    "occ": num("Occupancy [waves/SIMD]"), "lds": num("LDS Size [bytes/block]"),
+                    "vspill": num("VGPRs Spill"), "sspill": num("SGPRs Spill")})
+    return out
+
+
+def main():
+    args = sys.argv[1:]
+    prec = "d"
+    units = ["spgemm_hash"]
+    own_only = False
+    filt = []
+    i = 0
+    while i < len(args):
+        a = args[i]
+        if a in ("d", "s"):
+            prec = a
+        elif a == "--unit":
+            i += 1
+            units = list(UNITS) if args[i] == "all" else [args[i]]
+        elif a == "--own":
+            own_only = True
+        else:
+            filt.append(a)
+        i += 1
+    print("%-88s %5s %5s %7s %4s %7s %6s %6s" % ("kernel", "VGPR", "SGPR", "scratch", "occ", "LDS", "vspill", "sspill"))
+    n_own = n_scratch = 0
+    for u in units:
+        print("# unit %s.hip (%s)" % (u, "double" if prec == "d" else "float"))
+        for r in unit_resources(prec, u):
+            if own_only and not r["own"]:
+                continue
+            short = r["name"].replace("nsp::spgemm::", "").replace("nsp::spmv::", "").replace("nsp::amb::", "").replace("nsp::", "")
+            if filt and not any(f in short for f in filt):
+                continue
+            n_own += r["own"]
+            n_scratch += r["own"] and r["scratch"] > 0
+            print("%-88s %5d %5d %7d %4d %7d %6d %6d" % (short[:88], r["vgpr"] + r["agpr"], r["sgpr"], r["scratch"], r["occ"],
+                                                         r["lds"], r["vspill"], r["sspill"]))
+    print("# own kernels: %d, with scratch: %d" % (n_own, n_scratch))
 
 
 if __name__ == "__main__":
