@@ -246,9 +246,11 @@ def runtime_report():
                     libs[base] = path
     except OSError:
         pass
+    rocm = [v for k, v in libs.items() if k.startswith(("libamdhip64", "librccl", "librocsparse"))]
+    # no HIP runtime mapped at all (dry run, CPU emulation of the device) is NOT "on the system runtime"
     return {"mapped": libs, "torch_imported": "torch" in sys.modules,
-            "system_rocm_runtime": all(v.startswith("/opt/rocm") for k, v in libs.items()
-                                       if k.startswith(("libamdhip64", "librccl", "librocsparse")))}
+            "system_rocm_runtime": any(os.path.basename(v).startswith("libamdhip64") for v in rocm)
+                                   and all(v.startswith("/opt/rocm") for v in rocm)}
 
 
 def run_config(case, pmc, deadline):
@@ -413,6 +415,11 @@ def main():
     else:
         lib = ns.load("d")
         dl = ns.load_dist("d")
+    # a library built by tests/emu (the kernels compiled for the HOST against a lane-by-lane emulation of the device
+    # model) says so in its build string: whatever it produces is a test of control flow and answers, never a number
+    emulated_device = (not dry) and lib.nsparse_build_info().decode().split()[2:3] == ["emu"]
+    if emulated_device:
+        log("[bench] the loaded libnsparse is the CPU emulation build (tests/emu): this line is NOT a measurement")
     w = 8
     planes = 5 if dry else 257            # mesh planes of the cant-class brick per rank (cant: 62,451 = 3 * 9 * 9 * 257 rows)
     rows_rank = 3 * 9 * 9 * planes
@@ -934,6 +941,9 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic" if "synthetic" in src else "file",
             **({"emulated_ranks": "NSPARSE_BENCH_EMULATE=1: ranks share the GPUs that exist, no communicator -- a "
                                   "control-flow test, NOT a measurement"} if emulate and world > 1 else {}),
+            **({"emulated_device": "libnsparse was built by tests/emu (NSPARSE_LIB_DIR points at it): the kernels ran on "
+                                   "host threads -- answers are checked, every time is host time, NOT a measurement"}
+               if emulated_device else {}),
             **({"dry_run": "NSPARSE_BENCH_DRYRUN=1: no device, every time and counter is made up (tools/bench_dry.py) -- "
                            "a test of this script's control flow, NOT a measurement"} if dry else {}),
             "runtime": runtime_report(),

@@ -592,10 +592,17 @@ int nsparse_dist_spgemm(nsparse_dist_t h, sfCSR *a_block, sfCSR *b, sfCSR *c_blo
 {
     g_err = 0;
     if (!h || !a_block || !b || !c_block) return g_err = -1;
+    // c_block is an output: whatever its device pointers held on entry is not ours to free later
+    c_block->d_rpt = nullptr;
+    c_block->d_col = nullptr;
+    c_block->d_val = nullptr;
     spgemm_kernel_hash(a_block, b, c_block);  // synchronous; an empty block gives an empty C of a_block->M rows
     // the callee clears its (per-thread) error word on entry: non-zero now = this call failed, c_block is not a result
     const int after = nsparse_last_error();
     if (after != 0) {
+        // what the failed call had already allocated goes back to the library (advisor r05: it used to leak with the
+        // memset), then the struct is emptied so that nobody reads a half-built C
+        release_csr(*c_block);
         memset(c_block, 0, sizeof(*c_block));
         return g_err = after;
     }

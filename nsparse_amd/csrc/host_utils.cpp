@@ -444,11 +444,17 @@ void check_spgemm_answer(sfCSR c, sfCSR ans)
 #ifndef NSPARSE_SRC_HASH
 #define NSPARSE_SRC_HASH "unknown"
 #endif
-// "gfx950 <precision> <content hash of csrc + headers at build time>": lets a harness check that the
-// shared object it loaded was built from the sources beside it.
+// "gfx950 <precision> <content hash of csrc + headers at build time>[ experiments]": lets a harness check that the
+// shared object it loaded was built from the sources beside it, and whether it is the -DNSPARSE_EXPERIMENTS variant
+// (the one that reads the measurement switches and carries the opt-in kernels).
+#ifdef NSPARSE_EXPERIMENTS
+#define NSP_BUILD_KIND " experiments"
+#else
+#define NSP_BUILD_KIND ""
+#endif
 const char *nsparse_build_info(void)
 {
-    return NSPARSE_REAL_IS_FLOAT ? "gfx950 float " NSPARSE_SRC_HASH : "gfx950 double " NSPARSE_SRC_HASH;
+    return NSPARSE_REAL_IS_FLOAT ? "gfx950 float " NSPARSE_SRC_HASH NSP_BUILD_KIND : "gfx950 double " NSPARSE_SRC_HASH NSP_BUILD_KIND;
 }
 
 }  // extern "C"

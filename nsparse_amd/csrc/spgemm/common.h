@@ -19,6 +19,19 @@ constexpr bool kExperiments = true;
 constexpr bool kExperiments = false;
 #endif
 
+// tests/emu only: census of the B entries a heavy-row kernel loads against the products it accumulates (family =
+// FC_* below; what = 0 B.col loads, 1 B.val loads, 2 products, 3 tiles).  The product build compiles it away.
+enum { FC_TILED = 0, FC_RANKED = 1, FC_RANKED_SYM = 2, FC_FLAT = 3, FC_WALK = 4 };
+#ifdef NSP_EMU
+extern "C" void nsp_emu_count(int family, int what, long long n);
+#define NSP_COUNT(family, what, n) nsp_emu_count((family), (what), (long long)(n))
+#else
+#define NSP_COUNT(family, what, n) ((void)0)
+#endif
+// a counted load of one B column index / one B value (heavy-row kernels; FC = the kernel's family)
+#define NSP_LDC(FC, p, k) (NSP_COUNT(FC, 0, 1), (p)[k])
+#define NSP_LDV(FC, p, k) (NSP_COUNT(FC, 1, 1), (p)[k])
+
 // ---- bin ladders ------------------------------------------------------------------
 // Symbolic, n = intermediate products of the row (upper bound of its nnz):
 //   bin 0  n <= 32      sub-wave rows, 4 lanes per row, 64-key table per row

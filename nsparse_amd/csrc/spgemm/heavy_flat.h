@@ -1,0 +1,234 @@
+// spgemm/heavy_flat.h -- heavy numeric rows, STATELESS tiles over a panel table of B (round 6).
+// Part of the spgemm_hash.hip translation unit (kernels are launched from its host code).
+//
+// The cursor kernels (heavy_tiled.h, heavy_ranked.h) keep, per entry of the A row, a position in its row of B that
+// moves from tile to tile: tile t + 1 cannot start before tile t has written its cursors back, every lane-serial
+// cursor is a chain of dependent loads (state -> column -> compare -> refill), look-ahead that is not consumed is
+// fetched again (tests/emu census, profiles/r06_emu_fetch_counts.txt: 1.17-1.43 x the minimum bytes per product in
+// the dense tiles, 1.35-2.4 x in the ranked ones), and a hub row of A (more than 4096 entries) walks its state
+// arrays in global memory one entry after the other.
+//
+// Here the position is not carried, it is LOOKED UP: once per call a panel table of B is built,
+//     tab[s][p] = index of the first entry of the B row in slot s whose column is >= p * G      (p = 0 .. np),
+// so that the part of B row c inside column panel p is  [tab[slot(c)][p], tab[slot(c)][p + 1])  -- one 8-byte gather,
+// the same shape as the (B.rpt[c], B.rpt[c + 1]) gather of every other kernel.  A tile of a C row is then an ordinary
+// FLAT product walk (common.h: walk_products_flat) whose extents come from the table: three dependent round trips per
+// batch of 1024 entries of A whatever the lengths, vector loads of consecutive entries, no state to write back,
+// nothing that ties tile t + 1 to tile t, and every entry of B inside the table is fetched exactly once per C row.
+// Rows of B of at most `min_len` entries may be left out of the table (slot -1: matrices with millions of short
+// rows, where a pointer row per B row would dwarf B): they are walked whole by every tile and filtered by column --
+// 4 % of the products of the heavy rows of R-MAT-22.
+//
+// Replaces the tile loop of calculate_value_col_bin_each_gl (cuda-c/src/kernel/kernel_spgemm_hash_d.cu:929-1027: one
+// global-memory hash table per heavy row, then a sort) like k_num_tiled does; output identical to it.
+#pragma once
+#include "common.h"
+
+namespace nsp {
+namespace spgemm {
+
+// slot_of[r] = table slot of B row r (rows longer than min_len), -1 otherwise; slot_row[s] = r.  The order of the
+// slots is whatever the atomics make it: it names table rows, it does not reach the result.
+__global__ __launch_bounds__(256) void k_panel_slots(const int *__restrict__ brpt, int m, int min_len,
+                                                     int *__restrict__ slot_of, int *__restrict__ slot_row,
+                                                     int *__restrict__ count, int slots_max)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= m) return;
+    int s = -1;
+    if (brpt[r + 1] - brpt[r] > min_len) {
+        s = atomicAdd(count, 1);
+        if (s < slots_max) slot_row[s] = r;
+        else s = -1;  // (cannot happen: slots_max is an upper bound of the rows longer than min_len)
+    }
+    slot_of[r] = s;
+}
+
+// One thread per (slot, panel boundary): lower bound of p * G in the sorted row.
+__global__ __launch_bounds__(256) void k_panel_fill(const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                    const int *__restrict__ slot_row, const int *__restrict__ count,
+                                                    int np, int G, int *__restrict__ tab)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int stride = np + 1;
+    const long long s = i / stride;
+    const int p = (int)(i - s * stride);
+    if (s >= *count) return;
+    const int r = slot_row[s];
+    int lo = brpt[r], hi = brpt[r + 1];
+    const long long target = (long long)p * G;
+    while (lo < hi) {
+        const int mid = lo + ((hi - lo) >> 1);
+        if ((long long)bcol[mid] < target) lo = mid + 1;
+        else hi = mid;
+    }
+    tab[i] = lo;
+}
+
+// ===================================================================================
+//  heavy numeric rows: dense column tiles = panels of the table, one flat walk each
+// ===================================================================================
+// Same rows, same queue, same LDS window and the same ordered emission as k_num_tiled<BS, W>; G = W.
+template <int BS, int W>
+__global__ __launch_bounds__(BS) void k_num_flat(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                 const real *__restrict__ aval,
+                                                 const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                 const real *__restrict__ bval, int bnnz,
+                                                 const int *__restrict__ slot_of, const int *__restrict__ tab, int tstride,
+                                                 const int *__restrict__ crpt, int *__restrict__ ccol,
+                                                 real *__restrict__ cval,
+                                                 const int *__restrict__ row_perm, int bin_off, int count,
+                                                 BinState *bs, const int *__restrict__ row_lo,
+                                                 const int *__restrict__ row_span, int write_col, int dens,
+                                                 const long long *__restrict__ list_off, long long list_work,
+                                                 const int *__restrict__ row_prod)
+{
+    constexpr int NW = BS / 64;
+    constexpr int V = VW, U = 4;
+    constexpr int R = W / NW;  // columns of a tile emitted by one wavefront
+    constexpr int IT = R / 64;
+    static_assert(W % (NW * 64) == 0, "tile width must split evenly over the wavefronts");
+    __shared__ __attribute__((aligned(16))) acc_t dense[W];
+    __shared__ __attribute__((aligned(16))) unsigned int flag4[W / 4];
+    __shared__ int2 s_ext[BS];
+    __shared__ real s_av[BS];
+    __shared__ FlatScratch<BS> fs;
+    __shared__ int s_row;
+    __shared__ int s_wcnt[NW];
+    unsigned char *flag = reinterpret_cast<unsigned char *>(flag4);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    struct __attribute__((aligned(4))) I2 {
+        int b, e;
+    };
+    // The window is clean on entry to every tile: cleared here once, the emission resets what it finds occupied.
+    for (int i = threadIdx.x; i < W; i += BS) dense[i] = 0;
+    for (int i = threadIdx.x; i < W / 4; i += BS) flag4[i] = 0;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_row = atomicAdd(&bs->queue_head, 1);
+        __syncthreads();
+        const int q = s_row;
+        if (q >= count) break;
+        const int rid = row_perm[bin_off + q];
+        const int lo = row_lo[rid], span = row_span[rid];
+        // the rows k_num_tiled leaves to k_num_ranked / k_num_listed are left to them here as well
+        if (dens > 0 && ((long long)(crpt[rid + 1] - crpt[rid]) * dens < span || span > 32 * W)) continue;
+        if (list_work > 0 && list_wanted(crpt[rid + 1] - crpt[rid], row_prod[rid], list_work) &&
+            (list_off == nullptr || list_off[rid] >= 0))
+            continue;
+        const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+        const int p_lo = lo / W, p_hi = (int)(((long long)lo + span - 1) / W);
+        int pos = crpt[rid];
+        for (int p = p_lo; p <= p_hi; p++) {
+            const int c0 = p * W;
+            if (threadIdx.x == 0) NSP_COUNT(FC_FLAT, 3, 1);
+            // ---- one flat walk of the products of this tile ----------------------------------------------------
+            for (int b0 = a_beg; b0 < a_end; b0 += BS) {
+                const int nb = a_end - b0 < BS ? a_end - b0 : BS;
+                int2 e = make_int2(0, 0);
+                real av = 0;
+                if ((int)threadIdx.x < nb) {
+                    const int j = b0 + threadIdx.x;
+                    const int c = acol[j];  // (read again by every tile of the row: cacheable, not nontemporal)
+                    av = aval[j];
+                    const int s = slot_of[c];
+                    const I2 r = s >= 0 ? *reinterpret_cast<const I2 *>(tab + (long long)s * tstride + p)
+                                        : *reinterpret_cast<const I2 *>(brpt + c);  // short row: whole, filtered below
+                    e.x = r.b;
+                    e.y = r.e;
+                }
+                const int nch = (e.y - e.x + V - 1) / V;
+                s_ext[threadIdx.x] = e;
+                s_av[threadIdx.x] = av;
+                const int incl = wave_incl_scan(nch);
+                if (lane == 63) fs.wsum[w] = incl;
+                __syncthreads();
+                int base = 0, total = 0;
+#pragma unroll
+                for (int u = 0; u < NW; u++) {
+                    const int c = fs.wsum[u];
+                    base += u < w ? c : 0;
+                    total += c;
+                }
+                fs.pref[threadIdx.x] = base + incl - nch;
+                __syncthreads();
+                for (int ch0 = threadIdx.x; ch0 < total; ch0 += BS * U) {
+                    IVecT<V> pk[U];
+                    RVecT<V> pv[U];
+                    int pn[U];
+                    real sc[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int ch = ch0 + u * BS;
+                        pn[u] = 0;
+                        sc[u] = 0;
+                        if (ch < total) {
+                            int i = 0;  // the last entry whose first chunk is not beyond ch
+#pragma unroll
+                            for (int step = BS / 2; step >= 1; step >>= 1) {
+                                const int j = i + step;
+                                if (j < nb && fs.pref[j] <= ch) i = j;
+                            }
+                            const int2 x = s_ext[i];
+                            sc[u] = s_av[i];
+                            pn[u] = fetch_chunk<true, V>(bcol, bval, x.x + (ch - fs.pref[i]) * V, x.y, bnnz, pk[u], pv[u]);
+                            if (pn[u] > 0) {
+                                NSP_COUNT(FC_FLAT, 0, V);  // the vector load brings V entries, whatever pn says
+                                NSP_COUNT(FC_FLAT, 1, V);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+#pragma unroll
+                        for (int i = 0; i < V; i++) {
+                            const unsigned int idx = (unsigned int)(pk[u].v[i] - c0);
+                            if (i < pn[u] && idx < (unsigned int)W) {
+                                NSP_COUNT(FC_FLAT, 2, 1);
+                                flag[idx] = 1;
+                                unsafeAtomicAdd(dense + idx, (acc_t)(sc[u] * pv[u].v[i]));
+                            }
+                        }
+                    }
+                }
+                __syncthreads();  // the next batch overwrites the parked entries
+            }
+            lds_barrier();
+            // ---- ordered emission: wavefront w owns columns [w*R, (w+1)*R) of the tile (as in k_num_tiled) ---------
+            const int r0 = w * R;
+            unsigned long long msk[IT];
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < IT; j++) {
+                msk[j] = __ballot(flag[r0 + j * 64 + lane] != 0);
+                cnt += __popcll(msk[j]);
+            }
+            if (lane == 0) s_wcnt[w] = cnt;
+            lds_barrier();
+            int wpos = pos, total = 0;
+            for (int u = 0; u < NW; u++) {
+                const int c = s_wcnt[u];
+                if (u < w) wpos += c;
+                total += c;
+            }
+#pragma unroll
+            for (int j = 0; j < IT; j++) {
+                const unsigned long long m = msk[j];
+                if ((m >> lane) & 1ull) {
+                    const int idx = r0 + j * 64 + lane;
+                    const int o = wpos + __popcll(m & ((1ull << lane) - 1ull));
+                    if (write_col & 1) ccol[o] = c0 + idx;
+                    cval[o] = (real)dense[idx];
+                    dense[idx] = 0;  // leave the window clean for the next tile
+                    flag[idx] = 0;
+                }
+                wpos += __popcll(m);
+            }
+            pos += total;
+            lds_barrier();
+        }
+    }
+}
+
+}  // namespace spgemm
+}  // namespace nsp

@@ -148,7 +148,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             e_nc[u] = INF;
             e_av[u] = 0;
             if (e < alen && init_entry(e, e_cur[u], e_end[u], e_av[u]) && e_cur[u] < e_end[u])
-                e_nc[u] = bcol[e_cur[u]];
+                e_nc[u] = NSP_LDC((SYM ? FC_RANKED_SYM : FC_RANKED), bcol, e_cur[u]);
         }
         for (int e = threadIdx.x + EPT * BS; e < alen; e += BS) {
             int cur, end;
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             const bool serial = init_entry(e, cur, end, av);
             st_cur[e] = cur;
             st_end[e] = end;
-            st_next[e] = (serial && cur < end) ? bcol[cur] : INF;
+            st_next[e] = (serial && cur < end) ? NSP_LDC((SYM ? FC_RANKED_SYM : FC_RANKED), bcol, cur) : INF;
             st_av[e] = av;
         }
         __syncthreads();
@@ -202,10 +202,12 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                 if (wd_est < 1024) wd_est = 1024;
                 t_max = rem_span <= wd_est ? row_end : t_lo + (int)wd_est;
             }
+            if (threadIdx.x == 0) NSP_COUNT(SYM ? FC_RANKED_SYM : FC_RANKED, 3, 1);
             // One walk of everything inside [t_lo, t_hi).  PASS2 = false: mark columns.
             // PASS2 = true: accumulate by rank and commit the cursors.
             auto touch = [&](auto pass2, int col, real x) {
                 const unsigned int idx = (unsigned int)(col - t_lo);
+                if (decltype(pass2)::value) NSP_COUNT(SYM ? FC_RANKED_SYM : FC_RANKED, 2, 1);
                 if (SYM || !decltype(pass2)::value) {
                     atomicOr(&bits[idx >> 5], 1u << (idx & 31));
                 } else {
@@ -218,10 +220,10 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             auto load_batch = [&](auto pass2, int k, int end, int c0, int(&c)[LA], real(&v)[LA]) {
                 c[0] = c0;
 #pragma unroll
-                for (int j = 1; j < LA; j++) c[j] = k + j < end ? bcol[k + j] : INF;
+                for (int j = 1; j < LA; j++) c[j] = k + j < end ? NSP_LDC((SYM ? FC_RANKED_SYM : FC_RANKED), bcol, k + j) : INF;
                 if (!SYM && decltype(pass2)::value) {
 #pragma unroll
-                    for (int j = 0; j < LA; j++) v[j] = k + j < end ? bval[k + j] : (real)0;
+                    for (int j = 0; j < LA; j++) v[j] = k + j < end ? NSP_LDV((SYM ? FC_RANKED_SYM : FC_RANKED), bval, k + j) : (real)0;
                 }
             };
             // uses the leading pairs that lie inside the tile; returns how many, and the column after them
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             };
             // after a batch that was used up completely: keep going, one round trip per batch
             auto walk_rest = [&](auto pass2, int t_hi, int &k, int end, int &col, real av) {
-                col = k < end ? bcol[k] : INF;
+                col = k < end ? NSP_LDC((SYM ? FC_RANKED_SYM : FC_RANKED), bcol, k) : INF;
                 while (col < t_hi) {
                     int c[LA];
                     real v[LA];
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                     const int n = consume(pass2, t_hi, c, v, av, col);
                     k += n;
                     if (n < LA) return;
-                    col = k < end ? bcol[k] : INF;
+                    col = k < end ? NSP_LDC((SYM ? FC_RANKED_SYM : FC_RANKED), bcol, k) : INF;
                 }
             };
             auto walk = [&](auto pass2, int t_hi) {
@@ -266,9 +268,9 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                         const int i = i0 + j * NW;
                         mt[j] = i < nlong ? l_meta[i] : make_int4(0, 0, 64, 0);
                         const int kk = mt[j].x + lane;
-                        col[j] = kk < mt[j].y ? bcol[kk] : INF;
+                        col[j] = kk < mt[j].y ? NSP_LDC((SYM ? FC_RANKED_SYM : FC_RANKED), bcol, kk) : INF;
                         bv[j] = 0;
-                        if (P2 && !SYM) bv[j] = kk < mt[j].y ? bval[kk] : (real)0;
+                        if (P2 && !SYM) bv[j] = kk < mt[j].y ? NSP_LDV((SYM ? FC_RANKED_SYM : FC_RANKED), bval, kk) : (real)0;
                     }
                 };
                 auto sweep_use = [&](int i0, const int4(&mt)[SB], const int(&col)[SB], const real(&bv)[SB]) {
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                             if (__builtin_amdgcn_readlane(c, 63) >= t_hi) break;
                             k += mt[j].z;
                             const int kk = k + lane;
-                            c = kk < mt[j].y ? bcol[kk] : INF;
-                            if (P2 && !SYM) x = kk < mt[j].y ? bval[kk] : (real)0;
+                            c = kk < mt[j].y ? NSP_LDC((SYM ? FC_RANKED_SYM : FC_RANKED), bcol, kk) : INF;
+                            if (P2 && !SYM) x = kk < mt[j].y ? NSP_LDV((SYM ? FC_RANKED_SYM : FC_RANKED), bval, kk) : (real)0;
                         }
                         if (P2 && lane == 0) l_meta[i].x = k;
                     }

@@ -124,12 +124,12 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
             if (e < alen && init_entry(e, e_cur[u], e_end[u], e_av[u])) {
                 const int k = e_cur[u], end = e_end[u];
                 if (k < end) {
-                    e_c0[u] = bcol[k];
-                    e_v0[u] = bval[k];
+                    e_c0[u] = NSP_LDC(FC_TILED, bcol, k);
+                    e_v0[u] = NSP_LDV(FC_TILED, bval, k);
                 }
                 if (k + 1 < end) {
-                    e_c1[u] = bcol[k + 1];
-                    e_v1[u] = bval[k + 1];
+                    e_c1[u] = NSP_LDC(FC_TILED, bcol, k + 1);
+                    e_v1[u] = NSP_LDV(FC_TILED, bval, k + 1);
                 }
             }
         }
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
             const bool serial = init_entry(e, cur, end, av);
             st_cur[e] = cur;
             st_end[e] = end;
-            st_next[e] = (serial && cur < end) ? bcol[cur] : INF;
+            st_next[e] = (serial && cur < end) ? NSP_LDC(FC_TILED, bcol, cur) : INF;
             st_av[e] = av;
         }
         __syncthreads();
@@ -157,12 +157,12 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                 const int4 mt = l_meta[i];
                 const int ka = mt.x + lane, kb = ka + mt.z;
                 if (ka < mt.y) {
-                    pa_col[s] = bcol[ka];
-                    pa_val[s] = bval[ka];
+                    pa_col[s] = NSP_LDC(FC_TILED, bcol, ka);
+                    pa_val[s] = NSP_LDV(FC_TILED, bval, ka);
                 }
                 if (kb < mt.y) {
-                    pb_col[s] = bcol[kb];
-                    pb_val[s] = bval[kb];
+                    pb_col[s] = NSP_LDC(FC_TILED, bcol, kb);
+                    pb_val[s] = NSP_LDV(FC_TILED, bval, kb);
                 }
             }
         }
@@ -171,9 +171,11 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
         int pos = crpt[rid];
         for (int t0 = 0; t0 < span; t0 += W) {
             const int tw = span - t0 < W ? span - t0 : W;  // columns in this tile
+            if (threadIdx.x == 0) NSP_COUNT(FC_TILED, 3, 1);
             const int c0 = lo + t0, tile_end = c0 + tw;
             auto acc = [&](int col, real x) {
                 const int idx = col - c0;
+                NSP_COUNT(FC_TILED, 2, 1);
                 flag[idx] = 1;
                 unsafeAtomicAdd(dense + idx, (acc_t)x);
             };
@@ -208,8 +210,8 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                         pa_val[s] = pb_val[s];
                         const int k = mt.x + mt.z + lane;
                         const bool ok = k < mt.y;
-                        pb_col[s] = ok ? bcol[k] : INF;
-                        pb_val[s] = ok ? bval[k] : (real)0;
+                        pb_col[s] = ok ? NSP_LDC(FC_TILED, bcol, k) : INF;
+                        pb_val[s] = ok ? NSP_LDV(FC_TILED, bval, k) : (real)0;
                         more = true;
                     }
                 }
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                             e_cur[u] += 2;
                             const int k = e_cur[u];
                             const bool ok = k < e_end[u];
-                            e_c0[u] = ok ? bcol[k] : INF;
-                            e_v0[u] = ok ? bval[k] : (real)0;
+                            e_c0[u] = ok ? NSP_LDC(FC_TILED, bcol, k) : INF;
+                            e_v0[u] = ok ? NSP_LDV(FC_TILED, bval, k) : (real)0;
                             more = true;
                         } else {
                             e_cur[u] += 1;
@@ -233,8 +235,8 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                         }
                         const int k1 = e_cur[u] + 1;
                         const bool ok1 = k1 < e_end[u];
-                        e_c1[u] = ok1 ? bcol[k1] : INF;
-                        e_v1[u] = ok1 ? bval[k1] : (real)0;
+                        e_c1[u] = ok1 ? NSP_LDC(FC_TILED, bcol, k1) : INF;
+                        e_v1[u] = ok1 ? NSP_LDV(FC_TILED, bval, k1) : (real)0;
                     }
                 }
             } while (__any(more));
@@ -257,8 +259,8 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                     mt[j] = i < nlong ? l_meta[i] : make_int4(0, 0, 64, INF);
                     const int k = mt[j].x + lane;
                     const bool ld = mt[j].w < tile_end && k < mt[j].y;
-                    col[j] = ld ? bcol[k] : INF;
-                    bv[j] = ld ? bval[k] : (real)0;
+                    col[j] = ld ? NSP_LDC(FC_TILED, bcol, k) : INF;
+                    bv[j] = ld ? NSP_LDV(FC_TILED, bval, k) : (real)0;
                 }
 #pragma unroll
                 for (int j = 0; j < SB; j++) {
@@ -273,8 +275,8 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                         if (__builtin_amdgcn_readlane(c, 63) >= tile_end) break;
                         cp += mt[j].z;
                         const int k = cp + lane;
-                        c = k < mt[j].y ? bcol[k] : INF;
-                        x = k < mt[j].y ? bval[k] : (real)0;
+                        c = k < mt[j].y ? NSP_LDC(FC_TILED, bcol, k) : INF;
+                        x = k < mt[j].y ? NSP_LDV(FC_TILED, bval, k) : (real)0;
                     }
                     // columns ascend across the lanes: the first lane at or beyond the tile end holds
                     // the next column this slot will contribute
@@ -300,9 +302,9 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                         real v[LA];
                         c[0] = col;
 #pragma unroll
-                        for (int j = 1; j < LA; j++) c[j] = cur + j < end ? bcol[cur + j] : INF;
+                        for (int j = 1; j < LA; j++) c[j] = cur + j < end ? NSP_LDC(FC_TILED, bcol, cur + j) : INF;
 #pragma unroll
-                        for (int j = 0; j < LA; j++) v[j] = cur + j < end ? bval[cur + j] : (real)0;
+                        for (int j = 0; j < LA; j++) v[j] = cur + j < end ? NSP_LDV(FC_TILED, bval, cur + j) : (real)0;
                         int n = 0;
                         col = INF;
 #pragma unroll
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(BS) void k_num_tiled(const int *__restrict__ arpt, 
                             }
                         }
                         cur += n;
-                        if (n == LA) col = cur < end ? bcol[cur] : INF;
+                        if (n == LA) col = cur < end ? NSP_LDC(FC_TILED, bcol, cur) : INF;
                     }
                     st_cur[e] = cur;
                     st_next[e] = col;

@@ -49,6 +49,7 @@
 //   spgemm/block.h         k_num_block, k_twin_groups                     (numeric bins 6-9: node blocks)
 //   spgemm/heavy_tiled.h   k_num_tiled                                    (bin 5, dense tiles)
 //   spgemm/heavy_ranked.h  k_num_ranked                                   (bin 5, thin rows)
+//   spgemm/heavy_flat.h    k_panel_slots, k_panel_fill, k_num_flat        (bin 5, stateless tiles; experiments build)
 //   spgemm/lean.h          k_sym_lean, k_num_lean                         (hash bins 1-4 on an instruction diet, round 4)
 //
 // Results: C.rpt / C.col are bit-identical to the reference by construction (distinct
@@ -72,6 +73,7 @@
 #include "spgemm/fused.h"
 #include "spgemm/heavy_tiled.h"
 #include "spgemm/heavy_ranked.h"
+#include "spgemm/heavy_flat.h"
 #include "spgemm/lean.h"
 
 namespace nsp {
@@ -265,7 +267,7 @@ struct BinLauncher {
     bool timed;      // begin / end events per bin (nsparse_set_bin_timing, or profiling mode)
     int main_bin;    // the bin with the most rows runs on the main stream itself (no fork/join)
     bool side_bins = false;  // some other bin has rows: only then is the fork event worth recording
-    void *deferred[4] = {};  // scratch of kernels still in flight: returned to the cache by collect()
+    void *deferred[8] = {};  // scratch of kernels still in flight: returned to the cache by collect()
     int ndeferred = 0;
     void free_later(void *p) { deferred[ndeferred++] = p; }
     int most_bin = -1;  // the bin with the most rows
@@ -637,7 +639,37 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                        bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows,   \
                        d_bs, row_lo, row_span, slab, stride_ints, amax, write_col, long_len, d_prof, ranked_dens, \
                        list_off, list_w, row_prod)
-        if (ranked_dens >= 0) {
+        // NSPARSE_HEAVY_FLAT=1 (experiments build, until it has been timed on the device): the dense tiles as
+        // stateless flat walks over a panel table of B (heavy_flat.h) instead of the cursor kernel
+        static const int heavy_flat = exp_env("NSPARSE_HEAVY_FLAT", 0);
+        bool flat_done = false;
+        if constexpr (kExperiments) {
+            if (heavy_flat && ranked_dens >= 0 && tile_sel == 0) {
+                const int np = (int)(((long long)b->N + kTileW - 1) / kTileW);
+                // every row of B in the table while that stays small next to B; else only rows of more than 16 entries
+                // (an upper bound of their number sizes the table: no round trip to the host)
+                const bool all_rows = (long long)b->M * (np + 1) * 4 <= (256LL << 20);
+                const int min_len = all_rows ? -1 : 16;
+                const long long slots_max = all_rows ? (long long)b->M : std::min<long long>(b->M, (long long)b->nnz / (min_len + 1) + 1);
+                // one block: [count, pad | slot_of: M | slot_row: slots_max | tab: slots_max * (np + 1)]
+                const size_t n_ints = 2 + (size_t)b->M + (size_t)slots_max + (size_t)slots_max * (np + 1) + 2;
+                int *blk = (int *)dev_alloc(sizeof(int) * n_ints);
+                int *d_cnt = blk, *slot_of = blk + 2, *slot_row = slot_of + b->M, *tab = slot_row + slots_max;
+                NSP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
+                hipLaunchKernelGGL(k_panel_slots, dim3(ceil_div(b->M, 256)), dim3(256), 0, st, brpt, b->M, min_len, slot_of,
+                                   slot_row, d_cnt, (int)slots_max);
+                const long long cells = slots_max * (np + 1);
+                hipLaunchKernelGGL(k_panel_fill, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, brpt, bcol,
+                                   (const int *)slot_row, (const int *)d_cnt, np, kTileW, tab);
+                hipLaunchKernelGGL((k_num_flat<1024, kTileW>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval, brpt, bcol,
+                                   bval, b->nnz, (const int *)slot_of, (const int *)tab, np + 1, c->d_rpt, c->d_col, c->d_val,
+                                   row_perm, off[kNumGlobalBin], rows, d_bs, row_lo, row_span, write_col, ranked_dens,
+                                   list_off, list_w, row_prod);
+                L.free_later(blk);
+                flat_done = true;
+            }
+        }
+        if (ranked_dens >= 0 && !flat_done) {
 #ifdef NSPARSE_EXPERIMENTS
             if (tile_sel == 1) { NSP_TILED(1024, kTileW / 2); }
             else if (tile_sel == 2) { NSP_TILED(512, kTileW / 2); }
@@ -752,10 +784,14 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
         if (lean_on && (grp || blk_all)) {                                                     \
             if constexpr ((BS) == 128 || kExperiments) {                                       \
                 if (write_col & 1) NSP_NUM_BLOCK_GO(BS, SPAN, 1) else NSP_NUM_BLOCK_GO(BS, SPAN, 2) \
+            } else {  /* the invariant blk <=> 128 threads broke: report, never leave the bin's rows unwritten */ \
+                set_error(-21, "window kernel not instantiated for this workgroup size", __FILE__, __LINE__); \
             }                                                                                  \
         } else {                                                                               \
             if constexpr ((BS) != 128 || kExperiments) {                                       \
                 if (write_col & 1) NSP_NUM_DENSE_GO(BS, SPAN, 1) else NSP_NUM_DENSE_GO(BS, SPAN, 2) \
+            } else {                                                                           \
+                set_error(-21, "window kernel not instantiated for this workgroup size", __FILE__, __LINE__); \
             }                                                                                  \
         }                                                                                      \
         NSP_LAUNCH_CHECK();                                                                    \

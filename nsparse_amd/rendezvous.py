@@ -22,6 +22,7 @@ The directory: $NSPARSE_RDV when the launcher made one (bench.py spawning its ow
 import hmac
 import json
 import os
+import select
 import socket
 import stat
 import struct
@@ -102,10 +103,31 @@ def _recv(sock):
         if not chunk:
             raise RendezvousError("peer closed the connection")
         buf += chunk
+    return _parse(bytes(buf))
+
+
+def _parse(data):
     try:
-        return _dec(json.loads(bytes(buf).decode()))
-    except (ValueError, UnicodeDecodeError) as e:
-        raise RendezvousError(f"malformed message: {e!r}") from e
+        return _dec(json.loads(data.decode()))
+    except (ValueError, UnicodeDecodeError, RecursionError) as e:  # (RecursionError: a deeply nested payload)
+        raise RendezvousError(f"malformed message: {type(e).__name__}") from e
+
+
+MAX_HELLO = 4096      # bytes: {"rank": r, "token": 32 hex digits}
+HELLO_TIMEOUT = 5.0   # a connection that has not said hello by then is closed; it delays nobody meanwhile
+
+
+def _hello_ok(hello, world, joined, token):
+    """True when `hello` is {rank: an int in 1..world-1 that has not joined, token: this job's}.  Tokens are compared
+    as BYTES (hmac.compare_digest refuses non-ASCII str), and nothing a stranger can put into the message may raise."""
+    try:
+        r = hello.get("rank") if isinstance(hello, dict) else None
+        tok = hello.get("token") if isinstance(hello, dict) else None
+        return (isinstance(r, int) and not isinstance(r, bool) and 1 <= r < world and r not in joined
+                and isinstance(tok, str)
+                and hmac.compare_digest(tok.encode("utf-8", "surrogatepass"), token.encode()))
+    except Exception:  # noqa: BLE001 -- whatever it was, it was not a rank of this job
+        return False
 
 
 class Rendezvous:
@@ -132,32 +154,67 @@ class Rendezvous:
                 f.write(f"{srv.getsockname()[1]} {token}")
             os.replace(tmp, port_file)  # atomic: a reader sees the whole number or no file
             self._srv = srv
-            while len(self.peers) < self.world - 1:
-                left = deadline - time.time()
-                if left <= 0:
-                    missing = sorted(set(range(1, self.world)) - set(self.peers))
-                    raise RendezvousError(f"rank 0: ranks {missing} of {self.world} did not join within "
-                                          f"{self.timeout:.0f} s ({self.dir})")
-                srv.settimeout(left)
-                try:
-                    conn, _ = srv.accept()
-                except socket.timeout:
-                    continue
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                conn.settimeout(min(self.timeout, 5.0))  # a stranger that connects and says nothing costs 5 s, not the job
-                try:
-                    hello = _recv(conn)
-                    r = hello.get("rank") if isinstance(hello, dict) else None
-                    ok = (isinstance(r, int) and not isinstance(r, bool) and 1 <= r < self.world and r not in self.peers
-                          and isinstance(hello.get("token"), str) and hmac.compare_digest(hello["token"], token))
-                except (RendezvousError, OSError):
-                    ok = False
-                if not ok:
-                    self.rejected += 1
-                    conn.close()
-                    continue
-                conn.settimeout(self.timeout)
-                self.peers[r] = conn
+            # Hellos are read concurrently: every accepted connection waits in `pending` with its own deadline and
+            # buffer, so a stranger that connects and says nothing (or dribbles bytes) holds up no real rank.
+            pending = {}  # socket -> [bytes so far, drop-dead time]
+            try:
+                while len(self.peers) < self.world - 1:
+                    now = time.time()
+                    if now >= deadline:
+                        missing = sorted(set(range(1, self.world)) - set(self.peers))
+                        raise RendezvousError(f"rank 0: ranks {missing} of {self.world} did not join within "
+                                              f"{self.timeout:.0f} s ({self.dir})")
+                    for c in [c for c, (_, t) in pending.items() if t <= now]:
+                        self._reject(pending, c)
+                    wake = min([deadline] + [t for _, t in pending.values()])
+                    ready, _, _ = select.select([srv] + list(pending), [], [], max(0.0, min(wake - now, 1.0)))
+                    for c in ready:
+                        if c is srv:
+                            try:
+                                conn, _ = srv.accept()
+                            except OSError:
+                                continue
+                            if len(pending) >= 4 * self.world + 16:  # a flood: the oldest waiting stranger goes
+                                self._reject(pending, min(pending, key=lambda k: pending[k][1]))
+                            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                            conn.setblocking(False)
+                            pending[conn] = [b"", time.time() + min(self.timeout, HELLO_TIMEOUT)]
+                            continue
+                        # exactly the bytes of the hello and no more: what a rank sends next (its first collective)
+                        # stays in the socket for _exchange
+                        buf = pending[c][0]
+                        want = 4 - len(buf) if len(buf) < 4 else 4 + struct.unpack("<I", buf[:4])[0] - len(buf)
+                        try:
+                            chunk = c.recv(want)
+                        except (BlockingIOError, InterruptedError):
+                            continue
+                        except OSError:
+                            chunk = b""
+                        if not chunk:
+                            self._reject(pending, c)
+                            continue
+                        buf += chunk
+                        pending[c][0] = buf
+                        if len(buf) < 4:
+                            continue
+                        n = struct.unpack("<I", buf[:4])[0]
+                        if n > MAX_HELLO:
+                            self._reject(pending, c)  # an absurd length is refused before anything is buffered
+                        elif len(buf) == 4 + n:
+                            try:
+                                hello = _parse(buf[4:])
+                            except Exception:  # noqa: BLE001
+                                hello = None
+                            if _hello_ok(hello, self.world, self.peers, token):
+                                del pending[c]
+                                c.setblocking(True)
+                                c.settimeout(self.timeout)
+                                self.peers[hello["rank"]] = c
+                            else:
+                                self._reject(pending, c)
+            finally:
+                for c in list(pending):
+                    c.close()
         else:
             while not os.path.exists(port_file):
                 if time.time() > deadline:
@@ -171,6 +228,11 @@ class Rendezvous:
             self.sock.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             self.sock.settimeout(self.timeout)
             _send(self.sock, {"rank": self.rank, "token": token})
+
+    def _reject(self, pending, conn):
+        self.rejected += 1
+        pending.pop(conn, None)
+        conn.close()
 
     # ---- the one primitive: everybody's object to rank 0, f(list) back to everybody --------------------------
     def _exchange(self, obj, combine, what):

@@ -803,4 +803,21 @@ void emu_reset_stats(void)
 {
     for (int i = 0; i < 8; i++) emu::g_stats[i] = 0;
 }
+// ---- B-entry fetch census (round 6): the product's heavy-row kernels report, per kernel family, how many column
+// indices and values of B they loaded and how many products they accumulated (spgemm/common.h: NSP_COUNT, compiled in
+// under NSP_EMU only).  Bytes, not clocks: "B entries fetched per product" is a property of the algorithm that a CPU
+// can count.  16 families x {0: B.col loads, 1: B.val loads, 2: products accumulated, 3: tiles / rows (kernel's own)}.
+static std::atomic<long long> g_fetch[16][4];
+void nsp_emu_count(int family, int what, long long n)
+{
+    if ((unsigned)family < 16u && (unsigned)what < 4u) g_fetch[family][what].fetch_add(n, std::memory_order_relaxed);
+}
+void emu_get_fetch_counts(long long out[64], int reset)
+{
+    for (int f = 0; f < 16; f++)
+        for (int w = 0; w < 4; w++) {
+            out[f * 4 + w] = g_fetch[f][w].load();
+            if (reset) g_fetch[f][w] = 0;
+        }
+}
 }

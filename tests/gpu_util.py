@@ -203,6 +203,15 @@ def ladders(lib):
     return list(sym), list(num)
 
 
+def experiments_lib_dir():
+    """The -DNSPARSE_EXPERIMENTS sibling of the library directory in use (nsparse_amd/lib -> nsparse_amd/lib_exp,
+    tests/emu/lib -> tests/emu/lib_exp: __graft_entry__.build() makes both), or None when it has not been built."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cur = os.environ.get("NSPARSE_LIB_DIR") or os.path.join(root, "nsparse_amd", "lib")
+    exp = cur.rstrip("/") + "_exp"
+    return exp if os.path.exists(os.path.join(exp, "libnsparse_d.so")) else None
+
+
 def spgemm_subprocess(A, env, prec="d", B=None):
     """Run spgemm() on A (times B, default A) in a fresh interpreter with extra environment (the
     library reads its tuning switches once per process).  Returns (C dict, dict of stats lists)."""
@@ -223,9 +232,10 @@ def spgemm_subprocess(A, env, prec="d", B=None):
             "A = ld(%r); B = ld(%r);"
             "got, st = spgemm(ns.load(%r), A, B);"
             "np.savez(%r, rpt=got['rpt'], col=got['col'], val=got['val']);"
-            "print(json.dumps(dict(sym=list(st.sym_bin_size), num=list(st.num_bin_size), fails=st.sym_fail_rows)))"
+            "print(json.dumps(dict(sym=list(st.sym_bin_size), num=list(st.num_bin_size), fails=st.sym_fail_rows,"
+            " build=ns.load(%r).nsparse_build_info().decode())))"
         ) % (root, os.path.join(root, "tests"), os.path.join(td, "a.npz"), os.path.join(td, "b.npz"), prec,
-             os.path.join(td, "c.npz"))
+             os.path.join(td, "c.npz"), prec)
         r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
                            env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-3000:]

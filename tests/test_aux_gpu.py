@@ -77,6 +77,7 @@ def test_roctx_ranges_reach_a_marker_trace(tmp_path):
     assert "nsparse:spgemm" in text or "roctxRangePush" in text, text[:500]
 
 
+
 def test_asan_build_runs_clean():
     """`make -C nsparse_amd/csrc asan` (host code instrumented: loader, plan search, workspace cache, launch paths): one
     small SpGEMM and one AMB SpMV through that library with the ASan runtime preloaded; no report."""
@@ -95,9 +96,14 @@ def test_asan_build_runs_clean():
     env = dict(os.environ, LD_PRELOAD=rt, NSPARSE_LIB_DIR=libdir,
                ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:exitcode=23")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-    if "AddressSanitizer" in r.stderr and "libnsparse" not in r.stderr:
-        pytest.skip("ASan report with no frame of this library in it (the ROCm runtime under a preloaded ASan): "
-                    + r.stderr[-400:])
+    if "AddressSanitizer" in r.stderr:
+        # Skipped ONLY when the faulting frame is positively the ROCm runtime's (a preloaded ASan under libamdhip64 /
+        # libhsa-runtime64 reports on their own allocations); an overflow caught in a memcpy / memset interceptor called
+        # from this library, or a report whose stack cannot be read, FAILS.
+        from asan_report import ROCM_RUNTIME_MODULES, first_module
+        culprit = first_module(r.stderr)
+        if culprit is not None and culprit.startswith(ROCM_RUNTIME_MODULES):
+            pytest.skip(f"ASan report raised inside the ROCm runtime ({culprit}), not by this library: " + r.stderr[-400:])
     assert "AddressSanitizer" not in r.stderr, r.stderr[-3000:]
     assert r.returncode == 0 and "DONE" in r.stdout, (r.returncode, r.stderr[-2000:])
 

@@ -178,6 +178,8 @@ def test_bench_py_itself_on_the_emulated_device(gpus, emu_lib):
     assert len(lines) == 1, r.stdout[:400]
     d = json.loads(lines[0])
     assert d["n_gpus"] == gpus and d["value"] > 0 and "dry_run" not in d and "emulated_ranks" not in d
+    # ... and the line says what produced it: no HIP runtime is mapped, the library is the emulation build
+    assert "NOT a measurement" in d["emulated_device"] and d["runtime"]["system_rocm_runtime"] is False
     assert d["config"]["rows_per_gpu"] == 62451 and d["roofline"]["bytes_per_launch"] > 0
     assert d["spmv"]["ans_check_fails"] == 0 and d["spmv"]["driver"].startswith("native: libnsparse_dist_d.so")
     if gpus > 1:

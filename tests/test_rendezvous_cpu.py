@@ -7,6 +7,7 @@ import time
 
 import pytest
 
+from nsparse_amd import rendezvous
 from nsparse_amd.rendezvous import Rendezvous, RendezvousError
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -123,14 +124,29 @@ def test_strangers_are_dropped_at_the_door(tmp_path):
     knock(json.dumps({"rank": 0, "token": token}).encode())
     knock(json.dumps({"rank": True, "token": token}).encode())
     knock(json.dumps([1, token]).encode())
+    # advisor r05: a token that is not ASCII (hmac.compare_digest raises TypeError on such a str) and a payload nested
+    # deeper than the JSON parser recurses (RecursionError) used to take rank 0 down with one packet each
+    knock(json.dumps({"rank": 1, "token": "\u00e9" * 32}).encode())
+    knock(json.dumps({"rank": 1, "token": "\ud800"}).encode())
+    deep = b'{"rank":1,"token":' + b"[" * 1900 + b"]" * 1900 + b"}"  # fits a hello (4096 B), too deep for json.loads
+    with pytest.raises(RendezvousError, match="RecursionError"):
+        rendezvous._parse(deep)
+    knock(deep)
     c = socket.create_connection(("127.0.0.1", int(port)), timeout=5)
     c.sendall(struct.pack("<I", 1 << 30))  # an absurd length is refused before anything is buffered
     c.close()
+    # silent strangers: connected, saying nothing.  They used to be served one at a time, 5 s each, with the real rank
+    # queued behind them; now they wait in their own slots and the real rank joins at once
+    mute = [socket.create_connection(("127.0.0.1", int(port)), timeout=5) for _ in range(6)]
+    t0 = time.time()
     rdv1 = Rendezvous(1, 2, directory=d, timeout=20.0)
     assert rdv1.allreduce([2.0], "sum") == [3.0]
+    assert time.time() - t0 < 3.0, "the real rank waited behind connections that said nothing"
     rdv1.close()
     t.join(30)
-    assert res["sum"] == [3.0] and res["rejected"] == 7
+    for c in mute:
+        c.close()
+    assert res["sum"] == [3.0] and res["rejected"] == 10  # (the mute ones were still waiting when the job was complete)
     assert not (tmp_path / "pwned").exists()
 
 

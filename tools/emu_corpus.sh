@@ -7,7 +7,7 @@
 #     test_fused_tails_under_a_cu_mask                       HSA_CU_MASK is a property of the real runtime
 #     test_single_rank_line_is_torch_free_and_on_the_system_runtime   asserts libamdhip64 is mapped
 #     test_cant_class_file_through_{loader_and_spgemm,amb}_sample     assert GFLOPS / GB/s floors of the device
-#     test_roctx_ranges_reach_a_marker_trace                 needs rocprofv3 on a device (passes vacuously without)
+#     test_roctx_ranges_reach_a_marker_trace                 rocprofv3 needs a device (the test skips when the profiler is absent, fails when it cannot trace)
 #     test_library_on_the_gpu_box_was_built_from_these_sources   the emulation build carries no source hash
 #     test_config5_rmat22                                    needs > 64 GB of host memory here (C alone is 24 GB, twice)
 cd "$(dirname "$0")/.."
