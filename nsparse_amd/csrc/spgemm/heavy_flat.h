@@ -175,6 +175,7 @@ __global__ __launch_bounds__(BS) void k_num_flat(const int *__restrict__ arpt, c
                             if (pn[u] > 0) {
                                 NSP_COUNT(FC_FLAT, 0, V);  // the vector load brings V entries, whatever pn says
                                 NSP_COUNT(FC_FLAT, 1, V);
+                                NSP_COUNT(FC_FLAT_EXTENT, 0, pn[u]);  // ... of which inside the extent
                             }
                         }
                     }
@@ -225,6 +226,200 @@ __global__ __launch_bounds__(BS) void k_num_flat(const int *__restrict__ arpt, c
                 wpos += __popcll(m);
             }
             pos += total;
+            lds_barrier();
+        }
+    }
+}
+
+// ===================================================================================
+//  heavy numeric rows, sparse flavour: list-driven bitmap-ranked tiles, one flat walk each
+// ===================================================================================
+// The rows k_num_ranked takes (thin over a wide window, or wider than 32 dense tiles) THAT HAVE A COLUMN LIST -- written by
+// the symbolic cursor kernel on matrices wider than 2^20 columns (config 5), or C.col itself in a numeric-only re-run.
+// Tile and accumulator are k_num_ranked's list-driven ones: a bitmap over W columns set from the next <= CAP entries of
+// the list, the prefix of a bitmap word = list position of its first entry, values added at prefix + rank, columns
+// leaving as a copy of the list.  What differs:
+//   * the tile is cut at PANEL boundaries of the table (it starts at the panel of the next listed column and ends at the
+//     last panel boundary not beyond the CAP-th next entry / the bitmap window), so the extent of a B row inside the tile
+//     is exact: tab[slot][first panel], tab[slot][last panel + 1];
+//   * only when ONE panel holds more than CAP listed columns is the tile cut inside it; the walk then filters by column
+//     and the next tile fetches the rest of that panel's entries again;
+//   * the products are walked flat (as in k_num_flat): no cursors, no sweep slots, no state.
+// Rows without a list stay with k_num_ranked (its `skip_listed` argument makes it leave the listed ones alone).  Own row
+// queue (BinState::queue_head3).
+template <int BS, int W, int CAP, int G>
+__global__ __launch_bounds__(BS) void k_num_ranked_flat(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                        const real *__restrict__ aval,
+                                                        const int *__restrict__ brpt, const int *__restrict__ bcol,
+                                                        const real *__restrict__ bval, int bnnz,
+                                                        const int *__restrict__ slot_of, const int *__restrict__ tab, int tstride,
+                                                        const int *__restrict__ crpt, int *__restrict__ ccol,
+                                                        real *__restrict__ cval,
+                                                        const int *__restrict__ row_perm, int bin_off, int count,
+                                                        BinState *bs, const int *__restrict__ row_lo,
+                                                        const int *__restrict__ row_span, int write_col, int dens, int tiled_w,
+                                                        const int *__restrict__ tcol, const long long *__restrict__ list_off,
+                                                        long long list_work, const int *__restrict__ row_prod)
+{
+    constexpr int NW = BS / 64;
+    constexpr int V = VW, U = 4;
+    constexpr int NWORD = W / 32;
+    constexpr int WPT = NWORD / BS;       // bitmap words per thread
+    constexpr int WG = (W / G) * G;       // whole panels under the bitmap
+    constexpr int INF = 0x7fffffff;
+    static_assert(NWORD == WPT * BS, "bitmap words split evenly over the threads");
+    static_assert(CAP <= 65535, "ranks are kept in 16 bits");
+    static_assert(WG >= G, "the bitmap covers at least one panel");
+    __shared__ __attribute__((aligned(16))) unsigned int bits[NWORD];
+    __shared__ __attribute__((aligned(16))) unsigned short pref[NWORD];
+    __shared__ __attribute__((aligned(16))) acc_t vals[CAP];
+    __shared__ int2 s_ext[BS];
+    __shared__ real s_av[BS];
+    __shared__ FlatScratch<BS> fs;
+    __shared__ int s_row, s_ntile;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < NWORD; i += BS) bits[i] = 0;
+    for (int i = threadIdx.x; i < CAP; i += BS) vals[i] = 0;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_row = atomicAdd(&bs->queue_head3, 1);
+        __syncthreads();
+        const int q = s_row;
+        if (q >= count) break;
+        const int rid = row_perm[bin_off + q];
+        const int span = row_span[rid];
+        int pos = crpt[rid];
+        const int row_nnz = crpt[rid + 1] - pos;
+        // the same split as k_num_ranked: thick rows of at most 32 dense tiles belong to the dense-tile kernel
+        if (dens > 0 && (long long)row_nnz * dens >= span && span <= 32 * tiled_w) continue;
+        if (list_work > 0 && list_wanted(row_nnz, row_prod[rid], list_work) && (list_off == nullptr || list_off[rid] >= 0))
+            continue;
+        const int *__restrict__ rlist = nullptr;
+        if (tcol != nullptr) {  // (list_off == nullptr: a numeric-only re-run, the list is C.col itself)
+            if (list_off == nullptr) rlist = tcol + pos;
+            else if (list_off[rid] >= 0) rlist = tcol + list_off[rid];
+        }
+        if (rlist == nullptr) continue;  // k_num_ranked's row
+        const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+        int k0 = 0;
+        while (k0 < row_nnz) {
+            if (threadIdx.x == 0) NSP_COUNT(FC_RANKED_FLAT, 3, 1);
+            const int cnt = row_nnz - k0 < CAP ? row_nnz - k0 : CAP;
+            const int first = rlist[k0];
+            const int base = first / G * G;
+            const long long limit_ll = (long long)base + WG;
+            const int limit = limit_ll > INF ? INF : (int)limit_ll;
+            const int nxt = k0 + cnt < row_nnz ? rlist[k0 + cnt] : INF;
+            int hi = limit;
+            if (nxt < limit) {
+                hi = nxt / G * G;             // the last panel boundary not beyond the first entry that does not fit
+                if (hi <= base) hi = nxt;     // more than CAP listed columns inside one panel: cut inside it
+            }
+            if (threadIdx.x == 0) s_ntile = cnt;  // unless an entry at or beyond `hi` says otherwise (below)
+            lds_barrier();
+            for (int k = threadIdx.x; k < cnt; k += BS) {
+                const int c = rlist[k0 + k];
+                const int cp = k > 0 ? rlist[k0 + k - 1] : -1;
+                if (c < hi) {
+                    const unsigned int idx = (unsigned int)(c - base);
+                    atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+                    if (k == 0 || ((unsigned int)(cp - base) >> 5) != (idx >> 5)) pref[idx >> 5] = (unsigned short)k;
+                } else if (k == 0 || cp < hi) {
+                    s_ntile = k;  // the first entry beyond the tile ends it (exactly one thread sees it)
+                }
+            }
+            lds_barrier();
+            const int ntile = s_ntile;
+            const int p_a = base / G, p_b = (int)(((long long)hi + G - 1) / G);
+            // ---- one flat walk of the products inside [first, hi) --------------------------------------------------
+            for (int b0 = a_beg; b0 < a_end; b0 += BS) {
+                const int nb = a_end - b0 < BS ? a_end - b0 : BS;
+                int2 e = make_int2(0, 0);
+                real av = 0;
+                if ((int)threadIdx.x < nb) {
+                    const int j = b0 + threadIdx.x;
+                    const int c = acol[j];
+                    av = aval[j];
+                    const int s = slot_of[c];
+                    if (s >= 0) {
+                        const int *t = tab + (long long)s * tstride;
+                        e.x = t[p_a];
+                        e.y = t[p_b < tstride ? p_b : tstride - 1];
+                    } else {  // short row: whole, filtered below
+                        e.x = brpt[c];
+                        e.y = brpt[c + 1];
+                    }
+                }
+                const int nch = (e.y - e.x + V - 1) / V;
+                s_ext[threadIdx.x] = e;
+                s_av[threadIdx.x] = av;
+                const int incl = wave_incl_scan(nch);
+                if (lane == 63) fs.wsum[w] = incl;
+                __syncthreads();
+                int sbase = 0, total = 0;
+#pragma unroll
+                for (int u = 0; u < NW; u++) {
+                    const int c = fs.wsum[u];
+                    sbase += u < w ? c : 0;
+                    total += c;
+                }
+                fs.pref[threadIdx.x] = sbase + incl - nch;
+                __syncthreads();
+                for (int ch0 = threadIdx.x; ch0 < total; ch0 += BS * U) {
+                    IVecT<V> pk[U];
+                    RVecT<V> pv[U];
+                    int pn[U];
+                    real sc[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int ch = ch0 + u * BS;
+                        pn[u] = 0;
+                        sc[u] = 0;
+                        if (ch < total) {
+                            int i = 0;
+#pragma unroll
+                            for (int step = BS / 2; step >= 1; step >>= 1) {
+                                const int j = i + step;
+                                if (j < nb && fs.pref[j] <= ch) i = j;
+                            }
+                            const int2 x = s_ext[i];
+                            sc[u] = s_av[i];
+                            pn[u] = fetch_chunk<true, V>(bcol, bval, x.x + (ch - fs.pref[i]) * V, x.y, bnnz, pk[u], pv[u]);
+                            if (pn[u] > 0) {
+                                NSP_COUNT(FC_RANKED_FLAT, 0, V);
+                                NSP_COUNT(FC_RANKED_FLAT, 1, V);
+                                NSP_COUNT(FC_FLAT_EXTENT, 1, pn[u]);  // ... of which inside the extent (the rest: lanes of the same vector load)
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+#pragma unroll
+                        for (int i = 0; i < V; i++) {
+                            const int col = pk[u].v[i];
+                            if (i < pn[u] && col >= first && col < hi) {
+                                NSP_COUNT(FC_RANKED_FLAT, 2, 1);
+                                const unsigned int idx = (unsigned int)(col - base);
+                                const unsigned int below = bits[idx >> 5] & ((1u << (idx & 31)) - 1u);
+                                unsafeAtomicAdd(vals + (int)pref[idx >> 5] + __popc(below), (acc_t)(sc[u] * pv[u].v[i]));
+                            }
+                        }
+                    }
+                }
+                __syncthreads();  // the next batch overwrites the parked entries
+            }
+            lds_barrier();
+            // ---- emission: the columns are the list, the values are in list order ------------------------------------
+            if (write_col & 1)
+                for (int r = threadIdx.x; r < ntile; r += BS) ccol[pos + r] = rlist[k0 + r];
+            for (int r = threadIdx.x; r < ntile; r += BS) {
+                cval[pos + r] = (real)vals[r];
+                vals[r] = 0;
+            }
+#pragma unroll
+            for (int j = 0; j < WPT; j++) bits[threadIdx.x + j * BS] = 0;
+            pos += ntile;
+            k0 += ntile;
             lds_barrier();
         }
     }

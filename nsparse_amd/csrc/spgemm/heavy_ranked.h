@@ -43,8 +43,10 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
                                                    unsigned long long *prof, int *__restrict__ row_nz_out = nullptr,
                                                    int *__restrict__ tcol = nullptr,
                                                    long long *__restrict__ list_off = nullptr,
-                                                   long long list_work = 0, const int *__restrict__ row_prod = nullptr)
+                                                   long long list_work = 0, const int *__restrict__ row_prod = nullptr,
+                                                   int skip_listed = 0)
 {
+    // skip_listed (experiments build): rows that have a column list belong to k_num_ranked_flat (heavy_flat.h)
     // SYM with tcol != nullptr: the columns of every tile are also written out as the row's sorted list
     // (common.h: bits_to_list) when common.h: list_wanted says so.  Numeric with list_work > 0: rows that
     // list_wanted picks and that have a list (list_off == nullptr: every such row, the list is C.col itself)
@@ -108,6 +110,7 @@ __global__ __launch_bounds__(BS) void k_num_ranked(const int *__restrict__ arpt,
             if (list_off == nullptr) rlist = tcol + pos;
             else if (list_off[rid] >= 0) rlist = tcol + list_off[rid];
         }
+        if (kExperiments && !SYM && skip_listed && rlist != nullptr) continue;
         bool listing = false;
         if (SYM && tcol != nullptr) {
             const int np = row_prod[rid];

@@ -641,15 +641,22 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                        list_off, list_w, row_prod)
         // NSPARSE_HEAVY_FLAT=1 (experiments build, until it has been timed on the device): the dense tiles as
         // stateless flat walks over a panel table of B (heavy_flat.h) instead of the cursor kernel
-        static const int heavy_flat = exp_env("NSPARSE_HEAVY_FLAT", 0);
+        static const int heavy_flat = exp_env("NSPARSE_HEAVY_FLAT", 0);  // bit 0: dense tiles, bit 1: list-driven ranked tiles
         bool flat_done = false;
+        int *pt_slot_of = nullptr, *pt_tab = nullptr;
+        int pt_np = 0;
         if constexpr (kExperiments) {
-            if (heavy_flat && ranked_dens >= 0 && tile_sel == 0) {
+            if (heavy_flat) {
                 const int np = (int)(((long long)b->N + kTileW - 1) / kTileW);
-                // every row of B in the table while that stays small next to B; else only rows of more than 16 entries
-                // (an upper bound of their number sizes the table: no round trip to the host)
+                // every row of B in the table while that stays small next to B; else only rows of more than min_len entries,
+                // min_len from a worst-case budget of 1 GiB: at most nnz / (min_len + 1) rows are that long, and that bound
+                // sizes the table (no round trip to the host; the fill kernel touches only the rows that exist).  A row
+                // outside the table is walked whole by every tile of a C row and filtered by column: on R-MAT-22 at a fifth
+                // of config 5's edges min_len = 16 cost a third of the products again in such re-reads (tests/emu census).
                 const bool all_rows = (long long)b->M * (np + 1) * 4 <= (256LL << 20);
-                const int min_len = all_rows ? -1 : 16;
+                const long long per_row = (long long)(np + 1) * 4;
+                int min_len = all_rows ? -1 : (int)std::min<long long>(64, ((long long)b->nnz * per_row + (1LL << 30) - 1) / (1LL << 30) - 1);
+                if (!all_rows && min_len < 1) min_len = 1;
                 const long long slots_max = all_rows ? (long long)b->M : std::min<long long>(b->M, (long long)b->nnz / (min_len + 1) + 1);
                 // one block: [count, pad | slot_of: M | slot_row: slots_max | tab: slots_max * (np + 1)]
                 const size_t n_ints = 2 + (size_t)b->M + (size_t)slots_max + (size_t)slots_max * (np + 1) + 2;
@@ -661,12 +668,15 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                 const long long cells = slots_max * (np + 1);
                 hipLaunchKernelGGL(k_panel_fill, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, brpt, bcol,
                                    (const int *)slot_row, (const int *)d_cnt, np, kTileW, tab);
-                hipLaunchKernelGGL((k_num_flat<1024, kTileW>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval, brpt, bcol,
-                                   bval, b->nnz, (const int *)slot_of, (const int *)tab, np + 1, c->d_rpt, c->d_col, c->d_val,
-                                   row_perm, off[kNumGlobalBin], rows, d_bs, row_lo, row_span, write_col, ranked_dens,
-                                   list_off, list_w, row_prod);
                 L.free_later(blk);
-                flat_done = true;
+                pt_slot_of = slot_of, pt_tab = tab, pt_np = np;
+                if ((heavy_flat & 1) && ranked_dens >= 0 && tile_sel == 0) {
+                    hipLaunchKernelGGL((k_num_flat<1024, kTileW>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval, brpt, bcol,
+                                       bval, b->nnz, (const int *)slot_of, (const int *)tab, np + 1, c->d_rpt, c->d_col, c->d_val,
+                                       row_perm, off[kNumGlobalBin], rows, d_bs, row_lo, row_span, write_col, ranked_dens,
+                                       list_off, list_w, row_prod);
+                    flat_done = true;
+                }
             }
         }
         if (ranked_dens >= 0 && !flat_done) {
@@ -693,7 +703,23 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                        brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, off[kNumGlobalBin], rows, d_bs,   \
                        row_lo, row_span, slab, stride_ints, amax, write_col, long_len, ranked_dens,                 \
                        tile_sel == 0 ? kTileW : (tile_sel == 3 ? kTileW / 4 : kTileW / 2), d_prof, (int *)nullptr,  \
-                       const_cast<int *>(tcol), const_cast<long long *>(list_off), list_w, row_prod)
+                       const_cast<int *>(tcol), const_cast<long long *>(list_off), list_w, row_prod, ranked_flat ? 1 : 0)
+            // NSPARSE_HEAVY_FLAT bit 1: the rows that have a column list through stateless tiles (heavy_flat.h); the
+            // cursor kernel then takes only the rows without one
+            const bool ranked_flat = kExperiments && (heavy_flat & 2) && pt_tab != nullptr && tcol != nullptr;
+            if constexpr (kExperiments) {
+                if (ranked_flat) {
+#define NSP_RANKED_FLAT(WX, CAPX)                                                               \
+    hipLaunchKernelGGL((k_num_ranked_flat<1024, WX, CAPX, kTileW>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval, brpt, \
+                       bcol, bval, b->nnz, (const int *)pt_slot_of, (const int *)pt_tab, pt_np + 1, c->d_rpt, c->d_col,    \
+                       c->d_val, row_perm, off[kNumGlobalBin], rows, d_bs, row_lo, row_span, write_col, ranked_dens,       \
+                       tile_sel == 0 ? kTileW : (tile_sel == 3 ? kTileW / 4 : kTileW / 2), tcol, list_off, list_w, row_prod)
+                    if (ranked_sel == 1) { NSP_RANKED_FLAT(524288, 5120); }
+                    else { NSP_RANKED_FLAT(262144, kRankCap); }
+#undef NSP_RANKED_FLAT
+                    NSP_LAUNCH_CHECK();
+                }
+            }
             if (ranked_sel == 1) { NSP_RANKED(524288, 6144, 512); }
             else { NSP_RANKED(262144, kRankCap, 1024); }
 #undef NSP_RANKED

@@ -212,7 +212,7 @@ def experiments_lib_dir():
     return exp if os.path.exists(os.path.join(exp, "libnsparse_d.so")) else None
 
 
-def spgemm_subprocess(A, env, prec="d", B=None):
+def spgemm_subprocess(A, env, prec="d", B=None, numeric_again=False):
     """Run spgemm() on A (times B, default A) in a fresh interpreter with extra environment (the
     library reads its tuning switches once per process).  Returns (C dict, dict of stats lists)."""
     import json
@@ -230,16 +230,18 @@ def spgemm_subprocess(A, env, prec="d", B=None):
             "import nsparse_amd as ns; from gpu_util import spgemm;"
             "ld = lambda f: (lambda z: dict(rpt=z['rpt'], col=z['col'], val=z['val'], M=int(z['M']), N=int(z['N'])))(np.load(f));"
             "A = ld(%r); B = ld(%r);"
-            "got, st = spgemm(ns.load(%r), A, B);"
-            "np.savez(%r, rpt=got['rpt'], col=got['col'], val=got['val']);"
+            "got, st = spgemm(ns.load(%r), A, B, numeric_again=%r);"
+            "np.savez(%r, **{k: got[k] for k in ('rpt', 'col', 'val', 'val_again', 'col_again') if k in got});"
             "print(json.dumps(dict(sym=list(st.sym_bin_size), num=list(st.num_bin_size), fails=st.sym_fail_rows,"
             " build=ns.load(%r).nsparse_build_info().decode())))"
         ) % (root, os.path.join(root, "tests"), os.path.join(td, "a.npz"), os.path.join(td, "b.npz"), prec,
-             os.path.join(td, "c.npz"), prec)
+             bool(numeric_again), os.path.join(td, "c.npz"), prec)
         r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True,
                            env=dict(os.environ, **env))
         assert r.returncode == 0, r.stderr[-3000:]
         stats = json.loads(r.stdout.strip().splitlines()[-1])
         z = np.load(os.path.join(td, "c.npz"))
         got = dict(M=A["M"], N=Bm["N"], nnz=int(z["rpt"][-1]), rpt=z["rpt"], col=z["col"], val=z["val"])
+        if numeric_again:
+            got["val_again"], got["col_again"] = z["val_again"], z["col_again"]
     return got, stats

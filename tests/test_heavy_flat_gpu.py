@@ -18,11 +18,13 @@ def assert_parity(orc, got, ref):
     assert orc.check_spgemm(got, ref) == 0, "values outside the reference tolerance"
 
 
-def flat(A, B=None, prec="d", **env):
+def flat(A, B=None, prec="d", numeric_again=False, **env):
+    """NSPARSE_HEAVY_FLAT=3: dense tiles (bit 0) and list-driven ranked tiles (bit 1) both stateless."""
     d = experiments_lib_dir()
     if d is None:
         pytest.skip("no experiments variant library beside the one in use (__graft_entry__.build() makes lib_exp)")
-    got, st = spgemm_subprocess(A, dict(NSPARSE_LIB_DIR=d, NSPARSE_HEAVY_FLAT="1", **env), prec=prec, B=B)
+    got, st = spgemm_subprocess(A, dict(dict(NSPARSE_LIB_DIR=d, NSPARSE_HEAVY_FLAT="3"), **env), prec=prec, B=B,
+                                numeric_again=numeric_again)
     assert st["build"].split()[-1] == "experiments", st["build"]
     return got, st
 
@@ -101,3 +103,51 @@ def test_short_rows_outside_the_table(oracle_d):
     got, st = flat(A, B)
     assert st["num"][5] == 4
     assert_parity(oracle_d, got, ref)
+
+
+def test_window_wider_than_the_bitmap_with_lists(oracle_d):
+    """3 M columns (symbolic cursor kernel, column lists on): every heavy row is thin and has a list, so all of them take
+    k_num_ranked_flat; tiles start at the panel of the next listed column and end at panel boundaries."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(77)
+    m, k, n = 48, 3000, 3_000_000
+    a = sp.random(m, k, density=120 / k, format="csr", random_state=rng, dtype=np.float64)
+    b = sp.random(k, n, density=220 / n, format="csr", random_state=rng, dtype=np.float64)
+    A, B = csr(a), csr(b)
+    ref = oracle_d.spgemm(A, B)
+    assert ref["row_nz"].min() > 8192
+    got, st = flat(A, B, numeric_again=True)
+    assert st["num"][5] == m
+    assert_parity(oracle_d, got, ref)
+    assert np.array_equal(got["col_again"], got["col"])
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("dens", ["-1", "12"])
+def test_numeric_rerun_has_a_list_for_every_heavy_row(dens, lib_d, oracle_d):
+    """A numeric-only re-run uses C.col as the list of every row.  With NSPARSE_RANKED_DENS=-1 all 560 heavy rows of
+    R-MAT-14 go through the list-driven stateless tiles in the re-run (W = 2^18, CAP = 10240): their dense low-column
+    stretch puts more than CAP listed columns into one 12288-column panel, so tiles are cut INSIDE a panel and the walk
+    filters by column.  The first run (no lists on a matrix this narrow) takes the cursor kernel for the same rows."""
+    A = synth(lib_d, 3, 14, 16, 0, seed=0x5EED0022)
+    ref = oracle_d.spgemm(A, A)
+    assert ref["row_nz"].max() > 10240
+    got, st = flat(A, numeric_again=True, NSPARSE_RANKED_DENS=dens)
+    assert_parity(oracle_d, got, ref)
+    assert np.array_equal(got["col_again"], got["col"])
+    again = dict(got, val=got["val_again"])
+    assert oracle_d.check_spgemm(again, ref) == 0
+
+
+def test_config5_code_paths_through_the_stateless_tiles(lib_d, oracle_d):
+    """R-MAT scale 22 at a fifth of config 5's edges (tests/test_configs_gpu.py has the cursor kernels on the same input):
+    4 M columns, 343 panels, only the B rows of more than 16 entries in the table, lists from the symbolic cursor kernel,
+    thick heavy rows through k_num_flat and thin ones through k_num_ranked_flat."""
+    A = synth(lib_d, 3, 22, 0, 1500000, seed=0x5EED0022)
+    got, st = flat(A, numeric_again=True)
+    assert st["num"][5] > 500
+    ref = oracle_d.spgemm_omp(A, A)
+    assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
+    assert oracle_d.check_spgemm(got, dict(ref, M=A["M"])) == 0
+    assert np.array_equal(got["col_again"], got["col"])
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9)

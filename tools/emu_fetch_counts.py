@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """B entries fetched per product in the heavy-row numeric kernels, counted on the CPU emulation (tests/emu).
 
-    python tools/emu_fetch_counts.py [case ...]            cases: rmat14 rmat16 rmat18s wide3m   (default: rmat14 rmat16 wide3m)
+    python tools/emu_fetch_counts.py [case ...]            cases: rmat14 rmat16 rmat18s rmat22s wide3m   (default: rmat14 rmat16 wide3m)
     EMU_LIB_DIR=tests/emu/lib_exp NSPARSE_HEAVY_FLAT=1 python tools/emu_fetch_counts.py
                                                            the same workloads through the stateless tiles (heavy_flat.h;
                                                            lib_exp = make -C tests/emu EXTRA=-DNSPARSE_EXPERIMENTS OUT=.../lib_exp)
@@ -27,7 +27,8 @@ import nsparse_amd as ns  # noqa: E402
 from gpu_util import spgemm, synth  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
 
-FAMILIES = {0: "k_num_tiled", 1: "k_num_ranked", 2: "k_num_ranked<SYM>", 3: "k_num_flat", 4: "walk_products"}
+FAMILIES = {0: "k_num_tiled", 1: "k_num_ranked", 2: "k_num_ranked<SYM>", 3: "k_num_flat", 4: "walk_products", 5: "k_num_ranked_flat"}
+IN_EXTENT = {3: 0, 5: 1}  # family -> slot of family 6 holding "entries loaded that lie inside their extent"
 
 
 def cases(lib):
@@ -46,6 +47,7 @@ def cases(lib):
         "rmat14": lambda: (synth(lib, 3, 14, 16, 0, seed=0x5EED0022),) * 2,      # heavy rows above the ranked tile capacity
         "rmat16": lambda: (synth(lib, 3, 16, 16, 0, seed=0x5EED0022),) * 2,      # hub rows of A beyond 4096 entries
         "rmat18s": lambda: (synth(lib, 3, 18, 0, 1500000, seed=0x5EED0022),) * 2,  # R-MAT-18 at a third of the edges
+        "rmat22s": lambda: (synth(lib, 3, 22, 0, 1500000, seed=0x5EED0022),) * 2,  # config 5 at a fifth of its edges: 4 M columns, lists
         "wide3m": wide3m,                                                           # 3 M columns: ranked tiles + lists
     }
 
@@ -59,8 +61,8 @@ def main():
     w = 8
     print("# B entries fetched per product, heavy-row numeric kernels, CPU emulation; NSPARSE_HEAVY_FLAT=%s NSPARSE_RANKED_DENS=%s"
           % (os.environ.get("NSPARSE_HEAVY_FLAT", "(default)"), os.environ.get("NSPARSE_RANKED_DENS", "(default)")))
-    print("%-10s %-20s %12s %12s %12s %9s %9s %9s %8s" % ("case", "kernel", "products", "B.col loads", "B.val loads",
-                                                          "col/prod", "val/prod", "bytes/min", "tiles"))
+    print("%-10s %-20s %12s %12s %12s %9s %9s %9s %8s %10s" % ("case", "kernel", "products", "B.col loads", "B.val loads",
+                                                               "col/prod", "val/prod", "bytes/min", "tiles", "in-extent"))
     for name in want:
         A, B = cases(lib)[name]()
         buf = (C.c_longlong * 64)()
@@ -76,9 +78,12 @@ def main():
             ncol, nval, nprod, ntile = (buf[f * 4 + i] for i in range(4))
             if nprod == 0 and ncol == 0:
                 continue
-            print("%-10s %-20s %12d %12d %12d %9.3f %9.3f %9.3f %8d" % (
+            # stateless kernels: entries inside their extent per product (the rest of "loads" are lanes of a 4-wide vector
+            # load past the end of a short extent -- same 16-byte request, no further sector)
+            inx = "%10.3f" % (buf[6 * 4 + IN_EXTENT[f]] / max(nprod, 1)) if f in IN_EXTENT else "%10s" % "-"
+            print("%-10s %-20s %12d %12d %12d %9.3f %9.3f %9.3f %8d %s" % (
                 name, label, nprod, ncol, nval, ncol / max(nprod, 1), nval / max(nprod, 1),
-                (4 * ncol + w * nval) / max((4 + w) * nprod, 1), ntile))
+                (4 * ncol + w * nval) / max((4 + w) * nprod, 1), ntile, inx))
         print("# %s: M %d nnz(A) %d nnz(C) %d heavy rows %d parity %s (%.0f s)" % (
             name, A["M"], len(A["col"]), got["nnz"], st.num_bin_size[5], "ok" if ok else "FAILED", dt))
         if not ok:

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 if [ -z "$FORCE" ] && [ -n "$(git status --porcelain --untracked-files=no)" ]; then echo "freeze: working tree not clean" >&2; exit 1; fi
 rm -rf .frozen.new && mkdir .frozen.new
 git archive HEAD | tar -x -C .frozen.new
-for d in nsparse_amd/lib nsparse_amd/lib_asan; do
+for d in nsparse_amd/lib nsparse_amd/lib_asan nsparse_amd/lib_exp; do
   [ -d "$d" ] || continue
   mkdir -p .frozen.new/$d
   # objects stay behind: only what is loaded or executed travels
