@@ -9,6 +9,7 @@
 #include <condition_variable>
 #include <map>
 #include <set>
+#include <string>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -72,6 +73,7 @@ struct Lane {
 };
 
 struct Worker {
+    int index = 0;             // position in the pool: a launch that a CU model limits to n resident workgroups uses workers 0 .. n-1
     std::vector<Lane> lanes;   // stacks are kept between workgroups
     void *sched_sp = nullptr;
     Lane *cur = nullptr;
@@ -366,6 +368,7 @@ struct Job {
     std::atomic<unsigned> next{0};
     std::atomic<unsigned> finished{0};
     unsigned total = 0;
+    int active = 1 << 30;  // workgroups of this launch that may be resident at once (compute-unit model, below)
 };
 // (never destroyed: the detached workers wait on them until the process ends)
 static std::mutex &g_mu = *new std::mutex;
@@ -442,10 +445,70 @@ int workers()
     return g_workers;
 }
 
+// ---- compute-unit model (round 6) ------------------------------------------------------------------------------------
+// The pool of EMU_WORKERS threads stands for EMU_CUS compute units (default: as many as workers; tests/test_emu_cpu.py runs the
+// selftest with half as many, so that a CU can hold two small workgroups and only one big one) of 160 KiB of LDS and 32
+// wavefront slots each.  A launch may have  CUs x min(160 KiB / (static + dynamic LDS), 32 / wavefronts per
+// workgroup, register occupancy x 4 / wavefronts per workgroup)  workgroups resident at once, never more than there are
+// workers: a kernel that takes more than half a CU's LDS runs one workgroup per CU, and that is what a co-residency census
+// (fused.h: k_census) counts and what a grid barrier can rely on -- not "8 workers".  Static LDS and occupancy come from the
+// REAL compiler (gfx950): `<library>.lds`, written by tools/kernel_resources.py next to the library (tests/emu/Makefile),
+// or emu_set_static_lds() (selftest).  A kernel the table does not know has static LDS 0.
+constexpr size_t kLdsPerCu = 160 * 1024;
+int cus()
+{
+    static const int n = [] {
+        const char *e = getenv("EMU_CUS");
+        const int v = e && atoi(e) > 0 ? atoi(e) : workers();
+        return v > 0 ? v : 1;
+    }();
+    return n;
+}
+struct KernelRes {
+    size_t lds = 0;
+    int occ = 8;  // waves per SIMD the register allocation allows
+};
+static std::mutex &g_res_mu = *new std::mutex;
+static std::map<std::string, KernelRes> &g_res_by_name = *new std::map<std::string, KernelRes>;
+static std::map<const void *, KernelRes> &g_res_by_func = *new std::map<const void *, KernelRes>;
+static std::set<std::string> &g_res_files = *new std::set<std::string>;
+void set_static_lds(const void *func, size_t bytes, int occ)
+{
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    g_res_by_func[func] = KernelRes{bytes, occ > 0 ? occ : 8};
+}
+static KernelRes resources_of(const void *func)
+{
+    std::lock_guard<std::mutex> lk(g_res_mu);
+    auto it = g_res_by_func.find(func);
+    if (it != g_res_by_func.end()) return it->second;
+    KernelRes r;
+    Dl_info di;
+    if (dladdr(func, &di) && di.dli_fname) {
+        const std::string file = std::string(di.dli_fname) + ".lds";
+        if (g_res_files.insert(file).second) {  // first kernel of this library: read its table
+            if (FILE *f = fopen(file.c_str(), "r")) {
+                char name[4096];
+                long lds;
+                int occ, vgpr;
+                while (fscanf(f, "%4095s %ld %d %d", name, &lds, &occ, &vgpr) == 4) g_res_by_name[name] = KernelRes{(size_t)lds, occ > 0 ? occ : 8};
+                fclose(f);
+            }
+        }
+        if (di.dli_sname) {
+            auto jt = g_res_by_name.find(di.dli_sname);
+            if (jt != g_res_by_name.end()) r = jt->second;
+        }
+    }
+    g_res_by_func[func] = r;
+    return r;
+}
+
 static std::vector<pthread_t> &g_worker_ids = *new std::vector<pthread_t>;
-static void worker_main()
+static void worker_main(int index)
 {
     Worker self;
+    self.index = index;
     t_w = &self;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -468,6 +531,7 @@ static void worker_main()
             job = g_job;
             seen = g_job_seq;
         }
+        if (self.index >= job->active) continue;  // this launch does not fill the device: the "CU" of this worker holds none of it
         for (;;) {
             const unsigned b = job->next.fetch_add(1);
             if (b >= job->total) break;
@@ -519,6 +583,12 @@ void launch(const char *name, const void *func, dim3 grid, dim3 block, size_t ld
     }
     if (lds_bytes > 160 * 1024) {
         fprintf(stderr, "emu: kernel %s asks for %zu bytes of dynamic LDS (a CU has 160 KiB)\n", name, lds_bytes);
+        abort();
+    }
+    const KernelRes res = resources_of(func);
+    if (res.lds + lds_bytes > kLdsPerCu) {
+        fprintf(stderr, "emu: kernel %s needs %zu bytes of static + %zu bytes of dynamic LDS per workgroup (a CU has 160 KiB)\n", name,
+                res.lds, lds_bytes);
         abort();
     }
     if (lds_bytes > 64 * 1024) {
@@ -581,9 +651,22 @@ void launch(const char *name, const void *func, dim3 grid, dim3 block, size_t ld
     job->lds = lds_bytes;
     job->total = grid.x;
     {
+        // resident workgroups of this launch (compute-unit model above)
+        const size_t lds_wg = res.lds + lds_bytes;
+        const int waves = (int)((nt + 63) / 64);
+        long per_cu = 32 / waves;
+        if (lds_wg > 0 && (long)(kLdsPerCu / lds_wg) < per_cu) per_cu = (long)(kLdsPerCu / lds_wg);
+        if ((long)res.occ * 4 / waves < per_cu) per_cu = (long)res.occ * 4 / waves;
+        if (per_cu < 1) per_cu = 1;
+        const long resident = per_cu * cus();
+        job->active = resident < workers() ? (int)resident : workers();
+        static const bool trace_res = getenv("EMU_TRACE") != nullptr;
+        if (trace_res) fprintf(stderr, "emu:   %zu B LDS per workgroup, %ld per CU x %d CUs -> %d resident\n", lds_wg, per_cu, cus(), job->active);
+    }
+    {
         std::lock_guard<std::mutex> lk(g_mu);
         if (g_threads.empty())
-            for (int i = 0; i < workers(); i++) g_threads.emplace_back(worker_main).detach();
+            for (int i = 0; i < workers(); i++) g_threads.emplace_back(worker_main, i).detach();
         g_job = job;
         g_job_seq++;
     }
@@ -718,7 +801,7 @@ hipError_t hipGetDevice(int *d) { *d = t_device; return hipSuccess; }
 hipError_t hipGetDeviceCount(int *n) { *n = emu_devices(); return hipSuccess; }
 hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t a, int)
 {
-    *v = a == hipDeviceAttributeMultiprocessorCount ? emu::workers() : 0;
+    *v = a == hipDeviceAttributeMultiprocessorCount ? emu::cus() : 0;
     return hipSuccess;
 }
 hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = -1; return hipSuccess; }
@@ -812,6 +895,8 @@ void nsp_emu_count(int family, int what, long long n)
 {
     if ((unsigned)family < 16u && (unsigned)what < 4u) g_fetch[family][what].fetch_add(n, std::memory_order_relaxed);
 }
+// static LDS / occupancy of a kernel the table cannot know (selftest)
+void emu_set_static_lds(const void *func, size_t bytes, int occ) { emu::set_static_lds(func, bytes, occ); }
 void emu_get_fetch_counts(long long out[64], int reset)
 {
     for (int f = 0; f < 16; f++)

@@ -96,6 +96,8 @@ hipError_t hipFuncSetAttribute(const void *f, hipFuncAttribute a, int v);
 // through bpermute / swizzle / shfl (0 on the hardware), [3] workgroups run, [4] DPP reads of an invalid lane
 void emu_get_stats(long long out[8]);
 void emu_reset_stats(void);
+void emu_set_static_lds(const void *func, size_t bytes, int occ);  // what <library>.lds says for the product's kernels
+void emu_get_fetch_counts(long long out[64], int reset);
 }
 
 // ---------------------------------------------------------------------------------------------- device side

@@ -1,6 +1,9 @@
 // tests/emu/selftest.cpp -- the emulator checked against what the INSTRUCTIONS are documented to do, on kernels small
 // enough to verify by hand (run by tests/test_emu_cpu.py).  Exit code 0 = every check passed.
 #include <hip/hip_runtime.h>
+#include <signal.h>
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <vector>
 
@@ -96,6 +99,17 @@ __global__ void k_dppmm(int *out)
     out[256 + threadIdx.x] = __builtin_amdgcn_update_dpp(-7, x, 0x111, 0xf, 0xf, true);   // row_shr:1 bound_ctrl: 0 at row starts
 }
 
+// counts how many workgroups of the launch are inside the kernel at the same time (what fused.h: k_census does)
+__global__ void k_resident(int *now, int *peak)
+{
+    if (threadIdx.x == 0) {
+        const int n = atomicAdd(now, 1) + 1;
+        atomicMax(peak, n);
+        for (int i = 0; i < 2000; i++) __builtin_amdgcn_s_sleep(8);  // stay a while: the others must overlap if they can
+        atomicAdd(now, -1);
+    }
+}
+
 int main()
 {
     int *d;
@@ -144,6 +158,36 @@ int main()
         CHECK(d[128 + l] == (((l >> 4) & 1) == 0 ? std::min(5, X(l)) : X(l)));
         CHECK(d[192 + l] == (l == 0 ? -7 : X(l - 1)));
         CHECK(d[256 + l] == ((l & 15) == 0 ? 0 : X(l - 1)));
+    }
+    // ---- LDS capacity and co-residency (round 6) --------------------------------------------------------------------
+    // The pool stands for `ncu` compute units of 160 KiB: a kernel that takes more than half a CU's LDS runs one workgroup
+    // per CU, one that takes a quarter runs up to four (never more than there are workers), and static + dynamic LDS above
+    // 160 KiB is refused at launch.  Static LDS comes from the real compiler's table for the product's kernels; here it is
+    // declared by hand.
+    {
+        auto peak_of = [&](size_t stat, size_t dyn) {
+            emu_set_static_lds(reinterpret_cast<const void *>(k_resident), stat, 8);
+            memset(d, 0, sizeof(int) * 2);
+            hipLaunchKernelGGL(k_resident, dim3(64), dim3(64), dyn, nullptr, d, d + 1);
+            CHECK(d[0] == 0);
+            return d[1];
+        };
+        const int p_big = peak_of(90 * 1024, 6 * 1024);     // 96 KiB: one per CU
+        const int p_quarter = peak_of(30 * 1024, 10 * 1024);  // 40 KiB: four per CU
+        CHECK(p_big >= 1 && p_big <= ncu);
+        CHECK(p_quarter <= 4 * ncu && p_quarter >= p_big);
+        printf("selftest: %d CUs; resident workgroups of a 96 KiB kernel %d, of a 40 KiB kernel %d\n", ncu, p_big, p_quarter);
+        fflush(stdout);
+        const pid_t pid = fork();
+        if (pid == 0) {  // 100 KiB static + 61 KiB dynamic = 161 KiB: must be refused (abort) before anything runs
+            fclose(stderr);
+            emu_set_static_lds(reinterpret_cast<const void *>(k_resident), 100 * 1024, 8);
+            hipLaunchKernelGGL(k_resident, dim3(1), dim3(64), 61 * 1024, nullptr, d, d + 1);
+            _exit(0);
+        }
+        int status = 0;
+        waitpid(pid, &status, 0);
+        CHECK(WIFSIGNALED(status) && WTERMSIG(status) == SIGABRT);
     }
     long long st[8];
     emu_get_stats(st);

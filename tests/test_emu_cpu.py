@@ -50,6 +50,29 @@ def test_emulated_instructions_against_hand_checked_kernels(emu_lib):
     strings, LDS + barriers, dynamic LDS, global atomics across workgroups, a grid barrier of co-resident workgroups."""
     r = subprocess.run([os.path.join(emu_lib, "selftest")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "selftest: 0 failures" in r.stdout, r.stdout + r.stderr
+    # round 6: the pool as 4 compute units of 160 KiB -- a kernel with 96 KiB of (static + dynamic) LDS runs one workgroup per
+    # CU, one with 40 KiB up to four (capped by the 8 workers), and 161 KiB is refused at launch (the selftest checks all three)
+    r = subprocess.run([os.path.join(emu_lib, "selftest")], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, EMU_CUS="4", EMU_WORKERS="8"))
+    assert r.returncode == 0 and "selftest: 0 failures" in r.stdout, r.stdout + r.stderr
+    import re
+    m = re.search(r"selftest: 4 CUs; resident workgroups of a 96 KiB kernel (\d+), of a 40 KiB kernel (\d+)", r.stdout)
+    assert m and 1 <= int(m.group(1)) <= 4 and int(m.group(1)) <= int(m.group(2)) <= 8, r.stdout
+
+
+def test_static_lds_of_the_products_kernels_is_policed(emu_lib):
+    """The emulation cannot see how much static LDS a kernel declares (it is thread-local storage there); the table the REAL
+    compiler produced for gfx950 sits next to the library (tests/emu/Makefile: <lib>.lds) and is what the launch check and the
+    co-residency of every launch are computed from.  It must be there, cover the big-LDS kernels, and stay within a CU."""
+    for p in ("d", "s"):
+        path = os.path.join(emu_lib, f"libnsparse_{p}.so.lds")
+        assert os.path.exists(path), f"{path} missing (make -C tests/emu lds; needs hipcc)"
+        rows = [ln.split() for ln in open(path)]
+        lds = {r[0]: int(r[1]) for r in rows}
+        assert len(lds) > 300
+        big = {k: v for k, v in lds.items() if "k_num_ranked" in k or "k_sym_tb" in k or "k_num_tiled" in k}
+        assert big and max(big.values()) > 128 * 1024, "the heavy-row kernels' static LDS did not reach the table"
+        assert max(lds.values()) <= 160 * 1024
 
 
 def test_the_library_loaded_is_the_emulation_and_not_the_product(emu_lib):

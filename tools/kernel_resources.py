@@ -2,6 +2,10 @@
 """Registers, scratch, LDS and occupancy of every kernel of every HIP translation unit of the product, from the
 compiler's own remarks (-Rpass-analysis=kernel-resource-usage; no GPU needed):
     python tools/kernel_resources.py [d|s] [--unit spgemm_hash|spmv_amb|amb_convert|dist_spmv|all] [--own] [filter ...]
+    python tools/kernel_resources.py [d|s] --lds-table FILE [--extra "-DFLAG ..."]
+        "<mangled name> <static LDS bytes> <occupancy, waves/SIMD> <VGPRs>" per kernel of every unit: what tests/emu loads
+        (next to its library, <lib>.lds) to police LDS capacity and derive co-residency -- the emulation itself cannot see
+        how much static LDS a kernel declares
 e.g. python tools/kernel_resources.py d --unit spmv_amb k_spmv_amb_row
 A kernel with ScratchSize > 0 spills: in the latency-bound row kernels that has always cost more than it bought, and
 an HBM-bound kernel that spills writes and re-reads its own operands.  tests/test_kernel_resources.py gates on it."""
@@ -60,7 +64,7 @@ def unit_resources(prec, unit, extra=()):
                 return int(r.get(key, "0"))
             except ValueError:
                 return 0
-        out.append({"name": full, "own": own, "unit": unit, "vgpr": num("VGPRs"), "agpr": num("AGPRs"),
+        out.append({"name": full, "mangled": r["mangled"], "own": own, "unit": unit, "vgpr": num("VGPRs"), "agpr": num("AGPRs"),
                     "sgpr": num("TotalSGPRs"), "scratch": num("ScratchSize [bytes/lane]"),
                     "occ": num("Occupancy [waves/SIMD]"), "lds": num("LDS Size [bytes/block]"),
                     "vspill": num("VGPRs Spill"), "sspill": num("SGPRs Spill")})
@@ -73,6 +77,8 @@ def main():
     units = ["spgemm_hash"]
     own_only = False
     filt = []
+    table = None
+    extra = []
     i = 0
     while i < len(args):
         a = args[i]
@@ -83,9 +89,25 @@ def main():
             units = list(UNITS) if args[i] == "all" else [args[i]]
         elif a == "--own":
             own_only = True
+        elif a == "--lds-table":
+            i += 1
+            table = args[i]
+        elif a == "--extra":
+            i += 1
+            extra = [f for f in args[i].split() if f.startswith("-D")]
         else:
             filt.append(a)
         i += 1
+    if table:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=4) as ex:
+            res = list(ex.map(lambda u: unit_resources(prec, u, extra), UNITS))
+        with open(table + ".tmp", "w") as f:
+            for rows in res:
+                for r in rows:
+                    f.write("%s %d %d %d\n" % (r["mangled"], r["lds"], r["occ"], r["vgpr"] + r["agpr"]))
+        os.replace(table + ".tmp", table)
+        return
     print("%-88s %5s %5s %7s %4s %7s %6s %6s" % ("kernel", "VGPR", "SGPR", "scratch", "occ", "LDS", "vspill", "sspill"))
     n_own = n_scratch = 0
     for u in units:
