@@ -254,10 +254,10 @@ Context &ctx()
         // million small rows and running alone at the end (NSPARSE_STREAM_PRIO=0: all equal)
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        const bool prio_on = !(getenv("NSPARSE_STREAM_PRIO") && atoi(getenv("NSPARSE_STREAM_PRIO")) == 0);
+        const bool prio_on = exp_env("NSPARSE_STREAM_PRIO", 1) != 0;
         for (int i = 0; i < kMaxBins; i++) {
             // NSPARSE_PRIO_BINS=<bit mask of bins>: which bins' streams get it (default: 4, 5, 10)
-            static const unsigned prio_mask = getenv("NSPARSE_PRIO_BINS") ? (unsigned)strtoul(getenv("NSPARSE_PRIO_BINS"), nullptr, 0) : 0x430u;
+            static const unsigned prio_mask = (unsigned)exp_env("NSPARSE_PRIO_BINS", 0x430);
             const bool big = prio_on && ((prio_mask >> i) & 1u);
             if (big) {
                 NSP_CHECK(hipStreamCreateWithPriority(&c.stream[i], hipStreamNonBlocking, prio_hi));

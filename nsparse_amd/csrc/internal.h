@@ -12,6 +12,29 @@
 
 namespace nsp {
 
+// ---- switches ------------------------------------------------------------------------------------------------------
+// The PRODUCT library reads nine behaviour switches from the environment (NSPARSE_DENSE, NSPARSE_TWINS, NSPARSE_FUSED,
+// NSPARSE_LIST, NSPARSE_AMB_TUNE, NSPARSE_BIN_CACHE, NSPARSE_DIST_TIMEOUT_S, NSPARSE_NO_ABORT, NSPARSE_ROCTX) and nothing
+// else.  Everything that exists to MEASURE -- kernel-form selectors, ablations, the opt-in kernel families that have not
+// been timed on the device yet -- goes through exp_env: read from the environment only in a -DNSPARSE_EXPERIMENTS build
+// (nsparse_amd/lib_exp), a constant in the product, so that the branches and kernel instantiations behind it are not
+// part of the product at all (`if constexpr (kExpBuild)` where a kernel template would otherwise be instantiated).
+#ifdef NSPARSE_EXPERIMENTS
+constexpr bool kExpBuild = true;
+#else
+constexpr bool kExpBuild = false;
+#endif
+static inline int exp_env(const char *name, int dflt)
+{
+#ifdef NSPARSE_EXPERIMENTS
+    const char *e = getenv(name);
+    return e ? (int)strtol(e, nullptr, 0) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
+}
+
 // ---- error channel -----------------------------------------------------------
 // The reference aborts through checkCudaErrors on any failure.  We do the
 // same by default, but record the code first so that NSPARSE_NO_ABORT=1 callers can

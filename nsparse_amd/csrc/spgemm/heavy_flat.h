@@ -27,16 +27,23 @@
 namespace nsp {
 namespace spgemm {
 
-// slot_of[r] = table slot of B row r (rows longer than min_len), -1 otherwise; slot_row[s] = r.  The order of the
-// slots is whatever the atomics make it: it names table rows, it does not reach the result.
+// slot_of[r] = table slot of B row r, -1 for rows outside the table; slot_row[s] = r; *count = slots in use.
+// ALL: every row has a slot (its own number).  Otherwise the rows longer than min_len, in whatever order the atomics
+// make it: the order names table rows, it does not reach the result.
+// (templates, like every kernel of this header: nothing of it is instantiated in a build that does not launch it)
+template <bool ALL>
 __global__ __launch_bounds__(256) void k_panel_slots(const int *__restrict__ brpt, int m, int min_len,
                                                      int *__restrict__ slot_of, int *__restrict__ slot_row,
                                                      int *__restrict__ count, int slots_max)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
+    if (ALL && r == 0) *count = m;
     if (r >= m) return;
     int s = -1;
-    if (brpt[r + 1] - brpt[r] > min_len) {
+    if (ALL) {
+        s = r;
+        slot_row[r] = r;
+    } else if (brpt[r + 1] - brpt[r] > min_len) {
         s = atomicAdd(count, 1);
         if (s < slots_max) slot_row[s] = r;
         else s = -1;  // (cannot happen: slots_max is an upper bound of the rows longer than min_len)
@@ -45,9 +52,10 @@ __global__ __launch_bounds__(256) void k_panel_slots(const int *__restrict__ brp
 }
 
 // One thread per (slot, panel boundary): lower bound of p * G in the sorted row.
+template <int G>
 __global__ __launch_bounds__(256) void k_panel_fill(const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                     const int *__restrict__ slot_row, const int *__restrict__ count,
-                                                    int np, int G, int *__restrict__ tab)
+                                                    int np, int *__restrict__ tab)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const int stride = np + 1;

@@ -62,7 +62,8 @@ struct LeanScratch {
 // Walk every intermediate product of one C row; `consume(k, v, n, sc)` gets 1 <= n <= 4 consecutive entries of a
 // B row and the A value.  Must be called by every thread of the workgroup (barriers inside when BS > 64).
 // U chunks are requested per thread before the first is consumed.
-template <int BS, bool WITH_VAL, int U, typename F>
+// PIPE (experiments): one chunk in flight behind the one being hashed instead of U requested together.
+template <int BS, bool WITH_VAL, int U, bool PIPE, typename F>
 __device__ __forceinline__ void lean_walk(const int *__restrict__ acol, const real *__restrict__ aval,
                                           const int *__restrict__ brpt, const int *__restrict__ bcol,
                                           const real *__restrict__ bval, int bnnz, int a_beg, int a_end,
@@ -200,7 +201,7 @@ __device__ __forceinline__ void lean_walk(const int *__restrict__ acol, const re
             }
             sync();
             const int wn = total - w0 < CAP ? total - w0 : CAP;  // chunks of this window
-#ifdef NSP_LEAN_PIPE
+            if constexpr (PIPE) {
             // one chunk in flight BEHIND the one being hashed (round r + 1 is requested before round r is consumed):
             // the memory round trip of a round hides behind the probes of the round before, at 12 registers per buffer
             {
@@ -231,7 +232,7 @@ __device__ __forceinline__ void lean_walk(const int *__restrict__ acol, const re
                     if (cn > 0) consume(ck, cv, cn, cs);
                 }
             }
-#else
+            } else {
 #pragma unroll
             for (int r0 = 0; r0 < 4; r0 += U) {
                 if (r0 * BS >= wn) break;  // uniform
@@ -255,7 +256,7 @@ __device__ __forceinline__ void lean_walk(const int *__restrict__ acol, const re
                 for (int u = 0; u < U; u++)
                     if (pn[u] > 0) consume(pk[u], pv[u], pn[u], sc[u]);
             }
-#endif
+            }
         }
         sync();  // the next batch overwrites the parked entries
     }
@@ -264,6 +265,8 @@ __device__ __forceinline__ void lean_walk(const int *__restrict__ acol, const re
 // Four find-or-inserts, the probes of a round issued back to back and NO branch inside a round: a key that is done
 // re-probes the slot it owns (CAS(slot, -1, key) on a slot that holds key writes nothing and returns key).  Elements
 // n .. 3 of a partial chunk are copies of element 0.  fresh += keys this call inserted.
+// BF (experiments): branch-free retry rounds over all four keys instead of a block per key.
+template <bool BF>
 __device__ __forceinline__ void lean_insert4(int *tab, int mask, int shift, int bits, const IVec &k, int n, int (&h)[VW], int &fresh)
 {
     int kk[VW], old[VW];
@@ -284,7 +287,7 @@ __device__ __forceinline__ void lean_insert4(int *tab, int mask, int shift, int 
     // (the retries: a block per key that only the lanes still probing that key enter -- five vector instructions per
     //  executed block.  A branch-free retry round over all four keys was measured: 36 VALU per round whether one lane
     //  retries or all, stencil numeric 1.81 -> 2.47 ms at load factor 1/2.)
-#ifdef NSP_LEAN_RETRY_BF
+    if constexpr (BF) {
     while (any) {  // branch-free round: a key that is done re-probes the slot it owns (a no-op)
 #pragma unroll
         for (int i = 0; i < VW; i++) h[i] = (h[i] + (pend[i] ? 1 : 0)) & mask;
@@ -298,7 +301,7 @@ __device__ __forceinline__ void lean_insert4(int *tab, int mask, int shift, int 
             any |= pend[i];
         }
     }
-#else
+    } else {
     while (any) {
         any = false;
 #pragma unroll
@@ -312,7 +315,7 @@ __device__ __forceinline__ void lean_insert4(int *tab, int mask, int shift, int 
             }
         }
     }
-#endif
+    }
 }
 
 // ---- one-wavefront sort of up to 128 distinct keys in registers ------------------------------------------------------
@@ -615,7 +618,8 @@ __device__ __forceinline__ void flip_sort_lds(int *s, int P)
 
 // ---- symbolic, bins 1..4 (set_row_nz_bin_each_tb :399-472) -----------------------------------------------------------
 // LIST: big-table bins may leave the sorted column list of a heavy row for the ranked numeric kernel (symbolic.h).
-template <int BS, int TMAX, int U>
+// FORM (experiments build; 0 in every launch of the default path): bit 0 = branch-free retry rounds, bit 1 = pipelined walk
+template <int BS, int TMAX, int U, int FORM = 0>
 __global__ __launch_bounds__(BS) void k_sym_lean(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                  const int *__restrict__ brpt, const int *__restrict__ bcol,
                                                  const int *__restrict__ row_perm, const int *__restrict__ row_prod,
@@ -644,10 +648,10 @@ __global__ __launch_bounds__(BS) void k_sym_lean(const int *__restrict__ arpt, c
     if (threadIdx.x == 0) s_nz = 0;
     // (the walk's first barrier also publishes the cleared table)
     int cnt = 0;
-    lean_walk<BS, false, U>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg, a_end, np, mb_row, &s_ls,
+    lean_walk<BS, false, U, (FORM & 2) != 0>(acol, (const real *)nullptr, brpt, bcol, (const real *)nullptr, bnnz, a_beg, a_end, np, mb_row, &s_ls,
                             [&](const IVec &k, const RVecT<1> &, int n, real) {
                                 int h[VW];
-                                lean_insert4(tab, mask, shift, bits, k, n, h, cnt);
+                                lean_insert4<(FORM & 1) != 0>(tab, mask, shift, bits, k, n, h, cnt);
                             });
     cnt = wave_sum(cnt);
     if (BS == 64) {
@@ -701,7 +705,7 @@ __global__ __launch_bounds__(BS) void k_sym_lean(const int *__restrict__ arpt, c
 
 // ---- numeric, bins 1..4 (calculate_value_col_bin_each_tb :829-927) ---------------------------------------------------
 // write_col: bit 0 write C.col (0: numeric-only re-run), bit 1 unsorted output.
-template <int BS, int TMAX, int U>
+template <int BS, int TMAX, int U, int FORM = 0>
 __global__ __launch_bounds__(BS) void k_num_lean(const int *__restrict__ arpt, const int *__restrict__ acol,
                                                  const real *__restrict__ aval, const int *__restrict__ brpt,
                                                  const int *__restrict__ bcol, const real *__restrict__ bval,
@@ -740,10 +744,10 @@ __global__ __launch_bounds__(BS) void k_num_lean(const int *__restrict__ arpt, c
     }
     if (threadIdx.x == 0) s_cnt = 0;
     // (the walk's first barrier also publishes the cleared tables)
-    lean_walk<BS, true, U>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, np_row, mb_row, &s_ov.w,
+    lean_walk<BS, true, U, (FORM & 2) != 0>(acol, aval, brpt, bcol, bval, bnnz, a_beg, a_end, np_row, mb_row, &s_ov.w,
                            [&](const IVec &k, const RVec &v, int m, real sc) {
                                int h[VW], fresh = 0;
-                               lean_insert4(keys, mask, shift, bits, k, m, h, fresh);
+                               lean_insert4<(FORM & 1) != 0>(keys, mask, shift, bits, k, m, h, fresh);
 #pragma unroll
                                for (int i = 0; i < VW; i++)
                                    if (i < m) unsafeAtomicAdd(vals + h[i], (acc_t)(sc * v.v[i]));

@@ -49,7 +49,7 @@
 //   spgemm/block.h         k_num_block, k_twin_groups                     (numeric bins 6-9: node blocks)
 //   spgemm/heavy_tiled.h   k_num_tiled                                    (bin 5, dense tiles)
 //   spgemm/heavy_ranked.h  k_num_ranked                                   (bin 5, thin rows)
-//   spgemm/heavy_flat.h    k_panel_slots, k_panel_fill, k_num_flat        (bin 5, stateless tiles; experiments build)
+//   spgemm/heavy_flat.h    k_panel_slots, k_panel_fill, k_num_flat, k_num_ranked_flat  (bin 5, stateless tiles; experiments build)
 //   spgemm/lean.h          k_sym_lean, k_num_lean                         (hash bins 1-4 on an instruction diet, round 4)
 //
 // Results: C.rpt / C.col are bit-identical to the reference by construction (distinct
@@ -83,18 +83,7 @@ namespace spgemm {
 //  host orchestration
 // ===================================================================================
 
-// Switches of the measurements in DESIGN.md 4.1: read from the environment only in a -DNSPARSE_EXPERIMENTS build,
-// constants in the product.
-static inline int exp_env(const char *name, int dflt)
-{
-#ifdef NSPARSE_EXPERIMENTS
-    const char *e = getenv(name);
-    return e ? atoi(e) : dflt;
-#else
-    (void)name;
-    return dflt;
-#endif
-}
+// (exp_env: internal.h -- switches of the measurements, read only in a -DNSPARSE_EXPERIMENTS build)
 
 // Numeric ladder in force.  NSPARSE_NUM_HEAVY_MIN=<n> (experiments): rows with more than n non-zeros go
 // to the heavy bin (cursor kernels, no sort) instead of the LDS hash bins above that size.
@@ -102,7 +91,7 @@ static const Thr &num_ladder()
 {
     static Thr t = [] {
         Thr v = kNumThr;
-        if (getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0) v.rank_span = 0;  // needs the block kernel
+        if (exp_env("NSPARSE_WINDOW_KERNEL", 1) == 0) v.rank_span = 0;  // needs the block kernel
         const int n = exp_env("NSPARSE_NUM_HEAVY_MIN", 0);
         if (n > 0)
             for (int q = 0; q < 4; q++)
@@ -133,11 +122,12 @@ static const Thr &sym_ladder()
 // round-2 criterion for parking long rows); 0: the round-2 walk (group walk + parked long rows).  R-MAT-22
 // 86.5 / 86.3 / 72.8 ms for 0 / 1 / 2 -- its rows are all hubs, so their AVERAGE B row is long as well --
 // webbase-1M class 2.71 / 2.46 / 2.42.
-static const int g_flat = getenv("NSPARSE_FLAT") ? atoi(getenv("NSPARSE_FLAT")) : 2;
-// round 4: the hash bins 1..4 of both phases run the lean kernels (lean.h); NSPARSE_TB_LEAN=0: round 3's k_sym_tb / k_num_tb,
-// bit 0: symbolic, bit 1: numeric
+static const int g_flat = exp_env("NSPARSE_FLAT", 2);
+// round 4: the lean kernels of the hash bins 1..4 (lean.h), experiments build only until they have been timed on the
+// device.  NSPARSE_TB_LEAN bit 0: symbolic, bit 1: numeric; bits 2 / 3 pick the form inside them (branch-free retry
+// rounds / pipelined walk) -- all four forms are template instantiations of ONE library, so the A/B costs one build
 static int g_deterministic = 0;  // nsparse_set_deterministic
-static const int g_tb_lean = getenv("NSPARSE_TB_LEAN") ? atoi(getenv("NSPARSE_TB_LEAN")) : 0;  // (off until the fixed 24-bit hash has been measured)
+static const int g_tb_lean = exp_env("NSPARSE_TB_LEAN", 0);  // (off until the fixed 24-bit hash has been measured)
 
 // Column lists (common.h: list_wanted): a heavy row goes to the listed kernel while slices x products stays within
 // this (NSPARSE_LIST_WORK); beyond it the cursor kernels, which see every product once, are cheaper.
@@ -426,15 +416,27 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
                        st, arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], \
                        hist[bin_], b->nnz, d_bs, (int *)nullptr, g_flat, TMAX >= 8192 ? tcol : (int *)nullptr, list_off,   \
                        row_span, 12, 12288)
+#define NSP_SYM_LEAN_GO(BS, TMAX, FORMX)                                                        \
+    hipLaunchKernelGGL((k_sym_lean<BS, TMAX, (BS >= 512 ? 4 : 2), FORMX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
+                       arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], hist[bin_], b->nnz, d_bs, \
+                       TMAX >= 8192 ? tcol : (int *)nullptr, list_off, row_span, 12, 12288)
 #define NSP_SYM_TB(BIN, BS, TMAX)                                                              \
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        if ((g_tb_lean & 1) && b->N <= (1 << 24)) /* lean_slot hashes 24 bits of the column */    \
-            hipLaunchKernelGGL((k_sym_lean<BS, TMAX, (BS >= 512 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
-                               arpt, acol, brpt, bcol, row_perm, row_prod, row_maxb, row_nz, off[bin_], hist[bin_], b->nnz, d_bs, \
-                               TMAX >= 8192 ? tcol : (int *)nullptr, list_off, row_span, 12, 12288);  \
-        else NSP_SYM_TB_GO(BS, TMAX);                                                          \
+        bool lean_done = false;                                                                \
+        if constexpr (kExperiments) { /* the lean family: experiments build only, until it has been timed on the device */ \
+            if ((g_tb_lean & 1) && b->N <= (1 << 24)) { /* lean_slot hashes 24 bits of the column */ \
+                switch ((g_tb_lean >> 2) & 3) { /* bits 2, 3: branch-free retries, pipelined walk */ \
+                    case 1: NSP_SYM_LEAN_GO(BS, TMAX, 1); break;                                 \
+                    case 2: NSP_SYM_LEAN_GO(BS, TMAX, 2); break;                                 \
+                    case 3: NSP_SYM_LEAN_GO(BS, TMAX, 3); break;                                 \
+                    default: NSP_SYM_LEAN_GO(BS, TMAX, 0);                                       \
+                }                                                                              \
+                lean_done = true;                                                              \
+            }                                                                                  \
+        }                                                                                      \
+        if (!lean_done) NSP_SYM_TB_GO(BS, TMAX);                                               \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -474,7 +476,7 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     };
     // bin 10 with windows wider than the 2^20-bit window and sorted rows of B: cursor kernel, every
     // product seen once (k_sym_bits would walk all products once per 2^20-column piece)
-    static const int sym_cursor_on = !(getenv("NSPARSE_SYM_CURSOR") && getenv("NSPARSE_SYM_CURSOR")[0] == '0');
+    static const int sym_cursor_on = exp_env("NSPARSE_SYM_CURSOR", 1) != 0;
     static const int sym_long_len = exp_env("NSPARSE_SYM_LONG", 32);
     if (hist[10] > 0 && now(10) && sym_cursor_on && b_sorted && max_span[10] > 32768 * 32 && max_alen > 0) {
         hipStream_t st = L.begin(10);
@@ -586,13 +588,13 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // longest, so they should not queue behind a million small rows.  Nothing here waits on the
     // host; the cursor slab returns to the cache when the call has drained (collect()).
     constexpr int kTileW = 12288;  // LDS accumulators are double in both builds
-    static const int tiled_on = !(getenv("NSPARSE_TILED") && getenv("NSPARSE_TILED")[0] == '0');
+    static const int tiled_on = exp_env("NSPARSE_TILED", 1) != 0;
     // B rows longer than this are swept by whole wavefronts (R-MAT-16 / 18 / 22: 128 -> 32 saves 9 / 8 / 4 %)
     static const int long_len = exp_env("NSPARSE_TILED_LONG", 32);
     static const int tile_sel = exp_env("NSPARSE_TILED_W", 0);
     // rows with fewer than one non-zero per ranked_dens columns of their window take the ranked
     // kernel (0: none, < 0: all)
-    static const int ranked_dens = getenv("NSPARSE_RANKED_DENS") ? atoi(getenv("NSPARSE_RANKED_DENS")) : 12;
+    static const int ranked_dens = exp_env("NSPARSE_RANKED_DENS", 12);
     // dense tiles alone: at most 1024 per row, wider matrices hash globally; with the ranked kernel
     // taking the wide rows there is no limit
     const bool use_tiled = tiled_on && b_sorted && hist[kNumGlobalBin] > 0 && max_alen > 0 &&
@@ -663,11 +665,15 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                 int *blk = (int *)dev_alloc(sizeof(int) * n_ints);
                 int *d_cnt = blk, *slot_of = blk + 2, *slot_row = slot_of + b->M, *tab = slot_row + slots_max;
                 NSP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
-                hipLaunchKernelGGL(k_panel_slots, dim3(ceil_div(b->M, 256)), dim3(256), 0, st, brpt, b->M, min_len, slot_of,
-                                   slot_row, d_cnt, (int)slots_max);
+                if (all_rows)
+                    hipLaunchKernelGGL(k_panel_slots<true>, dim3(ceil_div(b->M, 256)), dim3(256), 0, st, brpt, b->M, min_len,
+                                       slot_of, slot_row, d_cnt, (int)slots_max);
+                else
+                    hipLaunchKernelGGL(k_panel_slots<false>, dim3(ceil_div(b->M, 256)), dim3(256), 0, st, brpt, b->M, min_len,
+                                       slot_of, slot_row, d_cnt, (int)slots_max);
                 const long long cells = slots_max * (np + 1);
-                hipLaunchKernelGGL(k_panel_fill, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, brpt, bcol,
-                                   (const int *)slot_row, (const int *)d_cnt, np, kTileW, tab);
+                hipLaunchKernelGGL(k_panel_fill<kTileW>, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, brpt, bcol,
+                                   (const int *)slot_row, (const int *)d_cnt, np, tab);
                 L.free_later(blk);
                 pt_slot_of = slot_of, pt_tab = tab, pt_np = np;
                 if ((heavy_flat & 1) && ranked_dens >= 0 && tile_sel == 0) {
@@ -745,15 +751,27 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                        row_prod, row_maxb, off[bin_], hist[bin_], b->nnz,                       \
                        write_col | (g_flat ? 0 : 4) | (g_flat == 2 ? 8 : 0),                    \
                        tb_prof ? tb_prof + 8 * bin_ : nullptr)
+#define NSP_NUM_LEAN_GO(BS, TMAX, FORMX)                                                        \
+    hipLaunchKernelGGL((k_num_lean<BS, TMAX, (BS >= 512 ? 4 : 2), FORMX>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
+                       arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_prod, row_maxb, \
+                       off[bin_], hist[bin_], b->nnz, write_col)
 #define NSP_NUM_TB(BIN, BS, TMAX, PMAX)                                                        \
     if (hist[BIN] > 0 && now(BIN)) {                                                           \
         constexpr int bin_ = BIN;                                                              \
         hipStream_t st = L.begin(BIN);                                                         \
-        if ((g_tb_lean & 2) && !tb_prof && b->N <= (1 << 24))                                  \
-            hipLaunchKernelGGL((k_num_lean<BS, TMAX, (BS >= 512 ? 4 : 2)>), dim3(8 * ceil_div(hist[bin_], 8)), dim3(BS), 0, st, \
-                               arpt, acol, aval, brpt, bcol, bval, c->d_rpt, c->d_col, c->d_val, row_perm, row_prod, row_maxb, \
-                               off[bin_], hist[bin_], b->nnz, write_col);                      \
-        else NSP_NUM_TB_GO(BS, TMAX, PMAX);                                                    \
+        bool lean_done = false;                                                                \
+        if constexpr (kExperiments) {                                                          \
+            if ((g_tb_lean & 2) && !tb_prof && b->N <= (1 << 24)) {                              \
+                switch ((g_tb_lean >> 2) & 3) {                                                \
+                    case 1: NSP_NUM_LEAN_GO(BS, TMAX, 1); break;                                 \
+                    case 2: NSP_NUM_LEAN_GO(BS, TMAX, 2); break;                                 \
+                    case 3: NSP_NUM_LEAN_GO(BS, TMAX, 3); break;                                 \
+                    default: NSP_NUM_LEAN_GO(BS, TMAX, 0);                                       \
+                }                                                                              \
+                lean_done = true;                                                              \
+            }                                                                                  \
+        }                                                                                      \
+        if (!lean_done) NSP_NUM_TB_GO(BS, TMAX, PMAX);                                         \
         NSP_LAUNCH_CHECK();                                                                    \
         L.end(BIN);                                                                            \
     }
@@ -826,9 +844,9 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     // node-block numeric window kernel (block.h) for matrices with twin rows (grp != nullptr); rows of
     // matrices without that structure are one-row groups with one-entry runs, which the first kernel
     // (window.h: four entries per lane and step) walks in fewer instructions: cant-class irregular
-    // stand-in 0.42 ms against 0.63.  NSPARSE_LEAN=0: always the first kernel; =2: always the block one.
-    static const bool lean_on = !(getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0);
-    static const bool blk_all = getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 2;
+    // stand-in 0.42 ms against 0.63.  NSPARSE_WINDOW_KERNEL=0 (experiments build): always the first kernel; =2: always the block one.
+    static const bool lean_on = exp_env("NSPARSE_WINDOW_KERNEL", 1) != 0;
+    static const bool blk_all = exp_env("NSPARSE_WINDOW_KERNEL", 1) == 2;
     // workgroup sizes of the window bins: the node-block kernel is bound by the latency of its dependent
     // loads, i.e. by the groups in flight per CU, and does best with 128 threads per group (cant class:
     // 64 / 128 / 256 / 512 threads -> 0.240 / 0.197 / 0.216 / 0.41 ms); the first kernel keeps 256 / 256 / 512
@@ -1089,7 +1107,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // up here: a lookup under the cache lock per array (seventeen of them) was host time at the very start
     // of the call, before the first kernel is even queued.
     static const bool twins_on = !(getenv("NSPARSE_TWINS") && atoi(getenv("NSPARSE_TWINS")) == 0);
-    static const bool lean_on = !(getenv("NSPARSE_LEAN") && atoi(getenv("NSPARSE_LEAN")) == 0);
+    static const bool lean_on = exp_env("NSPARSE_WINDOW_KERNEL", 1) != 0;
     const bool find_twins = !numeric_only && twins_on && M > 1;
     const bool want_btwin = twins_on && lean_on && K > 1;
     unsigned int tsize = 1024;
@@ -1097,7 +1115,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     const long long twin_fill_words = find_twins ? (long long)tsize + ((long long)M * (1 + kGroupMembers) + 1) / 2 : 0;
     // matrices of kTwinSampleMin rows and more: k_b_info samples the rows of A, k_row_products probes the pattern map
     // only if the sample holds a pattern twice (setup.h: TwinSample; NSPARSE_TWIN_SAMPLE=0: always probe)
-    static const bool sample_on = !(getenv("NSPARSE_TWIN_SAMPLE") && atoi(getenv("NSPARSE_TWIN_SAMPLE")) == 0);
+    static const bool sample_on = exp_env("NSPARSE_TWIN_SAMPLE", 1) != 0;
     unsigned int sample_slots = 0;
     if (find_twins && sample_on && M >= kTwinSampleMin) {
         sample_slots = 1024;
@@ -1223,13 +1241,13 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // matrices of up to 1 M rows: the helper chains behind the big kernels are one launch each (fused.h)
     static const bool fused_on = !(getenv("NSPARSE_FUSED") && atoi(getenv("NSPARSE_FUSED")) == 0);
     // rows per thread of the fused tails: one up to 256 K rows, four up to 1 M (NSPARSE_FUSED_BIG=0: chains beyond 256 K)
-    static const bool fused_big = !(getenv("NSPARSE_FUSED_BIG") && atoi(getenv("NSPARSE_FUSED_BIG")) == 0);
+    static const bool fused_big = exp_env("NSPARSE_FUSED_BIG", 1) != 0;
     const int frows = (M + 1 <= kFusedMaxBlocks * 1024 || !fused_big) ? 1 : 4;
     const int fgrid = ceil_div(M + 1, 1024 * frows);
     // (one 1024-thread workgroup per CU at most: the grid barrier needs all of them resident, also on a
     //  partitioned or CU-masked device)
     // NSPARSE_FUSED_FORCE=1 (tests): skip the census, so that a CU-masked device exercises the time-out path
-    static const bool fused_force = getenv("NSPARSE_FUSED_FORCE") && atoi(getenv("NSPARSE_FUSED_FORCE")) == 1;
+    static const bool fused_force = exp_env("NSPARSE_FUSED_FORCE", 0) == 1;
     if (fused_on && !numeric_only && cx.coresident < 0 && fgrid <= kFusedMaxBlocks)
         cx.coresident = fused_force ? kFusedMaxBlocks : census_coresident(cx, s0);
     const bool fuse = fused_on && cx.fused_ok && !numeric_only && fgrid <= kFusedMaxBlocks && fgrid <= cx.coresident;
@@ -1243,7 +1261,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     const int grid_m = ceil_div(M, 1024);
     // (row records: not with the cache off -- two more megabyte-sized hipMalloc / hipFree pairs cost more
     //  than the round trips they save)
-    if (pooled && fuse && frows == 1 && use_bm && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
+    if (pooled && fuse && frows == 1 && use_bm && exp_env("NSPARSE_BLK_DESC", 1) != 0)
         sym_desc = (int4 *)dev_alloc(sizeof(int4) * 3 * (size_t)M);
     if (fuse) {
         const int seq = ++cx.seq;
@@ -1309,8 +1327,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
         {
             long long binned0 = 0;
             for (int q = 0; q < NB; q++) binned0 += h_sym->hist[q];
-            static const bool keyed_b_on = !(getenv("NSPARSE_KEYED") && atoi(getenv("NSPARSE_KEYED")) == 0) &&
-                                           !(getenv("NSPARSE_KEYED_B") && atoi(getenv("NSPARSE_KEYED_B")) == 0);
+            static const bool keyed_b_on = exp_env("NSPARSE_KEYED", 1) != 0 && exp_env("NSPARSE_KEYED_B", 1) != 0;
             if (keyed_b_on && find_twins && lean_on && fuse && !same_shape && K > 1 && (M - binned0) * 8 >= M) {
                 unsigned int tsb = 1024;
                 while (tsb < 2u * (unsigned int)K) tsb <<= 1;
@@ -1402,7 +1419,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
     // numeric window: full call -> rows whose bitmap was written; re-run -> every eligible row
     const int *num_span = numeric_only ? row_span : row_span_num;
     if (!numeric_only && bm == nullptr) num_thr.dense_ratio = num_thr.rank_span = 0;
-    if (pooled && fuse && frows == 1 && bm && lean_on && !(getenv("NSPARSE_BLK_DESC") && atoi(getenv("NSPARSE_BLK_DESC")) == 0))
+    if (pooled && fuse && frows == 1 && bm && lean_on && exp_env("NSPARSE_BLK_DESC", 1) != 0)
         blk_desc = (int4 *)dev_alloc(sizeof(int4) * 3 * (size_t)M);
     if (fuse) {
         // twins' results, groups, C.rpt, histogram, permutation and the publish in one launch (fused.h)
@@ -1469,7 +1486,7 @@ static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 
     // C = A * A on a matrix whose twin rows are mostly NOT neighbours (k_numeric_setup counted them): the
     // node-block kernel builds its runs of B rows from the pattern leaders instead of from neighbouring entries
-    static const bool keyed_on = !(getenv("NSPARSE_KEYED") && atoi(getenv("NSPARSE_KEYED")) == 0);
+    static const bool keyed_on = exp_env("NSPARSE_KEYED", 1) != 0;
     const int *bkey = nullptr;
     if (keyed_on && fuse && grp && twin_of && (long long)h_num->far_twins * 4 > (long long)S.twin_rows) {
         if (same_shape && h_num->ab_differ == 0) bkey = twin_of;  // B is A: A's own pattern leaders

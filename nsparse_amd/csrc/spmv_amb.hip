@@ -337,15 +337,14 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
     // matrix that streams from HBM reads eight far-apart regions at once under the remap and loses DRAM
     // locality: nlpkkt class 0.196 -> 0.178 ms without it (the bare value stream 0.164 -> 0.150).
     // NSPARSE_SPMV_NOREMAP=1 / NSPARSE_SPMV_REMAP=1 force either.
-    static const int env_noremap = getenv("NSPARSE_SPMV_NOREMAP") ? 1 : 0;
-    static const int env_remap = getenv("NSPARSE_SPMV_REMAP") ? 1 : 0;
+    static const int env_noremap = exp_env("NSPARSE_SPMV_NOREMAP", 0), env_remap = exp_env("NSPARSE_SPMV_REMAP", 0);
     const long long stream_bytes = (long long)mat->nnz * (long long)sizeof(real) + (long long)mat->nnz / mat->block_size * 2;
     const int no_remap = env_noremap || (!env_remap && stream_bytes > (128LL << 20));
     // (the forms below the whole-row kernel -- NSPARSE_SPMV_PIPE=0 / 1 / 2, NSPARSE_SPMV_PLAIN -- are round 1 / 2's kernels,
     //  kept for the before / after counters of tools/pmc_spmv.sh: instantiated in -DNSPARSE_EXPERIMENTS builds only
     //  (round 5: 200 of the 320 SpMV instantiations were reachable through those switches alone))
 #ifdef NSPARSE_EXPERIMENTS
-    static const int plain = getenv("NSPARSE_SPMV_PLAIN") ? 1 : 0;
+    static const int plain = exp_env("NSPARSE_SPMV_PLAIN", 0);
 #else
     constexpr int plain = 0;
 #endif
@@ -365,7 +364,7 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
     // blocks of one batch of the pipelined form: as many as keep values + x within ~48 registers
     constexpr int UB = BSZ >= 12 ? 1 : (BSZ >= 6 ? 2 : (BSZ >= 3 ? 4 : 8));
 #ifdef NSPARSE_EXPERIMENTS
-    static const int pipe = getenv("NSPARSE_SPMV_PIPE") ? atoi(getenv("NSPARSE_SPMV_PIPE")) : 4;  // 0: first form, 1 / 2: pipelined, 4: whole row in flight
+    static const int pipe = exp_env("NSPARSE_SPMV_PIPE", 4);  // 0: first form, 1 / 2: pipelined, 4: whole row in flight
 #else
     constexpr int pipe = 4;
 #endif
@@ -373,7 +372,7 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
     hipLaunchKernelGGL((k_spmv_amb_pipe<BSZ, AT, UBX>), grid, block, 0, st, d_y, mat->d_sellcs_val, \
                        mat->d_sellcs_col, mat->d_cl, mat->d_cs, d_x, mat->d_s_write_permutation, \
                        mat->d_s_write_permutation_offset, rows, (int)mat->seg_size, mat->M, mat->N, nb8_arg, abl)
-    static const int abl = getenv("NSPARSE_SPMV_ABL") ? atoi(getenv("NSPARSE_SPMV_ABL")) : 0;
+    static const int abl = exp_env("NSPARSE_SPMV_ABL", 0);
     // blocks of the whole-row form: values + x of NB blocks are live at once = NB * BSZ * 2 operands, two registers
     // each in double.  __launch_bounds__(1024) caps a lane at 128 VGPRs; past ~100 operand registers the compiler
     // spills (round 5: NB = 10 for BSZ 4 / 5 cost 148 / 316 B of scratch per lane, NB = 3 for BSZ 11 36 B -- an
@@ -383,9 +382,10 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
     constexpr int NB = BSZ == 1 ? 24 : (BSZ == 2 ? 14 : (BSZ == 3 ? 10 : (96 / (BSZ * 4) > 0 ? 96 / (BSZ * 4) : 1)));
     // cache-resident matrix of few chunks whose rows are wider than the whole-row form keeps in flight: split the
     // rows over W wavefronts (k_spmv_amb_split).  NSPARSE_SPMV_SPLIT=1: W chosen from the average row width, =2 / 4 / 8:
-    // that many; default 0 (off) until the kernel has been timed against the whole-row form on the device
-    static const int split_env = getenv("NSPARSE_SPMV_SPLIT") ? atoi(getenv("NSPARSE_SPMV_SPLIT")) : 0;
+    // that many; default 0 (off) until the kernel has been timed against the whole-row form on the device.  Experiments build only.
+    static const int split_env = exp_env("NSPARSE_SPMV_SPLIT", 0);
     constexpr int NBS = BSZ >= 12 ? 1 : (BSZ >= 6 ? 2 : (BSZ >= 3 ? 6 : (BSZ == 2 ? 8 : 12)));
+    if constexpr (kSpmvExperiments) {
     if (mat->chunk == 64 && pipe == 4 && !plain && split_env != 0 && !no_remap && mat->c_size <= 8192) {
         const double avgb = (double)mat->nnz / ((double)BSZ * (double)rows);  // average blocks per row (= chunk width)
         int W = 1;
@@ -404,6 +404,7 @@ static void launch_bs(real *d_y, const sfAMB *mat, const real *d_x, int tb, hipS
             return;
         }
     }
+    }  // (split-row form: experiments build only, until it has been timed against the whole-row form on the device)
     if (mat->chunk == 64 && pipe == 4 && !plain) {
         if (atomic)
             hipLaunchKernelGGL((k_spmv_amb_row<BSZ, true, NB, UB>), grid, block, 0, st, d_y, mat->d_sellcs_val,
@@ -440,7 +441,7 @@ static void launch(real *d_y, const sfAMB *mat, const real *d_x, const sfPlan *p
     // chunk present each row is stored exactly once, and the memset -- a third of the time of a
     // cache-resident SpMV -- is skipped.
     const bool every_row_stored = mat->seg_num == 1 && (long long)mat->c_size * mat->chunk >= (long long)mat->pad_M;
-    static const int no_memset = getenv("NSPARSE_SPMV_ABL") ? (atoi(getenv("NSPARSE_SPMV_ABL")) & 4) : 0;  // diagnostics
+    static const int no_memset = exp_env("NSPARSE_SPMV_ABL", 0) & 4;  // diagnostics
     if (!every_row_stored && mat->M > 0 && !no_memset) NSP_CHECK(hipMemsetAsync(d_y, 0, sizeof(real) * (size_t)mat->M, st));
     if (mat->c_size <= 0) return;
     int tb = (int)plan->thread_block;

@@ -212,6 +212,32 @@ def experiments_lib_dir():
     return exp if os.path.exists(os.path.join(exp, "libnsparse_d.so")) else None
 
 
+# Switches that only the -DNSPARSE_EXPERIMENTS build reads (csrc/internal.h: exp_env): measurement knobs and the opt-in
+# kernel families.  The product library treats them as constants, so a test that sets one runs on the variant library.
+EXPERIMENT_SWITCHES = ("NSPARSE_TB_LEAN", "NSPARSE_RANKED_DENS", "NSPARSE_FUSED_FORCE", "NSPARSE_FUSED_BIG", "NSPARSE_TWIN_SAMPLE",
+                       "NSPARSE_SYM_CURSOR", "NSPARSE_SPMV_SPLIT", "NSPARSE_SPMV_PIPE", "NSPARSE_SPMV_PLAIN", "NSPARSE_SPMV_ABL",
+                       "NSPARSE_SPMV_REMAP", "NSPARSE_SPMV_NOREMAP", "NSPARSE_KEYED", "NSPARSE_KEYED_B", "NSPARSE_TILED",
+                       "NSPARSE_HEAVY_FLAT", "NSPARSE_WINDOW_KERNEL", "NSPARSE_FLAT", "NSPARSE_BLK_DESC", "NSPARSE_STREAM_PRIO",
+                       "NSPARSE_PRIO_BINS")
+
+
+def variant_env(env, base=None):
+    """`env` (additions to the environment of a child process) with NSPARSE_LIB_DIR pointing at the experiments variant
+    of the library in use (or of `base`, a library directory) when it sets a switch only that build reads; skips the
+    test when the variant has not been built."""
+    if not any(k in EXPERIMENT_SWITCHES for k in env) or "NSPARSE_LIB_DIR" in env and env["NSPARSE_LIB_DIR"].rstrip("/").endswith("_exp"):
+        return env
+    if base is not None:
+        d = base.rstrip("/") + "_exp"
+        d = d if os.path.exists(os.path.join(d, "libnsparse_d.so")) else None
+    else:
+        d = experiments_lib_dir()
+    if d is None:
+        import pytest
+        pytest.skip("needs the -DNSPARSE_EXPERIMENTS variant library (__graft_entry__.build() makes lib_exp)")
+    return dict(env, NSPARSE_LIB_DIR=d)
+
+
 def spgemm_subprocess(A, env, prec="d", B=None, numeric_again=False):
     """Run spgemm() on A (times B, default A) in a fresh interpreter with extra environment (the
     library reads its tuning switches once per process).  Returns (C dict, dict of stats lists)."""
@@ -221,6 +247,7 @@ def spgemm_subprocess(A, env, prec="d", B=None, numeric_again=False):
     import sys
     import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = variant_env(env)
     with tempfile.TemporaryDirectory() as td:
         np.savez(os.path.join(td, "a.npz"), rpt=A["rpt"], col=A["col"], val=A["val"], M=A["M"], N=A["N"])
         Bm = A if B is None else B

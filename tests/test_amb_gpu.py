@@ -8,7 +8,7 @@ import pytest
 
 import nsparse_amd as ns
 from conftest import GOLDEN, TEST_MTX, load_golden
-from gpu_util import DeviceAMB, synth
+from gpu_util import DeviceAMB, synth, variant_env
 
 pytestmark = pytest.mark.gpu
 
@@ -192,5 +192,5 @@ def test_split_row_spmv_for_cache_resident_matrices(split, oracle_d):
             "    d.close()\n"
             "print('SPLIT_OK')\n" % (ROOT, os.path.join(ROOT, "tests")))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=ROOT,
-                       env=dict(os.environ, NSPARSE_SPMV_SPLIT=split))
+                       env=dict(os.environ, **variant_env(dict(NSPARSE_SPMV_SPLIT=split))))
     assert r.returncode == 0 and "SPLIT_OK" in r.stdout, r.stderr[-2000:]

@@ -33,7 +33,20 @@ def emu_lib():
     return LIB
 
 
+def _exp(emu_lib):
+    """The emulation build of the -DNSPARSE_EXPERIMENTS variant (tests/emu/lib_exp): the only library that reads the
+    measurement switches (NSPARSE_FUSED_FORCE, NSPARSE_TB_LEAN, ...) and carries the opt-in kernel families."""
+    d = emu_lib.rstrip("/") + "_exp"
+    if not os.path.exists(os.path.join(d, "libnsparse_d.so")):
+        pytest.skip("tests/emu/lib_exp not built (make -C tests/emu EXTRA=-DNSPARSE_EXPERIMENTS OUT=.../lib_exp libs)")
+    return d
+
+
 def _gpu_tests_on_emu(emu_lib, args, env=None, timeout=900, expect_min=1):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import EXPERIMENT_SWITCHES
+    if any(k in EXPERIMENT_SWITCHES for k in (env or {})):
+        emu_lib = _exp(emu_lib)
     e = dict(os.environ, NSPARSE_LIB_DIR=emu_lib, **(env or {}))
     r = subprocess.run([sys.executable, "-m", "pytest", "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"] + args, cwd=ROOT,
                        env=e, capture_output=True, text=True, timeout=timeout)
@@ -221,7 +234,7 @@ def test_grid_barrier_that_times_out_falls_back_to_the_chains(stall, tails_run, 
     import json
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "stalled_workgroup.py")], capture_output=True, text=True,
                        timeout=600, cwd=ROOT,
-                       env=dict(os.environ, NSPARSE_LIB_DIR=emu_lib, NSPARSE_FUSED_FORCE="1", EMU_STALL=stall, EMU_TRACE="1",
+                       env=dict(os.environ, NSPARSE_LIB_DIR=_exp(emu_lib), NSPARSE_FUSED_FORCE="1", EMU_STALL=stall, EMU_TRACE="1",
                                 EMU_CLOCK_DIV="200"))  # (the 50 ms bound is ~0.5 s of a busy host's time)
     assert r.returncode == 0, r.stderr[-2000:]
     calls = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("[")][-1])

@@ -487,7 +487,7 @@ def test_concurrent_callers_serialise(lib_d, oracle_d):
     assert not errs, errs
 
 
-@pytest.mark.parametrize("lean", ["0", "3"])
+@pytest.mark.parametrize("lean", ["0", "3", "7", "11", "15"])  # bits 2 / 3: branch-free retry rounds / pipelined walk (template forms)
 def test_hash_bins_both_kernel_families(lean, lib_d, oracle_d):
     """NSPARSE_TB_LEAN=3 / 0: the hash bins 1-4 of both phases through the lean kernels of round 4 (lean.h: owner-array
     product walk, 24-bit multiplicative hash, in-register sort of one-wavefront rows) and through round 3's k_sym_tb /
@@ -603,7 +603,7 @@ import ctypes as C, json, sys
 sys.path.insert(0, "tests")
 import numpy as np
 import nsparse_amd as ns
-from gpu_util import spgemm, synth
+from gpu_util import spgemm, synth, variant_env
 lib = ns.load("d")
 A = synth(lib, 0, 9, 9, 800, seed=5)          # 194,400 rows: the fused tails want 190 co-resident workgroups
 got, st = spgemm(lib, A)
@@ -630,7 +630,7 @@ def test_fused_tails_under_a_cu_mask(tmp_path, oracle_d):
     for tag, extra in (("plain", {}), ("mask", {"HSA_CU_MASK": "0:0-31"}),
                        ("mask_forced", {"HSA_CU_MASK": "0:0-31", "NSPARSE_FUSED_FORCE": "1"})):
         npz = str(tmp_path / f"{tag}.npz")
-        r = subprocess.run([sys.executable, "-c", _MASK_SCRIPT, npz], cwd=ROOT, env=dict(os.environ, **extra),
+        r = subprocess.run([sys.executable, "-c", _MASK_SCRIPT, npz], cwd=ROOT, env=dict(os.environ, **variant_env(extra)),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, (tag, r.stderr[-1500:])
         info = json.loads(r.stdout.strip().splitlines()[-1])
@@ -670,7 +670,7 @@ def test_non_finite_values_stay_in_their_columns(kind, dims, oracle_d):
     np.testing.assert_allclose(got["val"][ok], ref["val"][ok], rtol=1e-9)
 
 
-@pytest.mark.parametrize("lean", ["0", "3"])
+@pytest.mark.parametrize("lean", ["0", "3", "15"])
 def test_big_table_bins_on_clustered_columns(lean, oracle_d):
     """Rows of the two big-table numeric bins (683 .. 5461 non-zeros) through both kernel families (NSPARSE_TB_LEAN).
     B is a diagonal matrix, so a row of C has exactly the columns of its row of A and every A entry reaches a
@@ -696,7 +696,7 @@ def test_big_table_bins_on_clustered_columns(lean, oracle_d):
     assert st["num"][3] + st["num"][4] == len(rows), st["num"][:8]
 
 
-@pytest.mark.parametrize("lean", ["0", "3"])
+@pytest.mark.parametrize("lean", ["0", "3", "15"])
 def test_one_wavefront_bin(lean, oracle_d):
     """The rows of numeric bin 1 (17 .. 170 non-zeros) and symbolic bin 1 through both kernel families
     (NSPARSE_TB_LEAN): a 27-point stencil (every row in those bins; the lean walk spreads the 189 chunks of a row

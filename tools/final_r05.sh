@@ -5,7 +5,7 @@
 #             commits between the last proven tree and HEAD), so a red test names the commit that broke it
 #   smoke     __graft_entry__.smoke()
 #   bench     the bench line + kernel trace of the same command -> gpurun_out/r05/
-#   ab        tools/ab_lean3.sh: round-3 hash kernels vs the lean builds, serialised per-bin times
+#   ab        tools/ab_variants.sh: default kernels vs the lean hash forms and the stateless heavy-row tiles (one experiments library), serialised per-bin times
 #   spmv      cache-resident SpMV: split-row kernel widths against rocSPARSE csrmv
 #   profiles  per-config kernel stats + PMC (tools/profile_configs.sh)
 export TMPDIR=/tmp
@@ -55,12 +55,12 @@ print("driver_run_s", d.get("driver_run_s"))
 PY
   tail -5 $O/bench.err ;;
 ab)
-  bash tools/ab_lean3.sh stencil webbase1m rmat18 rmat22 2>&1 | tail -24 | tee $O/ab_lean3.txt
-  cp gpurun_out/ab_lean3.log $O/ab_lean3.log ;;
+  bash tools/ab_variants.sh stencil webbase1m rmat18 rmat22 2>&1 | tail -40 | tee $O/ab_variants.txt
+  cp gpurun_out/ab_variants.log $O/ab_variants.log ;;
 spmv)
   for sp in 0 1 2 4 8; do
     echo "== NSPARSE_SPMV_SPLIT=$sp"
-    NSPARSE_SPMV_SPLIT=$sp timeout 600 python bench.py --no-cpu --no-pmc --no-irregular --no-configs --no-large --steps 2 2>/dev/null | python -c "
+    NSPARSE_LIB_DIR=$PWD/nsparse_amd/lib_exp NSPARSE_SPMV_SPLIT=$sp timeout 600 python bench.py --no-cpu --no-pmc --no-irregular --no-configs --no-large --steps 2 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['spmv']
 print({k:s.get(k) for k in ('ms_per_spmv','ms_kernel_events','value','plan','ans_check_fails')}, s.get('vendor_csrmv'))"
