@@ -22,7 +22,8 @@ constexpr bool kExperiments = false;
 // tests/emu only: census of the B entries a heavy-row kernel loads against the products it accumulates (family =
 // FC_* below; what = 0 B.col loads, 1 B.val loads, 2 products, 3 tiles).  The product build compiles it away.
 enum { FC_TILED = 0, FC_RANKED = 1, FC_RANKED_SYM = 2, FC_FLAT = 3, FC_WALK = 4, FC_RANKED_FLAT = 5,
-       FC_FLAT_EXTENT = 6 /* what 0 / 1: entries inside their extent, k_num_flat / k_num_ranked_flat */ };
+       FC_FLAT_EXTENT = 6 /* what 0 / 1 / 2: entries inside their extent, k_num_flat / k_num_ranked_flat / k_sym_flat */,
+       FC_SYM_FLAT = 7 };
 #ifdef NSP_EMU
 extern "C" void nsp_emu_count(int family, int what, long long n);
 #define NSP_COUNT(family, what, n) nsp_emu_count((family), (what), (long long)(n))

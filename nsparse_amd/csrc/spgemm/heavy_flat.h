@@ -433,5 +433,140 @@ __global__ __launch_bounds__(BS) void k_num_ranked_flat(const int *__restrict__ 
     }
 }
 
+// ===================================================================================
+//  symbolic twin: bit windows wider than 2^20 columns, one flat walk per tile
+// ===================================================================================
+// The rows the SYM mode of k_num_ranked takes (symbolic bin 10 on matrices wider than 2^20 columns with sorted B): count
+// the distinct columns of the row and, when asked, write them out as the row's sorted list (common.h: bits_to_list) for
+// the list-driven numeric tiles.  Same tile (a bitmap over W columns), same listing rule and list allocation; what
+// differs is the walk: a tile is the WG = (W / G) * G columns of whole panels starting at the panel of the row's first
+// column, the extent of a B row inside it is tab[slot][first panel] .. tab[slot][last panel + 1], and the column ids are
+// read flat, four at a time, once -- the cursor kernel loads 1.6-1.9 column ids per product (tests/emu census).
+// Own row queue (queue_head2 of the SYMBOLIC counter block, like the kernel it replaces).
+template <int BS, int W, int G>
+__global__ __launch_bounds__(BS) void k_sym_flat(const int *__restrict__ arpt, const int *__restrict__ acol,
+                                                 const int *__restrict__ brpt, const int *__restrict__ bcol, int bnnz,
+                                                 const int *__restrict__ slot_of, const int *__restrict__ tab, int tstride,
+                                                 const int *__restrict__ row_perm, int bin_off, int count, BinState *bs,
+                                                 const int *__restrict__ row_lo, const int *__restrict__ row_span,
+                                                 int *__restrict__ row_nz_out, int *__restrict__ tcol,
+                                                 long long *__restrict__ list_off, long long list_work,
+                                                 const int *__restrict__ row_prod)
+{
+    constexpr int NW = BS / 64;
+    constexpr int V = VW, U = 4;
+    constexpr int NWORD = W / 32;
+    constexpr int WG = (W / G) * G;
+    static_assert(WG >= G, "the bitmap covers at least one panel");
+    __shared__ __attribute__((aligned(16))) unsigned int bits[NWORD];
+    __shared__ int2 s_ext[BS];
+    __shared__ FlatScratch<BS> fs;
+    __shared__ int s_wsum[NW];
+    __shared__ int s_row;
+    __shared__ long long s_off;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < NWORD; i += BS) bits[i] = 0;
+    while (true) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_row = atomicAdd(&bs->queue_head2, 1);
+        __syncthreads();
+        const int q = s_row;
+        if (q >= count) break;
+        const int rid = row_perm[bin_off + q];
+        const int lo = row_lo[rid], span = row_span[rid];
+        bool listing = false;
+        if (tcol != nullptr) {
+            const int np = row_prod[rid];
+            const int lcap = np < span ? np : span;
+            // list_work < 0: a list for every row that can be heavy in the numeric phase; > 0: only the rows the listed
+            // kernel would take; -2: diagnostics, no stores (the rule of k_num_ranked<SYM>)
+            listing = list_work < 0 ? np > kListMinNnz : list_wanted(lcap, np, list_work);
+            if (listing && threadIdx.x == 0) {
+                s_off = (long long)atomicAdd(&bs->list_cursor, (unsigned long long)lcap);
+                list_off[rid] = list_work == -2 ? -1 : s_off;
+            }
+        }
+        __syncthreads();  // s_off
+        const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+        const long long row_end = (long long)lo + span;
+        int sym_cnt = 0;
+        for (long long t = (long long)(lo / G) * G; t < row_end; t += WG) {
+            const int t0 = (int)t;
+            const int p_a = t0 / G, p_b = p_a + W / G;
+            if (threadIdx.x == 0) NSP_COUNT(FC_SYM_FLAT, 3, 1);
+            for (int b0 = a_beg; b0 < a_end; b0 += BS) {
+                const int nb = a_end - b0 < BS ? a_end - b0 : BS;
+                int2 e = make_int2(0, 0);
+                if ((int)threadIdx.x < nb) {
+                    const int c = acol[b0 + threadIdx.x];
+                    const int s = slot_of[c];
+                    if (s >= 0) {
+                        const int *tr = tab + (long long)s * tstride;
+                        e.x = tr[p_a];
+                        e.y = tr[p_b < tstride ? p_b : tstride - 1];
+                    } else {  // short row: whole, filtered below
+                        e.x = brpt[c];
+                        e.y = brpt[c + 1];
+                    }
+                }
+                const int nch = (e.y - e.x + V - 1) / V;
+                s_ext[threadIdx.x] = e;
+                const int incl = wave_incl_scan(nch);
+                if (lane == 63) fs.wsum[w] = incl;
+                __syncthreads();
+                int sbase = 0, total = 0;
+#pragma unroll
+                for (int u = 0; u < NW; u++) {
+                    const int c = fs.wsum[u];
+                    sbase += u < w ? c : 0;
+                    total += c;
+                }
+                fs.pref[threadIdx.x] = sbase + incl - nch;
+                __syncthreads();
+                for (int ch0 = threadIdx.x; ch0 < total; ch0 += BS * U) {
+                    IVecT<V> pk[U];
+                    RVecT<1> pv;
+                    int pn[U];
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+                        const int ch = ch0 + u * BS;
+                        pn[u] = 0;
+                        if (ch < total) {
+                            int i = 0;
+#pragma unroll
+                            for (int step = BS / 2; step >= 1; step >>= 1) {
+                                const int j = i + step;
+                                if (j < nb && fs.pref[j] <= ch) i = j;
+                            }
+                            const int2 x = s_ext[i];
+                            pn[u] = fetch_chunk<false, V>(bcol, (const real *)nullptr, x.x + (ch - fs.pref[i]) * V, x.y, bnnz, pk[u], pv);
+                            if (pn[u] > 0) {
+                                NSP_COUNT(FC_SYM_FLAT, 0, V);
+                                NSP_COUNT(FC_FLAT_EXTENT, 2, pn[u]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; u++) {
+#pragma unroll
+                        for (int i = 0; i < V; i++) {
+                            const unsigned int idx = (unsigned int)(pk[u].v[i] - t0);
+                            if (i < pn[u] && idx < (unsigned int)WG) {
+                                NSP_COUNT(FC_SYM_FLAT, 2, 1);
+                                atomicOr(&bits[idx >> 5], 1u << (idx & 31));
+                            }
+                        }
+                    }
+                }
+                __syncthreads();  // the next batch overwrites the parked entries
+            }
+            lds_barrier();
+            sym_cnt += bits_to_list<BS, true>(bits, NWORD, t0, listing ? tcol + s_off + sym_cnt : (int *)nullptr, s_wsum,
+                                              list_work == -2);
+        }
+        if (threadIdx.x == 0) row_nz_out[rid] = sym_cnt;  // nnz of the row = bits seen over all tiles (uniform)
+    }
+}
+
 }  // namespace spgemm
 }  // namespace nsp

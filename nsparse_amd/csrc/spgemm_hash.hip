@@ -49,7 +49,7 @@
 //   spgemm/block.h         k_num_block, k_twin_groups                     (numeric bins 6-9: node blocks)
 //   spgemm/heavy_tiled.h   k_num_tiled                                    (bin 5, dense tiles)
 //   spgemm/heavy_ranked.h  k_num_ranked                                   (bin 5, thin rows)
-//   spgemm/heavy_flat.h    k_panel_slots, k_panel_fill, k_num_flat, k_num_ranked_flat  (bin 5, stateless tiles; experiments build)
+//   spgemm/heavy_flat.h    k_panel_slots, k_panel_fill, k_num_flat, k_num_ranked_flat, k_sym_flat  (stateless tiles; experiments build)
 //   spgemm/lean.h          k_sym_lean, k_num_lean                         (hash bins 1-4 on an instruction diet, round 4)
 //
 // Results: C.rpt / C.col are bit-identical to the reference by construction (distinct
@@ -396,6 +396,53 @@ static void fold_small_hash_bins(const int *hist_in, int *hist, int *off)
     }
 }
 
+// Panel table of B for the stateless heavy-row kernels (heavy_flat.h; experiments build): built at most once per call by
+// the first phase that wants it -- the symbolic phase (k_sym_flat) or the numeric one -- on that phase's heavy-bin
+// stream, freed with the symbolic / numeric launcher's deferred scratch when the call has drained.  (One call at a time:
+// ApiLock.)
+struct PanelTable {
+    int *slot_of = nullptr, *tab = nullptr;
+    int np = 0;
+};
+static PanelTable g_panel;
+constexpr int kPanelW = 12288;  // = the dense tile width (numeric_phase: kTileW)
+
+static void build_panel_table(const sfCSR *b, BinLauncher &L, hipStream_t st)
+{
+    if constexpr (kExperiments) {
+        if (g_panel.tab != nullptr) return;
+        const int *brpt = b->d_rpt, *bcol = b->d_col;
+        const int np = (int)(((long long)b->N + kPanelW - 1) / kPanelW);
+        // every row of B in the table while that stays small next to B; else only rows of more than min_len entries,
+        // min_len from a worst-case budget of 1 GiB: at most nnz / (min_len + 1) rows are that long, and that bound
+        // sizes the table (no round trip to the host; the fill kernel touches only the rows that exist).  A row
+        // outside the table is walked whole by every tile of a C row and filtered by column: on R-MAT-22 at a fifth
+        // of config 5's edges min_len = 16 cost a third of the products again in such re-reads (tests/emu census).
+        const bool all_rows = (long long)b->M * (np + 1) * 4 <= (256LL << 20);
+        const long long per_row = (long long)(np + 1) * 4;
+        int min_len = all_rows ? -1 : (int)std::min<long long>(64, ((long long)b->nnz * per_row + (1LL << 30) - 1) / (1LL << 30) - 1);
+        if (!all_rows && min_len < 1) min_len = 1;
+        const long long slots_max = all_rows ? (long long)b->M : std::min<long long>(b->M, (long long)b->nnz / (min_len + 1) + 1);
+        // one block: [count, pad | slot_of: M | slot_row: slots_max | tab: slots_max * (np + 1)]
+        const size_t n_ints = 2 + (size_t)b->M + (size_t)slots_max + (size_t)slots_max * (np + 1) + 2;
+        int *blk = (int *)dev_alloc(sizeof(int) * n_ints);
+        int *d_cnt = blk, *slot_of = blk + 2, *slot_row = slot_of + b->M, *tab = slot_row + slots_max;
+        NSP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
+        if (all_rows)
+            hipLaunchKernelGGL(k_panel_slots<true>, dim3(ceil_div(b->M, 256)), dim3(256), 0, st, brpt, b->M, min_len,
+                               slot_of, slot_row, d_cnt, (int)slots_max);
+        else
+            hipLaunchKernelGGL(k_panel_slots<false>, dim3(ceil_div(b->M, 256)), dim3(256), 0, st, brpt, b->M, min_len,
+                               slot_of, slot_row, d_cnt, (int)slots_max);
+        const long long cells = slots_max * (np + 1);
+        hipLaunchKernelGGL(k_panel_fill<kPanelW>, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, brpt, bcol,
+                           (const int *)slot_row, (const int *)d_cnt, np, tab);
+        NSP_LAUNCH_CHECK();
+        L.free_later(blk);
+        g_panel.slot_of = slot_of, g_panel.tab = tab, g_panel.np = np;
+    }
+}
+
 static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod, const int *row_maxb,
                                   const int *row_lo,
                                   const int *row_span, int *row_nz, int *row_perm, const int *hist_in,
@@ -478,7 +525,26 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     // product seen once (k_sym_bits would walk all products once per 2^20-column piece)
     static const int sym_cursor_on = exp_env("NSPARSE_SYM_CURSOR", 1) != 0;
     static const int sym_long_len = exp_env("NSPARSE_SYM_LONG", 32);
-    if (hist[10] > 0 && now(10) && sym_cursor_on && b_sorted && max_span[10] > 32768 * 32 && max_alen > 0) {
+    // NSPARSE_HEAVY_FLAT bit 2 (experiments build): the same rows through the stateless symbolic kernel (heavy_flat.h)
+    static const int sym_flat = exp_env("NSPARSE_HEAVY_FLAT", 0) & 4;
+    bool sym_flat_done = false;
+    if constexpr (kExperiments) {
+        if (sym_flat && hist[10] > 0 && now(10) && sym_cursor_on && b_sorted && max_span[10] > 32768 * 32 && max_alen > 0) {
+            hipStream_t st = L.begin(10);
+            const int rows = hist[10];
+            const int groups = rows < 1024 ? rows : 1024;
+            build_panel_table(b, L, st);
+            hipLaunchKernelGGL((k_sym_flat<1024, 1048576, kPanelW>), dim3(groups), dim3(1024), 0, st, arpt, acol, brpt, bcol, b->nnz,
+                               (const int *)g_panel.slot_of, (const int *)g_panel.tab, g_panel.np + 1, row_perm, off[10], rows, d_bs,
+                               row_lo, row_span, row_nz, tcol, list_off, exp_env("NSPARSE_LIST_DRY", 0) ? -2LL : -1LL,
+                               (const int *)row_prod);
+            NSP_LAUNCH_CHECK();
+            L.end(10);
+            sym_flat_done = true;
+        }
+    }
+    if (sym_flat_done) {
+    } else if (hist[10] > 0 && now(10) && sym_cursor_on && b_sorted && max_span[10] > 32768 * 32 && max_alen > 0) {
         hipStream_t st = L.begin(10);
         const int rows = hist[10];
         const int amax = (max_alen + 1) & ~1;
@@ -643,42 +709,18 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                        list_off, list_w, row_prod)
         // NSPARSE_HEAVY_FLAT=1 (experiments build, until it has been timed on the device): the dense tiles as
         // stateless flat walks over a panel table of B (heavy_flat.h) instead of the cursor kernel
-        static const int heavy_flat = exp_env("NSPARSE_HEAVY_FLAT", 0);  // bit 0: dense tiles, bit 1: list-driven ranked tiles
+        static const int heavy_flat = exp_env("NSPARSE_HEAVY_FLAT", 0);  // bit 0: dense tiles, bit 1: list-driven ranked tiles, bit 2: symbolic
         bool flat_done = false;
         int *pt_slot_of = nullptr, *pt_tab = nullptr;
         int pt_np = 0;
         if constexpr (kExperiments) {
-            if (heavy_flat) {
-                const int np = (int)(((long long)b->N + kTileW - 1) / kTileW);
-                // every row of B in the table while that stays small next to B; else only rows of more than min_len entries,
-                // min_len from a worst-case budget of 1 GiB: at most nnz / (min_len + 1) rows are that long, and that bound
-                // sizes the table (no round trip to the host; the fill kernel touches only the rows that exist).  A row
-                // outside the table is walked whole by every tile of a C row and filtered by column: on R-MAT-22 at a fifth
-                // of config 5's edges min_len = 16 cost a third of the products again in such re-reads (tests/emu census).
-                const bool all_rows = (long long)b->M * (np + 1) * 4 <= (256LL << 20);
-                const long long per_row = (long long)(np + 1) * 4;
-                int min_len = all_rows ? -1 : (int)std::min<long long>(64, ((long long)b->nnz * per_row + (1LL << 30) - 1) / (1LL << 30) - 1);
-                if (!all_rows && min_len < 1) min_len = 1;
-                const long long slots_max = all_rows ? (long long)b->M : std::min<long long>(b->M, (long long)b->nnz / (min_len + 1) + 1);
-                // one block: [count, pad | slot_of: M | slot_row: slots_max | tab: slots_max * (np + 1)]
-                const size_t n_ints = 2 + (size_t)b->M + (size_t)slots_max + (size_t)slots_max * (np + 1) + 2;
-                int *blk = (int *)dev_alloc(sizeof(int) * n_ints);
-                int *d_cnt = blk, *slot_of = blk + 2, *slot_row = slot_of + b->M, *tab = slot_row + slots_max;
-                NSP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
-                if (all_rows)
-                    hipLaunchKernelGGL(k_panel_slots<true>, dim3(ceil_div(b->M, 256)), dim3(256), 0, st, brpt, b->M, min_len,
-                                       slot_of, slot_row, d_cnt, (int)slots_max);
-                else
-                    hipLaunchKernelGGL(k_panel_slots<false>, dim3(ceil_div(b->M, 256)), dim3(256), 0, st, brpt, b->M, min_len,
-                                       slot_of, slot_row, d_cnt, (int)slots_max);
-                const long long cells = slots_max * (np + 1);
-                hipLaunchKernelGGL(k_panel_fill<kTileW>, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, brpt, bcol,
-                                   (const int *)slot_row, (const int *)d_cnt, np, tab);
-                L.free_later(blk);
-                pt_slot_of = slot_of, pt_tab = tab, pt_np = np;
+            if (heavy_flat & 3) {
+                static_assert(kPanelW == kTileW, "a dense tile is one panel of the table");
+                build_panel_table(b, L, st);  // (the symbolic phase may have built it already)
+                pt_slot_of = g_panel.slot_of, pt_tab = g_panel.tab, pt_np = g_panel.np;
                 if ((heavy_flat & 1) && ranked_dens >= 0 && tile_sel == 0) {
                     hipLaunchKernelGGL((k_num_flat<1024, kTileW>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval, brpt, bcol,
-                                       bval, b->nnz, (const int *)slot_of, (const int *)tab, np + 1, c->d_rpt, c->d_col, c->d_val,
+                                       bval, b->nnz, (const int *)pt_slot_of, (const int *)pt_tab, pt_np + 1, c->d_rpt, c->d_col, c->d_val,
                                        row_perm, off[kNumGlobalBin], rows, d_bs, row_lo, row_span, write_col, ranked_dens,
                                        list_off, list_w, row_prod);
                     flat_done = true;
@@ -1058,6 +1100,7 @@ static int census_coresident(Context &cx, hipStream_t st)
 static bool run_once(sfCSR *a_in, sfCSR *b_in, sfCSR *c, bool numeric_only)
 {
     Context &cx = ctx();
+    g_panel = PanelTable{};  // (whatever the last call built went back to the block cache with its launcher)
     sfCSR a_chk = with_checked_hint(a_in), b_chk = with_checked_hint(b_in);
     const sfCSR *a = &a_chk, *b = &b_chk;
     if (a->M <= 0 || a->nnz <= 0 || b->nnz <= 0 || b->M <= 0) {

@@ -19,11 +19,12 @@ def assert_parity(orc, got, ref):
 
 
 def flat(A, B=None, prec="d", numeric_again=False, **env):
-    """NSPARSE_HEAVY_FLAT=3: dense tiles (bit 0) and list-driven ranked tiles (bit 1) both stateless."""
+    """NSPARSE_HEAVY_FLAT=7: dense tiles (bit 0), list-driven ranked tiles (bit 1) and the symbolic twin for windows wider
+    than 2^20 columns (bit 2), all stateless."""
     d = experiments_lib_dir()
     if d is None:
         pytest.skip("no experiments variant library beside the one in use (__graft_entry__.build() makes lib_exp)")
-    got, st = spgemm_subprocess(A, dict(dict(NSPARSE_LIB_DIR=d, NSPARSE_HEAVY_FLAT="3"), **env), prec=prec, B=B,
+    got, st = spgemm_subprocess(A, dict(dict(NSPARSE_LIB_DIR=d, NSPARSE_HEAVY_FLAT="7"), **env), prec=prec, B=B,
                                 numeric_again=numeric_again)
     assert st["build"].split()[-1] == "experiments", st["build"]
     return got, st
@@ -106,8 +107,9 @@ def test_short_rows_outside_the_table(oracle_d):
 
 
 def test_window_wider_than_the_bitmap_with_lists(oracle_d):
-    """3 M columns (symbolic cursor kernel, column lists on): every heavy row is thin and has a list, so all of them take
-    k_num_ranked_flat; tiles start at the panel of the next listed column and end at panel boundaries."""
+    """3 M columns: the symbolic phase through k_sym_flat (three tiles of 85 panels per row, column lists written), then
+    every heavy row -- thin, with a list -- through k_num_ranked_flat; tiles start at the panel of the next listed column
+    and end at panel boundaries.  Also with the cursor kernel in ONE of the two phases (bits 2 / 3 alone)."""
     import scipy.sparse as sp
     rng = np.random.default_rng(77)
     m, k, n = 48, 3000, 3_000_000
@@ -117,10 +119,13 @@ def test_window_wider_than_the_bitmap_with_lists(oracle_d):
     ref = oracle_d.spgemm(A, B)
     assert ref["row_nz"].min() > 8192
     got, st = flat(A, B, numeric_again=True)
-    assert st["num"][5] == m
+    assert st["num"][5] == m and st["sym"][10] == m
     assert_parity(oracle_d, got, ref)
     assert np.array_equal(got["col_again"], got["col"])
     np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9)
+    for bits in ("4", "3"):  # stateless symbolic + cursor numeric, and the other way round: the lists are interchangeable
+        g, _ = flat(A, B, NSPARSE_HEAVY_FLAT=bits)
+        assert_parity(oracle_d, g, ref)
 
 
 @pytest.mark.parametrize("dens", ["-1", "12"])

@@ -7,9 +7,10 @@
 #   lean_bf        NSPARSE_TB_LEAN=7      ... with branch-free retry rounds
 #   lean_pipe      NSPARSE_TB_LEAN=11     ... with the pipelined walk
 #   lean_bfpipe    NSPARSE_TB_LEAN=15     ... with both
-#   flat           NSPARSE_HEAVY_FLAT=3   stateless heavy-row tiles over the panel table (heavy_flat.h), dense + ranked
+#   flat           NSPARSE_HEAVY_FLAT=7   stateless heavy-row tiles over the panel table (heavy_flat.h): dense + ranked + symbolic
 #   flat_dense     NSPARSE_HEAVY_FLAT=1   only the dense tiles
 #   flat_ranked    NSPARSE_HEAVY_FLAT=2   only the list-driven ranked tiles
+#   flat_sym       NSPARSE_HEAVY_FLAT=4   only the symbolic twin (windows wider than 2^20 columns)
 #   bash tools/ab_variants.sh [case ...]      cases of tools/one_call_cfg.py (default: stencil webbase1m rmat18 rmat22)
 out=gpurun_out/ab_variants.log; : > $out
 EXP=$PWD/nsparse_amd/lib_exp
@@ -22,7 +23,7 @@ run() {  # <case> <label> <env...>
 for c in ${@:-stencil webbase1m rmat18 rmat22}; do
   run $c default NSPARSE_TB_LEAN=0
   case $c in
-    rmat*) run $c flat NSPARSE_HEAVY_FLAT=3; run $c flat_dense NSPARSE_HEAVY_FLAT=1; run $c flat_ranked NSPARSE_HEAVY_FLAT=2 ;;
+    rmat*) run $c flat NSPARSE_HEAVY_FLAT=7; run $c flat_dense NSPARSE_HEAVY_FLAT=1; run $c flat_ranked NSPARSE_HEAVY_FLAT=2; run $c flat_sym NSPARSE_HEAVY_FLAT=4 ;;
   esac
   run $c lean NSPARSE_TB_LEAN=3
   run $c lean_bf NSPARSE_TB_LEAN=7

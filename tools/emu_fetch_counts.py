@@ -27,8 +27,8 @@ import nsparse_amd as ns  # noqa: E402
 from gpu_util import spgemm, synth  # noqa: E402
 from oracle.oracle import Oracle  # noqa: E402
 
-FAMILIES = {0: "k_num_tiled", 1: "k_num_ranked", 2: "k_num_ranked<SYM>", 3: "k_num_flat", 4: "walk_products", 5: "k_num_ranked_flat"}
-IN_EXTENT = {3: 0, 5: 1}  # family -> slot of family 6 holding "entries loaded that lie inside their extent"
+FAMILIES = {0: "k_num_tiled", 1: "k_num_ranked", 2: "k_num_ranked<SYM>", 3: "k_num_flat", 4: "walk_products", 5: "k_num_ranked_flat", 7: "k_sym_flat"}
+IN_EXTENT = {3: 0, 5: 1, 7: 2}  # family -> slot of family 6 holding "entries loaded that lie inside their extent"
 
 
 def cases(lib):
