@@ -73,6 +73,29 @@ __global__ __launch_bounds__(256) void k_panel_fill(const int *__restrict__ brpt
     tab[i] = lo;
 }
 
+// ---- where the extents of an A entry are found --------------------------------------------------------------------------
+// The entries of a heavy row of A do not change from tile to tile, only the panel does.  `where` >= 0: the entry's B row
+// has a table row starting at tab + where (slot * stride: the table is at most 2^28 ints); `where` < 0: a short row
+// outside the table, ~where is the B row and its extent is the whole row (filtered by column later); kNoEntry: this
+// thread holds no entry of the batch.  The first kFlatEpt batches of BS entries keep (where, A value) in registers across
+// the tile loop, so that a tile starts with ONE gather -- the extents -- instead of the chain A.col -> slot -> extents;
+// further batches (rows of A with more than kFlatEpt * BS entries) walk the chain again for every tile.
+constexpr int kNoEntry = (int)0x80000000;
+constexpr int kFlatEpt = 2;
+__device__ __forceinline__ int flat_where(const int *__restrict__ acol, const int *__restrict__ slot_of, int tstride, int j)
+{
+    const int c = acol[j];
+    const int s = slot_of[c];
+    return s >= 0 ? s * tstride : ~c;
+}
+__device__ __forceinline__ int2 flat_extent(const int *__restrict__ brpt, const int *__restrict__ tab, int where, int p_a, int p_b)
+{
+    if (where == kNoEntry) return make_int2(0, 0);
+    if (where >= 0) return make_int2(tab[where + p_a], tab[where + p_b]);
+    const int c = ~where;
+    return make_int2(brpt[c], brpt[c + 1]);
+}
+
 // ===================================================================================
 //  heavy numeric rows: dense column tiles = panels of the table, one flat walk each
 // ===================================================================================
@@ -105,9 +128,6 @@ __global__ __launch_bounds__(BS) void k_num_flat(const int *__restrict__ arpt, c
     __shared__ int s_wcnt[NW];
     unsigned char *flag = reinterpret_cast<unsigned char *>(flag4);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    struct __attribute__((aligned(4))) I2 {
-        int b, e;
-    };
     // The window is clean on entry to every tile: cleared here once, the emission resets what it finds occupied.
     for (int i = threadIdx.x; i < W; i += BS) dense[i] = 0;
     for (int i = threadIdx.x; i < W / 4; i += BS) flag4[i] = 0;
@@ -127,24 +147,37 @@ __global__ __launch_bounds__(BS) void k_num_flat(const int *__restrict__ arpt, c
         const int a_beg = arpt[rid], a_end = arpt[rid + 1];
         const int p_lo = lo / W, p_hi = (int)(((long long)lo + span - 1) / W);
         int pos = crpt[rid];
+        int e_where[kFlatEpt];
+        real e_av[kFlatEpt];
+#pragma unroll
+        for (int u = 0; u < kFlatEpt; u++) {
+            const int j = a_beg + u * BS + (int)threadIdx.x;
+            e_where[u] = kNoEntry;
+            e_av[u] = 0;
+            if (j < a_end) {
+                e_where[u] = flat_where(acol, slot_of, tstride, j);
+                e_av[u] = aval[j];
+            }
+        }
         for (int p = p_lo; p <= p_hi; p++) {
             const int c0 = p * W;
             if (threadIdx.x == 0) NSP_COUNT(FC_FLAT, 3, 1);
             // ---- one flat walk of the products of this tile ----------------------------------------------------
-            for (int b0 = a_beg; b0 < a_end; b0 += BS) {
+            int kb = 0;
+            for (int b0 = a_beg; b0 < a_end; b0 += BS, kb++) {
                 const int nb = a_end - b0 < BS ? a_end - b0 : BS;
-                int2 e = make_int2(0, 0);
-                real av = 0;
-                if ((int)threadIdx.x < nb) {
-                    const int j = b0 + threadIdx.x;
-                    const int c = acol[j];  // (read again by every tile of the row: cacheable, not nontemporal)
-                    av = aval[j];
-                    const int s = slot_of[c];
-                    const I2 r = s >= 0 ? *reinterpret_cast<const I2 *>(tab + (long long)s * tstride + p)
-                                        : *reinterpret_cast<const I2 *>(brpt + c);  // short row: whole, filtered below
-                    e.x = r.b;
-                    e.y = r.e;
+                int where = kb == 0 ? e_where[0] : e_where[kFlatEpt - 1];
+                real av = kb == 0 ? e_av[0] : e_av[kFlatEpt - 1];
+                static_assert(kFlatEpt == 2, "two batches in registers");
+                if (kb >= kFlatEpt) {  // (uniform) beyond the register batches: the chain again, cacheable loads
+                    where = kNoEntry;
+                    av = 0;
+                    if ((int)threadIdx.x < nb) {
+                        where = flat_where(acol, slot_of, tstride, b0 + (int)threadIdx.x);
+                        av = aval[b0 + threadIdx.x];
+                    }
                 }
+                const int2 e = flat_extent(brpt, tab, where, p, p + 1);  // (short rows: whole, filtered below)
                 const int nch = (e.y - e.x + V - 1) / V;
                 s_ext[threadIdx.x] = e;
                 s_av[threadIdx.x] = av;
@@ -309,6 +342,18 @@ __global__ __launch_bounds__(BS) void k_num_ranked_flat(const int *__restrict__ 
         }
         if (rlist == nullptr) continue;  // k_num_ranked's row
         const int a_beg = arpt[rid], a_end = arpt[rid + 1];
+        int e_where[kFlatEpt];
+        real e_av[kFlatEpt];
+#pragma unroll
+        for (int u = 0; u < kFlatEpt; u++) {
+            const int j = a_beg + u * BS + (int)threadIdx.x;
+            e_where[u] = kNoEntry;
+            e_av[u] = 0;
+            if (j < a_end) {
+                e_where[u] = flat_where(acol, slot_of, tstride, j);
+                e_av[u] = aval[j];
+            }
+        }
         int k0 = 0;
         while (k0 < row_nnz) {
             if (threadIdx.x == 0) NSP_COUNT(FC_RANKED_FLAT, 3, 1);
@@ -340,24 +385,21 @@ __global__ __launch_bounds__(BS) void k_num_ranked_flat(const int *__restrict__ 
             const int ntile = s_ntile;
             const int p_a = base / G, p_b = (int)(((long long)hi + G - 1) / G);
             // ---- one flat walk of the products inside [first, hi) --------------------------------------------------
-            for (int b0 = a_beg; b0 < a_end; b0 += BS) {
+            const int p_bc = p_b < tstride ? p_b : tstride - 1;
+            int kb = 0;
+            for (int b0 = a_beg; b0 < a_end; b0 += BS, kb++) {
                 const int nb = a_end - b0 < BS ? a_end - b0 : BS;
-                int2 e = make_int2(0, 0);
-                real av = 0;
-                if ((int)threadIdx.x < nb) {
-                    const int j = b0 + threadIdx.x;
-                    const int c = acol[j];
-                    av = aval[j];
-                    const int s = slot_of[c];
-                    if (s >= 0) {
-                        const int *t = tab + (long long)s * tstride;
-                        e.x = t[p_a];
-                        e.y = t[p_b < tstride ? p_b : tstride - 1];
-                    } else {  // short row: whole, filtered below
-                        e.x = brpt[c];
-                        e.y = brpt[c + 1];
+                int where = kb == 0 ? e_where[0] : e_where[kFlatEpt - 1];
+                real av = kb == 0 ? e_av[0] : e_av[kFlatEpt - 1];
+                if (kb >= kFlatEpt) {  // (uniform) beyond the register batches
+                    where = kNoEntry;
+                    av = 0;
+                    if ((int)threadIdx.x < nb) {
+                        where = flat_where(acol, slot_of, tstride, b0 + (int)threadIdx.x);
+                        av = aval[b0 + threadIdx.x];
                     }
                 }
+                const int2 e = flat_extent(brpt, tab, where, p_a, p_bc);  // (short rows: whole, filtered below)
                 const int nch = (e.y - e.x + V - 1) / V;
                 s_ext[threadIdx.x] = e;
                 s_av[threadIdx.x] = av;
@@ -490,25 +532,24 @@ __global__ __launch_bounds__(BS) void k_sym_flat(const int *__restrict__ arpt, c
         const int a_beg = arpt[rid], a_end = arpt[rid + 1];
         const long long row_end = (long long)lo + span;
         int sym_cnt = 0;
+        int e_where[kFlatEpt];
+#pragma unroll
+        for (int u = 0; u < kFlatEpt; u++) {
+            const int j = a_beg + u * BS + (int)threadIdx.x;
+            e_where[u] = j < a_end ? flat_where(acol, slot_of, tstride, j) : kNoEntry;
+        }
         for (long long t = (long long)(lo / G) * G; t < row_end; t += WG) {
             const int t0 = (int)t;
             const int p_a = t0 / G, p_b = p_a + W / G;
             if (threadIdx.x == 0) NSP_COUNT(FC_SYM_FLAT, 3, 1);
-            for (int b0 = a_beg; b0 < a_end; b0 += BS) {
+            const int p_bc = p_b < tstride ? p_b : tstride - 1;
+            int kb = 0;
+            for (int b0 = a_beg; b0 < a_end; b0 += BS, kb++) {
                 const int nb = a_end - b0 < BS ? a_end - b0 : BS;
-                int2 e = make_int2(0, 0);
-                if ((int)threadIdx.x < nb) {
-                    const int c = acol[b0 + threadIdx.x];
-                    const int s = slot_of[c];
-                    if (s >= 0) {
-                        const int *tr = tab + (long long)s * tstride;
-                        e.x = tr[p_a];
-                        e.y = tr[p_b < tstride ? p_b : tstride - 1];
-                    } else {  // short row: whole, filtered below
-                        e.x = brpt[c];
-                        e.y = brpt[c + 1];
-                    }
-                }
+                int where = kb == 0 ? e_where[0] : e_where[kFlatEpt - 1];
+                if (kb >= kFlatEpt)  // (uniform) beyond the register batches
+                    where = (int)threadIdx.x < nb ? flat_where(acol, slot_of, tstride, b0 + (int)threadIdx.x) : kNoEntry;
+                const int2 e = flat_extent(brpt, tab, where, p_a, p_bc);  // (short rows: whole, filtered below)
                 const int nch = (e.y - e.x + V - 1) / V;
                 s_ext[threadIdx.x] = e;
                 const int incl = wave_incl_scan(nch);

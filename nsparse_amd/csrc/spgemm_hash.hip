@@ -407,22 +407,40 @@ struct PanelTable {
 static PanelTable g_panel;
 constexpr int kPanelW = 12288;  // = the dense tile width (numeric_phase: kTileW)
 
+// table geometry: panels, the shortest row that gets a table row (-1: every row), upper bound of the table rows
+static void panel_table_shape(const sfCSR *b, int &np, int &min_len, long long &slots_max)
+{
+    np = (int)(((long long)b->N + kPanelW - 1) / kPanelW);
+    // every row of B in the table while that stays small next to B; else only rows of more than min_len entries,
+    // min_len from a worst-case budget of 1 GiB: at most nnz / (min_len + 1) rows are that long, and that bound
+    // sizes the table (no round trip to the host; the fill kernel touches only the rows that exist).  A row
+    // outside the table is walked whole by every tile of a C row and filtered by column: on R-MAT-22 at a fifth
+    // of config 5's edges min_len = 16 cost a third of the products again in such re-reads (tests/emu census).
+    const bool all_rows = (long long)b->M * (np + 1) * 4 <= (256LL << 20);
+    const long long per_row = (long long)(np + 1) * 4;
+    min_len = all_rows ? -1 : (int)std::min<long long>(64, ((long long)b->nnz * per_row + (1LL << 30) - 1) / (1LL << 30) - 1);
+    if (!all_rows && min_len < 1) min_len = 1;
+    slots_max = all_rows ? (long long)b->M : std::min<long long>(b->M, (long long)b->nnz / (min_len + 1) + 1);
+}
+// (the kernels address a table row as an int offset: 2^26 ints with every row in, 2^28 under the 1 GiB budget)
+static bool panel_table_fits(const sfCSR *b)
+{
+    int np, min_len;
+    long long slots_max;
+    panel_table_shape(b, np, min_len, slots_max);
+    return slots_max * (np + 1) <= 0x7fffffffLL;
+}
+
 static void build_panel_table(const sfCSR *b, BinLauncher &L, hipStream_t st)
 {
     if constexpr (kExperiments) {
         if (g_panel.tab != nullptr) return;
         const int *brpt = b->d_rpt, *bcol = b->d_col;
-        const int np = (int)(((long long)b->N + kPanelW - 1) / kPanelW);
-        // every row of B in the table while that stays small next to B; else only rows of more than min_len entries,
-        // min_len from a worst-case budget of 1 GiB: at most nnz / (min_len + 1) rows are that long, and that bound
-        // sizes the table (no round trip to the host; the fill kernel touches only the rows that exist).  A row
-        // outside the table is walked whole by every tile of a C row and filtered by column: on R-MAT-22 at a fifth
-        // of config 5's edges min_len = 16 cost a third of the products again in such re-reads (tests/emu census).
-        const bool all_rows = (long long)b->M * (np + 1) * 4 <= (256LL << 20);
-        const long long per_row = (long long)(np + 1) * 4;
-        int min_len = all_rows ? -1 : (int)std::min<long long>(64, ((long long)b->nnz * per_row + (1LL << 30) - 1) / (1LL << 30) - 1);
-        if (!all_rows && min_len < 1) min_len = 1;
-        const long long slots_max = all_rows ? (long long)b->M : std::min<long long>(b->M, (long long)b->nnz / (min_len + 1) + 1);
+        if (!panel_table_fits(b)) return;  // no table: the callers keep the cursor kernels
+        int np, min_len;
+        long long slots_max;
+        panel_table_shape(b, np, min_len, slots_max);
+        const bool all_rows = min_len < 0;
         // one block: [count, pad | slot_of: M | slot_row: slots_max | tab: slots_max * (np + 1)]
         const size_t n_ints = 2 + (size_t)b->M + (size_t)slots_max + (size_t)slots_max * (np + 1) + 2;
         int *blk = (int *)dev_alloc(sizeof(int) * n_ints);
@@ -529,7 +547,8 @@ static BinLauncher symbolic_phase(const sfCSR *a, const sfCSR *b, int *row_prod,
     static const int sym_flat = exp_env("NSPARSE_HEAVY_FLAT", 0) & 4;
     bool sym_flat_done = false;
     if constexpr (kExperiments) {
-        if (sym_flat && hist[10] > 0 && now(10) && sym_cursor_on && b_sorted && max_span[10] > 32768 * 32 && max_alen > 0) {
+        if (sym_flat && panel_table_fits(b) && hist[10] > 0 && now(10) && sym_cursor_on && b_sorted && max_span[10] > 32768 * 32 &&
+            max_alen > 0) {
             hipStream_t st = L.begin(10);
             const int rows = hist[10];
             const int groups = rows < 1024 ? rows : 1024;
@@ -718,7 +737,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                 static_assert(kPanelW == kTileW, "a dense tile is one panel of the table");
                 build_panel_table(b, L, st);  // (the symbolic phase may have built it already)
                 pt_slot_of = g_panel.slot_of, pt_tab = g_panel.tab, pt_np = g_panel.np;
-                if ((heavy_flat & 1) && ranked_dens >= 0 && tile_sel == 0) {
+                if ((heavy_flat & 1) && pt_tab != nullptr && ranked_dens >= 0 && tile_sel == 0) {
                     hipLaunchKernelGGL((k_num_flat<1024, kTileW>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval, brpt, bcol,
                                        bval, b->nnz, (const int *)pt_slot_of, (const int *)pt_tab, pt_np + 1, c->d_rpt, c->d_col, c->d_val,
                                        row_perm, off[kNumGlobalBin], rows, d_bs, row_lo, row_span, write_col, ranked_dens,

@@ -105,7 +105,7 @@ def test_random_products_on_the_emulation(emu_lib):
     n = _gpu_tests_on_emu(emu_lib, ["tests/test_fuzz_gpu.py"],
                           env={"NSPARSE_FUZZ_SEEDS": "10", "NSPARSE_FUZZ_SQ_SEEDS": "6", "NSPARSE_FUZZ_AB_SEEDS": "4",
                                "NSPARSE_FUZZ_AMB_SEEDS": "8"})
-    assert n == 28
+    assert n == 32  # 10 + 6 + 4 + 8 random cases and the four bricks with 2 / 6 unknowns per node
 
 
 def test_both_hash_kernel_families_on_the_emulation(emu_lib):

@@ -111,6 +111,48 @@ def test_random_node_block_squares(seed, lib_d, oracle_d, lib_s, oracle_s):
     assert sum(st.sym_bin_size) + st.twin_rows == A["M"] and sum(st.num_bin_size) == A["M"]
 
 
+@pytest.mark.parametrize("shuffled", [False, True])
+@pytest.mark.parametrize("d", [2, 6])
+def test_bricks_with_two_and_six_unknowns_per_node(d, shuffled, lib_d, oracle_d):
+    """A 27-point brick of 5 x 5 x 12 nodes with d = 2 and d = 6 unknowns per node (the cant-class stand-in has 3): twin
+    classes of d rows.  The node-block numeric kernel works on groups of at most THREE rows (a leader and its lowest
+    and highest follower), so a class of 2 is one short group and a class of 6 is split -- whatever the split, all
+    but one row of every node must be found as twins, and C must be the oracle's, with the natural numbering and with
+    the unknowns shuffled inside bands (no twin is a neighbour then: keyed runs)."""
+    nx, ny, nz = 5, 5, 12
+    idx = np.arange(nx * ny * nz).reshape(nx, ny, nz)
+    rows, cols = [], []
+    for dx in (-1, 0, 1):
+        for dy in (-1, 0, 1):
+            for dz in (-1, 0, 1):
+                a = idx[max(0, -dx):nx - max(0, dx), max(0, -dy):ny - max(0, dy), max(0, -dz):nz - max(0, dz)]
+                b = idx[max(0, dx):nx - max(0, -dx), max(0, dy):ny - max(0, -dy), max(0, dz):nz - max(0, -dz)]
+                rows.append(a.ravel())
+                cols.append(b.ravel())
+    g = sp.csr_matrix((np.ones(sum(len(r) for r in rows)), (np.concatenate(rows), np.concatenate(cols))),
+                      shape=(idx.size, idx.size))
+    a = sp.kron(g, np.ones((d, d)), format="csr")
+    n = a.shape[0]
+    rng = np.random.default_rng(600 + d)
+    if shuffled:
+        perm = np.arange(n)
+        band = 9 * d
+        for s0 in range(0, n, band):
+            perm[s0:s0 + band] = s0 + rng.permutation(min(band, n - s0))
+        a = a[perm][:, perm].tocsr()
+    a.sort_indices()
+    a.data = rng.random(a.data.size) + 0.1
+    A = dict(M=n, N=n, rpt=a.indptr.astype(np.int32), col=a.indices.astype(np.int32), val=a.data.astype(np.float64))
+    ref = oracle_d.spgemm(A, A)
+    got, st = spgemm(lib_d, A, numeric_again=True)
+    assert np.array_equal(got["rpt"], ref["rpt"]) and np.array_equal(got["col"], ref["col"])
+    assert oracle_d.check_spgemm(got, ref) == 0
+    assert np.array_equal(got["col_again"], got["col"])
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9)
+    assert st.twin_rows == n - n // d, (st.twin_rows, n, d)
+    assert sum(st.sym_bin_size) + st.twin_rows == n and sum(st.num_bin_size) == n
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("NSPARSE_FUZZ_AB_SEEDS", "16"))))
 def test_random_node_block_products_with_another_b(seed, lib_d, oracle_d, lib_s, oracle_s):
     """A * B on node-block matrices with B != A: a row block of A times the whole A (what a rank of the partitioned
