@@ -17,8 +17,11 @@ SRC = r'''
 #include "spgemm/common.h"
 #include "spgemm/lean.h"
 namespace nsp { namespace spgemm {
-#define NUM(BS, T, U) template __global__ void k_num_lean<BS, T, U>(const int *, const int *, const real *, const int *, const int *, const real *, const int *, int *, real *, const int *, const int *, const int *, int, int, int, int);
-#define SYM(BS, T, U) template __global__ void k_sym_lean<BS, T, U>(const int *, const int *, const int *, const int *, const int *, const int *, const int *, int *, int, int, int, BinState *, int *, long long *, const int *, int, int);
+#define NUM1(BS, T, U, F) template __global__ void k_num_lean<BS, T, U, F>(const int *, const int *, const real *, const int *, const int *, const real *, const int *, int *, real *, const int *, const int *, const int *, int, int, int, int);
+#define SYM1(BS, T, U, F) template __global__ void k_sym_lean<BS, T, U, F>(const int *, const int *, const int *, const int *, const int *, const int *, const int *, int *, int, int, int, BinState *, int *, long long *, const int *, int, int);
+// all four forms (FORM bit 0: branch-free retry rounds, bit 1: pipelined walk): they share the inline-asm sorts
+#define NUM(BS, T, U) NUM1(BS, T, U, 0) NUM1(BS, T, U, 1) NUM1(BS, T, U, 2) NUM1(BS, T, U, 3)
+#define SYM(BS, T, U) SYM1(BS, T, U, 0) SYM1(BS, T, U, 1) SYM1(BS, T, U, 2) SYM1(BS, T, U, 3)
 NUM(64, 256, 2) NUM(256, 1024, 2) NUM(512, 4096, 4) NUM(1024, 8192, 4)
 SYM(64, 1024, 2) SYM(128, 2048, 2) SYM(512, 8192, 4) SYM(1024, 32768, 4)
 }}
@@ -91,7 +94,7 @@ def main():
         h, d = scan(open(asm).read())
         total_h += h
         total_d += d
-    print(f"dpp_hazard_scan: {total_d} DPP instructions in the lean kernels (8 instantiations x 2 precisions), {len(total_h)} hazards")
+    print(f"dpp_hazard_scan: {total_d} DPP instructions in the lean kernels (8 kernels x 4 forms x 2 precisions), {len(total_h)} hazards")
     for k, w, r, ws in total_h[:20]:
         print(f"  {k}: `{w}` then `{r}` after {ws} wait state(s)")
     return 1 if total_h else 0
