@@ -23,7 +23,8 @@ constexpr bool kExperiments = false;
 // FC_* below; what = 0 B.col loads, 1 B.val loads, 2 products, 3 tiles).  The product build compiles it away.
 enum { FC_TILED = 0, FC_RANKED = 1, FC_RANKED_SYM = 2, FC_FLAT = 3, FC_WALK = 4, FC_RANKED_FLAT = 5,
        FC_FLAT_EXTENT = 6 /* what 0 / 1 / 2: entries inside their extent, k_num_flat / k_num_ranked_flat / k_sym_flat */,
-       FC_SYM_FLAT = 7 };
+       FC_SYM_FLAT = 7,
+       FC_HASH_TB = 8, FC_HASH_LEAN = 9 /* what 0: keys handed to find-or-insert, 1: CAS probes issued, 2: keys that needed a retry */ };
 #ifdef NSP_EMU
 extern "C" void nsp_emu_count(int family, int what, long long n);
 #define NSP_COUNT(family, what, n) nsp_emu_count((family), (what), (long long)(n))
@@ -190,8 +191,10 @@ __device__ __forceinline__ int lds_load(const int *p)
 __device__ __forceinline__ int ht_find_or_insert(int *tab, int mask, int key, int *fresh)
 {
     int h = hash_slot(key, mask);
+    NSP_COUNT(FC_HASH_TB, 0, 1);
     while (true) {
         const int old = atomicCAS(tab + h, -1, key);
+        NSP_COUNT(FC_HASH_TB, 1, 1);
         if (old == -1 || old == key) {
             *fresh = old == -1;
             return h;
@@ -574,10 +577,13 @@ __device__ __forceinline__ void ht_insert_vec(int *tab, int mask, const IVecT<V>
     // collisions of all V elements are resolved in ONE loop (its exit test is the only branch: V
     // separate probe loops cost V exec-mask save / restore sequences per step even when nothing collides)
     bool pend[V], any = false;
+    NSP_COUNT(FC_HASH_TB, 0, n);
+    NSP_COUNT(FC_HASH_TB, 1, n);
 #pragma unroll
     for (int i = 0; i < V; i++) {
         pend[i] = old[i] != -1 && old[i] != k.v[i];
         any |= pend[i];
+        if (pend[i]) NSP_COUNT(FC_HASH_TB, 2, 1);
     }
     while (any) {
         any = false;
@@ -585,6 +591,7 @@ __device__ __forceinline__ void ht_insert_vec(int *tab, int mask, const IVecT<V>
         for (int i = 0; i < V; i++) {
             if (pend[i]) {
                 h[i] = (h[i] + 1) & mask;
+                NSP_COUNT(FC_HASH_TB, 1, 1);
                 old[i] = atomicCAS(tab + h[i], -1, k.v[i]);
                 pend[i] = old[i] != -1 && old[i] != k.v[i];
                 any |= pend[i];

@@ -278,11 +278,14 @@ __device__ __forceinline__ void lean_insert4(int *tab, int mask, int shift, int 
 #pragma unroll
     for (int i = 0; i < VW; i++) old[i] = atomicCAS(tab + h[i], -1, kk[i]);
     bool pend[VW], any = false;
+    NSP_COUNT(FC_HASH_LEAN, 0, n);
+    NSP_COUNT(FC_HASH_LEAN, 1, VW);  // (elements n .. 3 of a partial chunk are copies of element 0: their CAS is issued too)
 #pragma unroll
     for (int i = 0; i < VW; i++) {
         fresh += old[i] == -1;
         pend[i] = old[i] != -1 && old[i] != kk[i];
         any |= pend[i];
+        if (pend[i] && i < n) NSP_COUNT(FC_HASH_LEAN, 2, 1);
     }
     // (the retries: a block per key that only the lanes still probing that key enter -- five vector instructions per
     //  executed block.  A branch-free retry round over all four keys was measured: 36 VALU per round whether one lane
@@ -293,6 +296,7 @@ __device__ __forceinline__ void lean_insert4(int *tab, int mask, int shift, int 
         for (int i = 0; i < VW; i++) h[i] = (h[i] + (pend[i] ? 1 : 0)) & mask;
 #pragma unroll
         for (int i = 0; i < VW; i++) old[i] = atomicCAS(tab + h[i], -1, kk[i]);
+        NSP_COUNT(FC_HASH_LEAN, 1, VW);
         any = false;
 #pragma unroll
         for (int i = 0; i < VW; i++) {
@@ -308,6 +312,7 @@ __device__ __forceinline__ void lean_insert4(int *tab, int mask, int shift, int 
         for (int i = 0; i < VW; i++) {
             if (pend[i]) {
                 h[i] = (h[i] + 1) & mask;
+                NSP_COUNT(FC_HASH_LEAN, 1, 1);
                 const int o = atomicCAS(tab + h[i], -1, kk[i]);
                 fresh += o == -1;
                 pend[i] = o != -1 && o != kk[i];

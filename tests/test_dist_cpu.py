@@ -26,7 +26,8 @@ def _worker(rank, world, port, name, out):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
     import torch.distributed as dist
-    from nsparse_amd.dist import ShardedSpMV, csr_row_block, row_partition
+    from nsparse_amd.dist import csr_row_block, row_partition
+    from dist_driver import ShardedSpMV
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = load_golden(name)
@@ -82,7 +83,8 @@ def _worker_ragged(rank, world, port, name, out):
     import scipy.sparse as sp
     import torch
     import torch.distributed as dist
-    from nsparse_amd.dist import ShardedSpMV, csr_row_block, row_partition_nnz
+    from nsparse_amd.dist import csr_row_block, row_partition_nnz
+    from dist_driver import ShardedSpMV
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = load_golden(name)
@@ -124,7 +126,7 @@ def _worker_spgemm(rank, world, port, name, out):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import scipy.sparse as sp
     import torch.distributed as dist
-    from nsparse_amd.dist import ShardedSpGEMM
+    from dist_driver import ShardedSpGEMM
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = load_golden(name)

@@ -8,8 +8,8 @@ import numpy as np
 import pytest
 
 from gpu_util import DeviceAMB, spgemm, synth
-from nsparse_amd.dist import (ShardedSpGEMM, csr_row_block, make_gpu_local_spgemm, row_partition_nnz,
-                              row_partition_work, row_products)
+from nsparse_amd.dist import csr_row_block, row_partition_nnz, row_partition_work, row_products
+from dist_driver import ShardedSpGEMM, make_gpu_local_spgemm
 
 pytestmark = pytest.mark.gpu
 

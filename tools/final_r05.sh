@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-5 GPU run, ONE gpurun call; stages can be picked: bash tools/final_r05.sh [tests] [smoke] [bench] [ab] [spmv] [profiles]
+# The prepared GPU run (rounds 5-6), ONE gpurun call; stages can be picked: bash tools/final_r05.sh [tests] [smoke] [bench] [ab] [spmv] [profiles] [vprofiles]
 #   tests     the whole -m gpu suite, no -x (every failure is listed); each of the first failures is then re-run
 #             against the variant libraries nsparse_amd/lib_<commit>/ (built beforehand from git worktrees of the
 #             commits between the last proven tree and HEAD), so a red test names the commit that broke it
@@ -8,6 +8,9 @@
 #   ab        tools/ab_variants.sh: default kernels vs the lean hash forms and the stateless heavy-row tiles (one experiments library), serialised per-bin times
 #   spmv      cache-resident SpMV: split-row kernel widths against rocSPARSE csrmv
 #   profiles  per-config kernel stats + PMC (tools/profile_configs.sh)
+#   vprofiles the same for the R-MAT cases through the stateless heavy-row kernels of the variant library
+#             (nsparse_amd/lib_exp, NSPARSE_HEAVY_FLAT=7) -> gpurun_out/<tag>_flat/: kernel times AND the HBM traffic
+#             of k_num_flat / k_num_ranked_flat / k_sym_flat next to the cursor kernels' -- the A/B on bytes, not only on time
 export TMPDIR=/tmp
 TAG=${NSPARSE_TAG:-r05}
 O=gpurun_out/$TAG
@@ -67,6 +70,8 @@ print({k:s.get(k) for k in ('ms_per_spmv','ms_kernel_events','value','plan','ans
   done 2>&1 | tee $O/spmv_split.txt ;;
 profiles)
   bash tools/profile_configs.sh $TAG webbase1m stencil rmat18 rmat22 cant_irr 2>&1 | grep -E "^== " ;;
+vprofiles)
+  NSPARSE_LIB_DIR=$PWD/nsparse_amd/lib_exp NSPARSE_HEAVY_FLAT=7 bash tools/profile_configs.sh ${TAG}_flat rmat18 rmat22 2>&1 | grep -E "^== " ;;
 esac
 done
 echo "#### done $(date +%T)"
