@@ -28,23 +28,32 @@ namespace nsp {
 namespace spgemm {
 
 // slot_of[r] = table slot of B row r, -1 for rows outside the table; slot_row[s] = r; *count = slots in use.
-// ALL: every row has a slot (its own number).  Otherwise the rows longer than min_len, in whatever order the atomics
-// make it: the order names table rows, it does not reach the result.
+// ALL: every row has a slot (its own number).  Otherwise the rows longer than min_len, numbered by an exclusive scan of
+// their flags (k_panel_flags -> rocprim::exclusive_scan -> k_panel_slots<false>): ascending, deterministic, and no
+// atomics -- one returning atomic per long row on ONE counter would be 10^5 same-address device-scope atomics, which this
+// part serialises at ~20 ns each (HISTORY.md 4.1: why no kernel here counts that way).
 // (templates, like every kernel of this header: nothing of it is instantiated in a build that does not launch it)
+template <int DUMMY>
+__global__ __launch_bounds__(256) void k_panel_flags(const int *__restrict__ brpt, int m, int min_len, int *__restrict__ flag)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r <= m) flag[r] = r < m && brpt[r + 1] - brpt[r] > min_len ? 1 : 0;  // (flag[m] = 0: pos[m] is the count)
+}
+
 template <bool ALL>
 __global__ __launch_bounds__(256) void k_panel_slots(const int *__restrict__ brpt, int m, int min_len,
                                                      int *__restrict__ slot_of, int *__restrict__ slot_row,
-                                                     int *__restrict__ count, int slots_max)
+                                                     int *__restrict__ count, int slots_max, const int *__restrict__ pos)
 {
     const int r = blockIdx.x * 256 + threadIdx.x;
-    if (ALL && r == 0) *count = m;
+    if (r == 0) *count = ALL ? m : pos[m];
     if (r >= m) return;
     int s = -1;
     if (ALL) {
         s = r;
         slot_row[r] = r;
     } else if (brpt[r + 1] - brpt[r] > min_len) {
-        s = atomicAdd(count, 1);
+        s = pos[r];
         if (s < slots_max) slot_row[s] = r;
         else s = -1;  // (cannot happen: slots_max is an upper bound of the rows longer than min_len)
     }

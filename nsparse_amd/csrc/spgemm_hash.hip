@@ -441,17 +441,22 @@ static void build_panel_table(const sfCSR *b, BinLauncher &L, hipStream_t st)
         long long slots_max;
         panel_table_shape(b, np, min_len, slots_max);
         const bool all_rows = min_len < 0;
-        // one block: [count, pad | slot_of: M | slot_row: slots_max | tab: slots_max * (np + 1)]
-        const size_t n_ints = 2 + (size_t)b->M + (size_t)slots_max + (size_t)slots_max * (np + 1) + 2;
+        // one block: [count, pad | slot_of: M | slot_row: slots_max | tab: slots_max * (np + 1) | flag: M + 1 | pos: M + 1]
+        const size_t n_tab = (size_t)slots_max * (np + 1);
+        const size_t n_ints = 2 + (size_t)b->M + (size_t)slots_max + n_tab + 2 + (all_rows ? 0 : 2 * ((size_t)b->M + 1));
         int *blk = (int *)dev_alloc(sizeof(int) * n_ints);
         int *d_cnt = blk, *slot_of = blk + 2, *slot_row = slot_of + b->M, *tab = slot_row + slots_max;
-        NSP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(int), st));
-        if (all_rows)
+        if (all_rows) {
             hipLaunchKernelGGL(k_panel_slots<true>, dim3(ceil_div(b->M, 256)), dim3(256), 0, st, brpt, b->M, min_len,
-                               slot_of, slot_row, d_cnt, (int)slots_max);
-        else
+                               slot_of, slot_row, d_cnt, (int)slots_max, (const int *)nullptr);
+        } else {
+            int *flag = tab + n_tab + 2, *pos = flag + b->M + 1;
+            hipLaunchKernelGGL(k_panel_flags<0>, dim3(ceil_div(b->M + 1, 256)), dim3(256), 0, st, brpt, b->M, min_len, flag);
+            void *scan_tmp = scan_exclusive(flag, pos, b->M + 1, st);
             hipLaunchKernelGGL(k_panel_slots<false>, dim3(ceil_div(b->M, 256)), dim3(256), 0, st, brpt, b->M, min_len,
-                               slot_of, slot_row, d_cnt, (int)slots_max);
+                               slot_of, slot_row, d_cnt, (int)slots_max, (const int *)pos);
+            L.free_later(scan_tmp);  // (rocprim's scratch: back to the cache when the call has drained)
+        }
         const long long cells = slots_max * (np + 1);
         hipLaunchKernelGGL(k_panel_fill<kPanelW>, dim3((unsigned)((cells + 255) / 256)), dim3(256), 0, st, brpt, bcol,
                            (const int *)slot_row, (const int *)d_cnt, np, tab);
