@@ -88,7 +88,10 @@ __global__ __launch_bounds__(256) void k_panel_fill(const int *__restrict__ brpt
 // outside the table, ~where is the B row and its extent is the whole row (filtered by column later); kNoEntry: this
 // thread holds no entry of the batch.  The first kFlatEpt batches of BS entries keep (where, A value) in registers across
 // the tile loop, so that a tile starts with ONE gather -- the extents -- instead of the chain A.col -> slot -> extents;
-// further batches (rows of A with more than kFlatEpt * BS entries) walk the chain again for every tile.
+// further batches (hub rows of A: more than kFlatEpt * BS entries) keep theirs in the workgroup's slice of the heavy
+// bin's slab (the one the cursor kernels use for their state), written once per row and read back coalesced by the
+// thread that wrote it -- without it every tile repeats a random 4-byte gather of slot_of per entry.  (k_sym_flat has no
+// slab and walks the chain for those batches.)
 constexpr int kNoEntry = (int)0x80000000;
 constexpr int kFlatEpt = 2;
 __device__ __forceinline__ int flat_where(const int *__restrict__ acol, const int *__restrict__ slot_of, int tstride, int j)
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(BS) void k_num_flat(const int *__restrict__ arpt, c
                                                  BinState *bs, const int *__restrict__ row_lo,
                                                  const int *__restrict__ row_span, int write_col, int dens,
                                                  const long long *__restrict__ list_off, long long list_work,
-                                                 const int *__restrict__ row_prod)
+                                                 const int *__restrict__ row_prod,
+                                                 int *__restrict__ slab, long long stride_ints, int amax)
 {
     constexpr int NW = BS / 64;
     constexpr int V = VW, U = 4;
@@ -168,6 +172,14 @@ __global__ __launch_bounds__(BS) void k_num_flat(const int *__restrict__ arpt, c
                 e_av[u] = aval[j];
             }
         }
+        // hub rows: the entries beyond the register batches park theirs in the slab (entry e <-> thread e % BS, so every
+        // thread reads back what it wrote itself)
+        int *st_where = slab + (long long)blockIdx.x * stride_ints;
+        real *st_av = reinterpret_cast<real *>(st_where + amax);
+        for (int j = a_beg + kFlatEpt * BS + (int)threadIdx.x; j < a_end; j += BS) {
+            st_where[j - a_beg] = flat_where(acol, slot_of, tstride, j);
+            st_av[j - a_beg] = aval[j];
+        }
         for (int p = p_lo; p <= p_hi; p++) {
             const int c0 = p * W;
             if (threadIdx.x == 0) NSP_COUNT(FC_FLAT, 3, 1);
@@ -178,12 +190,12 @@ __global__ __launch_bounds__(BS) void k_num_flat(const int *__restrict__ arpt, c
                 int where = kb == 0 ? e_where[0] : e_where[kFlatEpt - 1];
                 real av = kb == 0 ? e_av[0] : e_av[kFlatEpt - 1];
                 static_assert(kFlatEpt == 2, "two batches in registers");
-                if (kb >= kFlatEpt) {  // (uniform) beyond the register batches: the chain again, cacheable loads
+                if (kb >= kFlatEpt) {  // (uniform) beyond the register batches: from the slab, coalesced
                     where = kNoEntry;
                     av = 0;
                     if ((int)threadIdx.x < nb) {
-                        where = flat_where(acol, slot_of, tstride, b0 + (int)threadIdx.x);
-                        av = aval[b0 + threadIdx.x];
+                        where = st_where[b0 - a_beg + (int)threadIdx.x];
+                        av = st_av[b0 - a_beg + (int)threadIdx.x];
                     }
                 }
                 const int2 e = flat_extent(brpt, tab, where, p, p + 1);  // (short rows: whole, filtered below)
@@ -309,7 +321,8 @@ __global__ __launch_bounds__(BS) void k_num_ranked_flat(const int *__restrict__ 
                                                         BinState *bs, const int *__restrict__ row_lo,
                                                         const int *__restrict__ row_span, int write_col, int dens, int tiled_w,
                                                         const int *__restrict__ tcol, const long long *__restrict__ list_off,
-                                                        long long list_work, const int *__restrict__ row_prod)
+                                                        long long list_work, const int *__restrict__ row_prod,
+                                                        int *__restrict__ slab, long long stride_ints, int amax)
 {
     constexpr int NW = BS / 64;
     constexpr int V = VW, U = 4;
@@ -363,6 +376,14 @@ __global__ __launch_bounds__(BS) void k_num_ranked_flat(const int *__restrict__ 
                 e_av[u] = aval[j];
             }
         }
+        // hub rows: the entries beyond the register batches park theirs in the slab (entry e <-> thread e % BS, so every
+        // thread reads back what it wrote itself)
+        int *st_where = slab + (long long)blockIdx.x * stride_ints;
+        real *st_av = reinterpret_cast<real *>(st_where + amax);
+        for (int j = a_beg + kFlatEpt * BS + (int)threadIdx.x; j < a_end; j += BS) {
+            st_where[j - a_beg] = flat_where(acol, slot_of, tstride, j);
+            st_av[j - a_beg] = aval[j];
+        }
         int k0 = 0;
         while (k0 < row_nnz) {
             if (threadIdx.x == 0) NSP_COUNT(FC_RANKED_FLAT, 3, 1);
@@ -400,12 +421,12 @@ __global__ __launch_bounds__(BS) void k_num_ranked_flat(const int *__restrict__ 
                 const int nb = a_end - b0 < BS ? a_end - b0 : BS;
                 int where = kb == 0 ? e_where[0] : e_where[kFlatEpt - 1];
                 real av = kb == 0 ? e_av[0] : e_av[kFlatEpt - 1];
-                if (kb >= kFlatEpt) {  // (uniform) beyond the register batches
+                if (kb >= kFlatEpt) {  // (uniform) beyond the register batches: from the slab, coalesced
                     where = kNoEntry;
                     av = 0;
                     if ((int)threadIdx.x < nb) {
-                        where = flat_where(acol, slot_of, tstride, b0 + (int)threadIdx.x);
-                        av = aval[b0 + threadIdx.x];
+                        where = st_where[b0 - a_beg + (int)threadIdx.x];
+                        av = st_av[b0 - a_beg + (int)threadIdx.x];
                     }
                 }
                 const int2 e = flat_extent(brpt, tab, where, p_a, p_bc);  // (short rows: whole, filtered below)

@@ -746,7 +746,7 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
                     hipLaunchKernelGGL((k_num_flat<1024, kTileW>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval, brpt, bcol,
                                        bval, b->nnz, (const int *)pt_slot_of, (const int *)pt_tab, pt_np + 1, c->d_rpt, c->d_col, c->d_val,
                                        row_perm, off[kNumGlobalBin], rows, d_bs, row_lo, row_span, write_col, ranked_dens,
-                                       list_off, list_w, row_prod);
+                                       list_off, list_w, row_prod, slab, stride_ints, amax);
                     flat_done = true;
                 }
             }
@@ -785,7 +785,8 @@ static BinLauncher numeric_phase(const sfCSR *a, const sfCSR *b, sfCSR *c, const
     hipLaunchKernelGGL((k_num_ranked_flat<1024, WX, CAPX, kTileW>), dim3(groups), dim3(1024), 0, st, arpt, acol, aval, brpt, \
                        bcol, bval, b->nnz, (const int *)pt_slot_of, (const int *)pt_tab, pt_np + 1, c->d_rpt, c->d_col,    \
                        c->d_val, row_perm, off[kNumGlobalBin], rows, d_bs, row_lo, row_span, write_col, ranked_dens,       \
-                       tile_sel == 0 ? kTileW : (tile_sel == 3 ? kTileW / 4 : kTileW / 2), tcol, list_off, list_w, row_prod)
+                       tile_sel == 0 ? kTileW : (tile_sel == 3 ? kTileW / 4 : kTileW / 2), tcol, list_off, list_w, row_prod, \
+                       slab, stride_ints, amax)
                     if (ranked_sel == 1) { NSP_RANKED_FLAT(524288, 5120); }
                     else { NSP_RANKED_FLAT(262144, kRankCap); }
 #undef NSP_RANKED_FLAT

@@ -57,9 +57,10 @@ def test_rmat14_heavy_rows(prec, lib_d, lib_s, oracle_d, oracle_s):
 
 
 def test_hub_rows_of_a_and_empty_tiles(oracle_d):
-    """Rows of A with ~3000 entries (three batches of the flat walk, the last one partial) over a B that mixes rows of
-    2-3 entries with rows of thousands, whose columns leave panels 2 and 3 of 6 empty (a tile without a product emits
-    nothing and leaves the window clean)."""
+    """Rows of A with 5000 entries (five batches of the flat walk: two whose extent locations stay in registers, three
+    that park them in the heavy bin's slab, the last one partial) over a B that mixes rows of 2-3 entries with rows of
+    thousands, whose columns leave panels 2 and 3 of 6 empty (a tile without a product emits nothing and leaves the
+    window clean)."""
     import scipy.sparse as sp
     rng = np.random.default_rng(61)
     k, n = 6000, 6 * 12288
@@ -71,8 +72,8 @@ def test_hub_rows_of_a_and_empty_tiles(oracle_d):
         cols.append(rng.choice(allowed, size=ln, replace=False))
     rows, cols = np.concatenate(rows), np.concatenate(cols)
     B = csr(sp.coo_matrix((rng.random(len(rows)) + 0.5, (rows, cols)), shape=(k, n)))
-    ar = np.repeat(np.arange(6), 3000)
-    ac = np.concatenate([rng.choice(k, size=3000, replace=False) for _ in range(6)])
+    ar = np.repeat(np.arange(6), 5000)
+    ac = np.concatenate([rng.choice(k, size=5000, replace=False) for _ in range(6)])
     A = csr(sp.coo_matrix((rng.random(len(ar)) + 0.5, (ar, ac)), shape=(6, k)))
     ref = oracle_d.spgemm(A, B)
     assert ref["row_nz"].min() > 5461
@@ -126,6 +127,24 @@ def test_window_wider_than_the_bitmap_with_lists(oracle_d):
     for bits in ("4", "3"):  # stateless symbolic + cursor numeric, and the other way round: the lists are interchangeable
         g, _ = flat(A, B, NSPARSE_HEAVY_FLAT=bits)
         assert_parity(oracle_d, g, ref)
+
+
+def test_hub_rows_of_a_on_a_wide_matrix(oracle_d):
+    """2.2 M columns, rows of A with 2600 entries: the thin heavy rows go through k_sym_flat (the chain for the batch
+    beyond its two register batches) and k_num_ranked_flat (that batch from the slab), several list-driven tiles each."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(78)
+    m, k, n = 5, 3000, 2_200_000
+    ar = np.repeat(np.arange(m), 2600)
+    ac = np.concatenate([rng.choice(k, size=2600, replace=False) for _ in range(m)])
+    A = csr(sp.coo_matrix((rng.random(len(ar)) + 0.5, (ar, ac)), shape=(m, k)))
+    B = csr(sp.random(k, n, density=40 / n, format="csr", random_state=rng, dtype=np.float64))
+    ref = oracle_d.spgemm(A, B)
+    assert ref["row_nz"].min() > 8192
+    got, st = flat(A, B, numeric_again=True)
+    assert st["num"][5] == m and st["sym"][10] == m
+    assert_parity(oracle_d, got, ref)
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9)
 
 
 @pytest.mark.parametrize("dens", ["-1", "12"])
