@@ -175,3 +175,39 @@ def test_config5_code_paths_through_the_stateless_tiles(lib_d, oracle_d):
     assert oracle_d.check_spgemm(got, dict(ref, M=A["M"])) == 0
     assert np.array_equal(got["col_again"], got["col"])
     np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_heavy_rows_at_panel_and_batch_edges(seed, oracle_d):
+    """Randomised heavy rows whose sizes sit ON the edges of the stateless kernels: matrix widths that are exact multiples
+    of the 12288-column panel (and one more), column windows that start and end exactly on panel boundaries, rows of A
+    with 1023 .. 2049 and 4100 entries (the 1024-entry batches, the two register batches, the slab batches), narrow
+    matrices (dense tiles, every row of B in the table) and matrices wider than 2^20 columns (symbolic twin, lists,
+    ranked tiles)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(4000 + seed)
+    G = 12288
+    n = int([3 * G, 3 * G + 1, 7 * G - 1, 50_000, 1_100_000 + seed, 86 * G, 2_300_000, 5 * G][seed])
+    k = 4500
+    lo_p = int(rng.integers(0, max(1, n // G - 2)))
+    c_lo = lo_p * G if seed % 2 == 0 else int(rng.integers(0, max(1, n - 2 * G)))
+    width = n - c_lo if n <= 100_000 else int(rng.choice([2 * G, 85 * G, n - c_lo]))
+    c_hi = min(n, c_lo + max(width, 2 * G))
+    lens = np.where(rng.random(k) < 0.06, rng.integers(300, 1500, k), rng.integers(0, 5, k))
+    lens = np.minimum(lens, c_hi - c_lo)
+    rows = np.concatenate([np.full(ln, r) for r, ln in enumerate(lens)])
+    cols = np.concatenate([c_lo + rng.choice(c_hi - c_lo, size=ln, replace=False) for ln in lens if ln > 0] or [np.zeros(0, int)])
+    B = csr(sp.coo_matrix((rng.random(len(rows)) + 0.5, (rows, cols)), shape=(k, n)))
+    alens = [1023, 1024, 2048, 2049, 4100]
+    m = 5
+    ar = np.concatenate([np.full(a, i) for i, a in enumerate(alens)])
+    ac = np.concatenate([rng.choice(k, size=a, replace=False) for a in alens])
+    A = csr(sp.coo_matrix((rng.random(len(ar)) + 0.5, (ar, ac)), shape=(m, k)))
+    ref = oracle_d.spgemm(A, B)
+    heavy = int((ref["row_nz"] > 5461).sum())
+    assert heavy >= 3, ref["row_nz"]
+    got, st = flat(A, B, numeric_again=True)
+    assert st["num"][5] == heavy
+    assert_parity(oracle_d, got, ref)
+    assert np.array_equal(got["col_again"], got["col"])
+    np.testing.assert_allclose(got["val_again"], got["val"], rtol=1e-9)
